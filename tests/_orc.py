@@ -1,0 +1,275 @@
+"""ctypes binding of oracle/liboracle.so (the CPU checker) for tests, smoke() and
+bench.py's cpu_baseline leg.  TEST INFRASTRUCTURE ONLY -- never imported by cafe_amd."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+def _build():
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    src = os.path.join(ORACLE_DIR, "cafe_oracle.c")
+    if (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class Range(C.Structure):
+    _fields_ = [("min", C.c_int), ("max", C.c_int), ("root_min", C.c_int), ("root_max", C.c_int)]
+
+
+class Tree(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int),
+        ("parent", C.POINTER(C.c_int)),
+        ("left", C.POINTER(C.c_int)),
+        ("right", C.POINTER(C.c_int)),
+        ("branchlength", C.POINTER(C.c_double)),
+        ("root", C.c_int),
+    ]
+
+
+MATH_FUNC = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_void_p)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(_build())
+    L.orc_gammaln.restype = C.c_double
+    L.orc_gammaln.argtypes = [C.c_double]
+    L.orc_chooseln.restype = C.c_double
+    L.orc_chooseln.argtypes = [C.c_double, C.c_double]
+    L.orc_poisspdf.restype = C.c_double
+    L.orc_poisspdf.argtypes = [C.c_int, C.c_double]
+    L.orc_pvalue.restype = C.c_double
+    L.orc_pvalue.argtypes = [C.c_double, _dp, C.c_int]
+    L.orc_chooseln_table.restype = C.POINTER(C.c_double)
+    L.orc_chooseln_table.argtypes = [C.c_int]
+    L.orc_birthdeath_rate_with_log_alpha.restype = C.c_double
+    L.orc_birthdeath_rate_with_log_alpha.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp, C.c_int]
+    L.orc_birthdeath_rate_with_log_alpha_beta.restype = C.c_double
+    L.orc_birthdeath_rate_with_log_alpha_beta.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _dp, C.c_int]
+    L.orc_birthdeath_likelihood_with_s_c.restype = C.c_double
+    L.orc_birthdeath_likelihood_with_s_c.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _dp, C.c_int]
+    L.orc_compute_birthdeath_rates.restype = None
+    L.orc_compute_birthdeath_rates.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, _dp]
+    L.orc_square_matrix_multiply.restype = None
+    L.orc_square_matrix_multiply.argtypes = [_dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
+    L.orc_matrices_build.restype = C.c_void_p
+    L.orc_matrices_build.argtypes = [C.POINTER(Tree), _dp, _dp, C.c_int, C.c_int]
+    L.orc_matrices_nkeys.restype = C.c_int
+    L.orc_matrices_nkeys.argtypes = [C.c_void_p]
+    L.orc_matrices_size.restype = C.c_int
+    L.orc_matrices_size.argtypes = [C.c_void_p]
+    L.orc_matrices_get.restype = C.POINTER(C.c_double)
+    L.orc_matrices_get.argtypes = [C.c_void_p, C.c_int]
+    L.orc_matrices_free.restype = None
+    L.orc_matrices_free.argtypes = [C.c_void_p]
+    L.orc_compute_tree_likelihoods.restype = None
+    L.orc_compute_tree_likelihoods.argtypes = [C.POINTER(Tree), C.POINTER(Range), C.c_void_p, _ip, _dp, C.c_int,
+                                               C.POINTER(C.c_ubyte), _dp, C.c_int]
+    L.orc_compute_posterior.restype = None
+    L.orc_compute_posterior.argtypes = [_dp, C.c_int, _dp, _dp, _ip, _dp]
+    L.orc_eval_posterior.restype = C.c_double
+    L.orc_eval_posterior.argtypes = [C.POINTER(Tree), C.c_int, C.c_int, _ip, _ip, C.POINTER(Range), _dp, _dp, _dp,
+                                     _dp, C.c_int, C.POINTER(C.c_ubyte), C.c_int, _ip, _dp, _ip, _dp]
+    L.orc_eval_root_likelihoods.restype = None
+    L.orc_eval_root_likelihoods.argtypes = [C.POINTER(Tree), C.c_int, C.c_int, _ip, _ip, _ip, _ip, C.c_void_p, _dp]
+    L.orc_init_family_size.restype = None
+    L.orc_init_family_size.argtypes = [C.POINTER(Range), C.c_int]
+    L.orc_family_check_the_pattern.restype = None
+    L.orc_family_check_the_pattern.argtypes = [C.c_int, C.c_int, _ip, _ip]
+    L.orc_prior_poisson.restype = None
+    L.orc_prior_poisson.argtypes = [_dp, C.c_int, C.c_int, C.c_double]
+    L.orc_lnLPoisson.restype = C.c_double
+    L.orc_lnLPoisson.argtypes = [C.c_double, C.c_int, C.c_int, _ip]
+    L.orc_find_poisson_lambda.restype = C.c_double
+    L.orc_find_poisson_lambda.argtypes = [C.c_int, C.c_int, _ip, C.c_double, _ip, _dp]
+    L.orc_fminsearch.restype = C.c_int
+    L.orc_fminsearch.argtypes = [MATH_FUNC, C.c_int, C.c_void_p, _dp, C.c_double, C.c_double, C.c_int, _dp, _dp, _ip]
+    L.orc_conditional_distribution.restype = None
+    L.orc_conditional_distribution.argtypes = [C.POINTER(Tree), C.POINTER(Range), C.c_void_p, C.c_int, _dp]
+    L.orc_tree_random_familysize.restype = C.c_int
+    L.orc_tree_random_familysize.argtypes = [C.POINTER(Tree), C.c_void_p, C.c_int, C.c_int, _ip]
+    _lib = L
+    return L
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+# ---------------------------------------------------------------------------
+# A tiny independent Newick reader for the tests (topology + branch lengths in the
+# reference's in-order nlist numbering, cafe/cafe_commands.cpp:2028-2051).
+# ---------------------------------------------------------------------------
+class PyTree:
+    def __init__(self, newick):
+        s = newick.strip().rstrip(";")
+        self.names, self.bl, self.children = [], [], []
+        pos = [0]
+
+        def parse():
+            node = len(self.names)
+            self.names.append("")
+            self.bl.append(-1.0)
+            self.children.append([])
+            if s[pos[0]] == "(":
+                pos[0] += 1
+                while True:
+                    ch = parse()
+                    self.children[node].append(ch)
+                    if s[pos[0]] == ",":
+                        pos[0] += 1
+                        continue
+                    assert s[pos[0]] == ")"
+                    pos[0] += 1
+                    break
+            j = pos[0]
+            while j < len(s) and s[j] not in ",():":
+                j += 1
+            self.names[node] = s[pos[0]:j]
+            pos[0] = j
+            if j < len(s) and s[j] == ":":
+                k = j + 1
+                while k < len(s) and s[k] not in ",()":
+                    k += 1
+                self.bl[node] = float(s[j + 1:k])
+                pos[0] = k
+            return node
+
+        root = parse()
+        order = []
+
+        def inorder(n):
+            if self.children[n]:
+                assert len(self.children[n]) == 2, "binary trees only"
+                inorder(self.children[n][0])
+                order.append(n)
+                inorder(self.children[n][1])
+            else:
+                order.append(n)
+
+        inorder(root)
+        idmap = {old: new for new, old in enumerate(order)}
+        n = len(order)
+        self.n_nodes = n
+        self.parent = np.full(n, -1, np.int32)
+        self.left = np.full(n, -1, np.int32)
+        self.right = np.full(n, -1, np.int32)
+        self.branchlength = np.full(n, -1.0, np.float64)
+        self.name = [""] * n
+        for old in range(n):
+            i = idmap[old]
+            self.name[i] = self.names[old]
+            self.branchlength[i] = self.bl[old]
+            if self.children[old]:
+                a, b = self.children[old]
+                self.left[i], self.right[i] = idmap[a], idmap[b]
+                self.parent[idmap[a]] = i
+                self.parent[idmap[b]] = i
+        self.root = idmap[root]
+        self.leaf_names = [self.name[i] for i in range(0, n, 2)]
+        self.n_leaves = (n + 1) // 2
+
+    def ctree(self):
+        t = Tree()
+        t.n_nodes = self.n_nodes
+        t.parent = iptr(self.parent)
+        t.left = iptr(self.left)
+        t.right = iptr(self.right)
+        t.branchlength = dptr(self.branchlength)
+        t.root = self.root
+        self._keep = t
+        return t
+
+
+def make_range(mn, mx, rmin, rmax):
+    r = Range()
+    r.min, r.max, r.root_min, r.root_max = mn, mx, rmin, rmax
+    return r
+
+
+def range_from_max(m):
+    r = Range()
+    lib().orc_init_family_size(C.byref(r), int(m))
+    return r
+
+
+def eval_posterior(tree, counts, rng, node_lambda, node_mu, prior, ref=None, errormatrix=None, err_mfs=0,
+                   leaf_has_err=None, nthreads=1):
+    L = lib()
+    counts = np.ascontiguousarray(counts, np.int32)
+    F, nl = counts.shape
+    nlam = np.ascontiguousarray(node_lambda, np.float64)
+    nmu = np.ascontiguousarray(node_mu, np.float64)
+    prior = np.ascontiguousarray(prior, np.float64)
+    ml = np.zeros(F)
+    mp = np.zeros(F)
+    am = np.zeros(F, np.int32)
+    fz = C.c_int(-1)
+    refp = iptr(np.ascontiguousarray(ref, np.int32)) if ref is not None else None
+    errp = dptr(np.ascontiguousarray(errormatrix, np.float64)) if errormatrix is not None else None
+    lhe = None
+    if leaf_has_err is not None:
+        lhe_arr = np.ascontiguousarray(leaf_has_err, np.uint8)
+        lhe = lhe_arr.ctypes.data_as(C.POINTER(C.c_ubyte))
+    t = tree.ctree()
+    score = L.orc_eval_posterior(C.byref(t), F, nl, iptr(counts), refp, C.byref(rng), dptr(nlam), dptr(nmu),
+                                 dptr(prior), errp, err_mfs, lhe, nthreads, C.byref(fz), dptr(ml), iptr(am), dptr(mp))
+    return score, fz.value, ml, am, mp
+
+
+def birthdeath_matrix(bl, lam, mu, M):
+    out = np.zeros((M + 1, M + 1))
+    lib().orc_compute_birthdeath_rates(float(bl), float(lam), float(mu), int(M), dptr(out))
+    return out
+
+
+def prior_poisson(n, shift, lam):
+    p = np.zeros(n)
+    lib().orc_prior_poisson(dptr(p), n, shift, float(lam))
+    return p
+
+
+def load_family_table(path, max_size=-1, sep="\t"):
+    """Family table reader following cafe/gene_family.cpp:186-225: header 'Desc ID sp...', rows
+    kept when max(count) <= max_size (or max_size < 0)."""
+    import gzip
+    op = gzip.open if path.endswith(".gz") else open
+    with op(path, "rt") as f:
+        header = f.readline().rstrip("\r\n").split(sep)
+        species = header[2:]
+        ids, rows = [], []
+        for line in f:
+            line = line.rstrip("\r\n")
+            if not line:
+                continue
+            parts = line.split(sep)
+            vals = [int(x) for x in parts[2:]]
+            if max_size < 0 or max(vals) <= max_size:
+                ids.append(parts[1])
+                rows.append(vals)
+    return species, ids, np.asarray(rows, np.int32)
+
+
+def reorder_to_tree(species, counts, tree):
+    """Column for leaf slot j <-> node 2j; species matched case-insensitively by name
+    (cafe/gene_family.cpp:413-445)."""
+    low = [s.lower() for s in species]
+    cols = [low.index(nm.lower()) for nm in tree.leaf_names]
+    return np.ascontiguousarray(counts[:, cols])
