@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""bench.py -- family-likelihood evaluations per second of the HIP hot path.
+
+A "step" is ONE objective evaluation (reset_birthdeath_cache + get_posterior,
+cafe/cafe_main.c:319-326 + cafe/lambda.cpp:691-724) over the whole count table of
+BASELINE.json configs[1]: 10k synthetic families per GPU, 16-taxon tree, max family size 100,
+single lambda.  Every step uses a different lambda (as the optimiser does), builds all
+transition matrices, prunes every family, reduces the score and returns it to the host.
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 run under torch.distributed.run: one process per GPU, families sharded (weak scaling:
+10k families per GPU), one RCCL all-gather of the per-chunk partial sums + one all-reduce(min) of
+the first-zero index per step.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak
+
+
+def algorithmic_bytes_per_family(n_leaves, R, C):
+    """SURVEY.md section 8(d) B_alg: the reference streams a dense sub-matrix on every child edge:
+    8 * (2*R*C + (E-2)*C*C) bytes per family evaluation, E = 2n-2 edges."""
+    E = 2 * n_leaves - 2
+    return 8.0 * (2.0 * R * C + (E - 2.0) * C * C)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--families", type=int, default=None, help="families per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d processes (WORLD_SIZE=%d)"
+                         % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import cafe_amd
+    from cafe_amd import prior as cprior
+    from cafe_amd import synth
+    from cafe_amd import tree as ctree
+
+    # ---- workload: this rank's shard of the family table -------------------------------
+    cfg = dict(synth.CONFIGS[args.config])
+    F_local = args.families or cfg["F"]
+    newick = synth.random_ultrametric_newick(cfg["n_taxa"], cfg["seed"])
+    tree = ctree.CafeTree(newick)
+    counts = synth.simulate_families(tree, F_local, cfg["m"], cfg["lam"], cfg["mu"], cfg["seed"] + 1 + rank)
+    rng = cafe_amd.init_family_size(cfg["m"])
+    R = rng.root_max - rng.root_min + 1
+    C = rng.max - rng.min + 1
+    lam_p = cprior.poisson_lambda_mle(counts)
+    prior = cprior.prior_rfsize_poisson(rng.root_min, lam_p)
+
+    eng = cafe_amd.Engine(local_rank)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+    tree.apply(eng)
+    eng.set_families(counts, rng)
+    n_chunks = eng.num_chunks()
+    eng.enable_timing(True)
+
+    d_chunks = torch.zeros(n_chunks, dtype=torch.float64, device="cuda")
+    d_fz = torch.zeros(1, dtype=torch.int32, device="cuda")
+    if world > 1:
+        d_all = torch.zeros(n_chunks * world, dtype=torch.float64, device="cuda")
+    has_mu = cfg["mu"] >= 0
+
+    def node_rates(step):
+        lam = cfg["lam"] * (1.0 + 0.003 * (step % 97))
+        nl = np.full(tree.n_nodes, lam)
+        nm = np.full(tree.n_nodes, cfg["mu"] * (1.0 + 0.002 * (step % 89)) if has_mu else -1.0)
+        return nl, nm
+
+    kernel_ms = []
+
+    def one_step(step):
+        nl, nm = node_rates(step)
+        if world == 1:
+            score, fz = eng.get_posterior(nl, nm, prior)
+            kernel_ms.append(eng.last_kernel_ms())
+            return score
+        eng.eval_posterior_async(nl, nm, prior, d_chunks.data_ptr(), d_fz.data_ptr())
+        dist.all_gather_into_tensor(d_all, d_chunks)
+        fzg = torch.where(d_fz < F_local, d_fz + rank * F_local, torch.full_like(d_fz, 2**31 - 1))
+        dist.all_reduce(fzg, op=dist.ReduceOp.MIN)
+        host = d_all.cpu()                    # the optimiser needs the value on the host
+        fz = int(fzg.item())
+        score = float(host.numpy().sum()) if fz == 2**31 - 1 else -math.inf
+        return score
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for s in range(args.warmup):
+        last = one_step(s)
+    kernel_ms.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        last = one_step(args.warmup + s)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    total_families = F_local * world
+    value = total_families * args.steps / dt
+    out = {
+        "metric": "family-likelihood evals/sec (full tree)",
+        "value": value,
+        "unit": "family-evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE.json configs[1]: %s; %d families per GPU, R=%d root sizes, %dx%d matrices, "
+                        "%d edges, one objective evaluation (matrix build + pruning + posterior + score) per step"
+                        % (cfg["desc"], F_local, R, C, C, 2 * tree.n_leaves - 2),
+            "families_per_gpu": F_local,
+            "n_taxa": cfg["n_taxa"],
+            "max_family_size": cfg["m"],
+            "parallelism": "families sharded x%d" % world,
+            "last_score": last,
+        },
+    }
+
+    if rank == 0 and world == 1 and kernel_ms:
+        km = np.array(kernel_ms)  # columns: K1 matrix build, K2 pruning+posterior, K3 score
+        k2_ms = float(km[:, 1].mean())
+        b_alg = algorithmic_bytes_per_family(tree.n_leaves, R, C)
+        achieved = b_alg * F_local / (k2_ms * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm",
+            "kernel": "k2_prune (pruning + posterior, all families in one launch)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_family": b_alg,
+            "families_per_launch": F_local,
+            "avg_launch_ms": k2_ms,
+            "note": "B_alg is the reference-faithful streaming cost (SURVEY.md 8d): an EFFECTIVE bandwidth, "
+                    "the matrices are shared by all families and stay cache resident",
+        }
+        f_alg = b_alg / 4.0  # 2 flops per 8-byte matrix element
+        out["roofline_fp64"] = {
+            "achieved": f_alg * F_local / (k2_ms * 1e-3) / 1e12,
+            "peak": FP64_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": f_alg * F_local / (k2_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            "note": "credited with the reference's dense product on every edge (leaf edges are gathers here)",
+        }
+        out["kernel_ms"] = {"k1_matrix_build": float(km[:, 0].mean()), "k2_prune": k2_ms,
+                            "k3_score": float(km[:, 2].mean())}
+        out["engine"] = eng.describe()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(newick, counts, rng, prior, cfg, eng, tree)
+
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(newick, counts, rng, prior, cfg, eng, tree):
+    """The oracle (CPU restatement of the reference algorithm, dense mat-vec on every edge) timed
+    on this box's host cores on a bounded sample of the same table; also used to cross-check the
+    GPU values of that sample."""
+    from tests import _orc as O
+    t = O.PyTree(newick)
+    orng = O.make_range(rng.min, rng.max, rng.root_min, rng.root_max)
+    lam = np.full(t.n_nodes, cfg["lam"])
+    mu = np.full(t.n_nodes, cfg["mu"] if cfg["mu"] >= 0 else -1.0)
+    cores = os.cpu_count() or 1
+    probe = counts[:64]
+    t0 = time.perf_counter()
+    O.eval_posterior(t, probe, orng, lam, mu, prior, nthreads=1)
+    t1 = time.perf_counter() - t0
+    per_fam_1t = t1 / len(probe)
+    n_1t = int(max(64, min(len(counts), 4.0 / per_fam_1t)))
+    t0 = time.perf_counter()
+    O.eval_posterior(t, counts[:n_1t], orng, lam, mu, prior, nthreads=1)
+    rate_1t = n_1t / (time.perf_counter() - t0)
+    n_mt = int(max(256, min(len(counts), 8.0 * rate_1t * cores * 0.5)))
+    t0 = time.perf_counter()
+    so, fzo, mlo, amo, mpo = O.eval_posterior(t, counts[:n_mt], orng, lam, mu, prior, nthreads=cores)
+    rate_mt = n_mt / (time.perf_counter() - t0)
+    # parity of the same sample on the GPU
+    eng.set_families(counts[:n_mt], rng)
+    sg, fzg, mlg, amg, mpg = eng.get_posterior(lam, mu, prior, per_family=True)
+    rel = float(np.max(np.abs(np.log(mpg) - np.log(mpo)) / np.abs(np.log(mpo))))
+    return {
+        "value": rate_mt,
+        "unit": "family-evals/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "one objective evaluation of the first %d families of the bench table, OpenMP over "
+                  "families on %d threads (includes the matrix build)" % (n_mt, cores),
+        "single_thread_value": rate_1t,
+        "single_thread_sample": "first %d families, 1 thread" % n_1t,
+        "gpu_vs_oracle_max_rel_err_log_posterior": rel,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,67 @@
+"""ctypes binding of the C ABI declared in include/cafehip.h.
+
+There is no fallback of any kind: if libcafehip.so is missing it is built with hipcc, and if it
+cannot be built or loaded an exception is raised.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes); must list every symbol of include/cafehip.h
+SIGNATURES = {
+    "cafehip_abi_version": (C.c_int, []),
+    "cafehip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "cafehip_destroy": (None, [C.c_void_p]),
+    "cafehip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cafehip_set_tree": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _dp]),
+    "cafehip_set_families": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "cafehip_set_error_model": (C.c_int, [C.c_void_p, C.c_int, _dp, _u8p]),
+    "cafehip_eval_posterior": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip, _dp, _ip, _dp]),
+    "cafehip_eval_posterior_async": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_void_p, C.c_void_p]),
+    "cafehip_num_chunks": (C.c_int, [C.c_void_p]),
+    "cafehip_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int)]),
+    "cafehip_matrix_size": (C.c_int, [C.c_void_p]),
+    "cafehip_reset_birthdeath_cache": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "cafehip_eval_root_likelihoods": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip, _dp]),
+    "cafehip_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "cafehip_last_kernel_ms": (C.c_int, [C.c_void_p, _dp]),
+    "cafehip_describe": (C.c_char_p, [C.c_void_p]),
+    "cafehip_last_error": (C.c_char_p, []),
+}
+
+CHUNK = 256  # CAFEHIP_CHUNK
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building first if needed) libcafehip.so and bind every ABI symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build()
+    L = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class CafeHipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise CafeHipError(load().cafehip_last_error().decode("utf-8", "replace"))

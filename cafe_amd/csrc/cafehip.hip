@@ -1,0 +1,1072 @@
+// cafehip.hip -- MI355X (gfx950) kernels and C ABI for CAFE's per-family likelihood
+// hot path.  See include/cafehip.h for the boundary and DESIGN.md for the layout.
+//
+//   K1  k1_build_matrices   birth-death transition matrices for every unique
+//                           (int branch length, lambda, mu) key of one evaluation
+//                           == compute_birthdeath_rates, libtree/birthdeath.c:238-286
+//   K2  k2_prune_*          post-order pruning of ALL families in one launch + the
+//                           per-family posterior == compute_tree_likelihoods +
+//                           compute_posterior, cafe/cafe_tree.c:191-323, cafe/lambda.cpp:657-689
+//   K3  k3_score            per-chunk sums of log max-posterior in family order and the
+//                           first zero-likelihood family == get_posterior, cafe/lambda.cpp:691-724
+//
+// gfx950 only.  No CPU fallback: every entry point fails if the device work fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/cafehip.h"
+#include "host_math.hpp"
+#include "schedule.hpp"
+
+namespace {
+
+constexpr int kMaxNodes = 256;   // up to 128 taxa
+constexpr int kMaxPrior = 1000;  // FAMILYSIZEMAX, libtree/family.h:8
+constexpr int kMaxLeaves = kMaxNodes / 2;
+constexpr int kParamRing = 8;
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                        \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// device-side parameter blocks
+// ------------------------------------------------------------------------------------
+struct KeyParam {
+    double log_alpha, log_beta, log_coeff, coeff;
+    int mode;  // host_math.hpp KeyScalars
+    int bl;
+};
+
+struct EvalParams {
+    int nkeys;
+    int pad;
+    int node_key[kMaxNodes];
+    KeyParam keys[kMaxNodes];
+    double logprior[kMaxPrior];
+};
+
+struct K2Args {
+    const double* PT;        // [nkeys][KP][LD]  PT[k][c*LD + s] = Pr(c | s)
+    const EvalParams* ep;
+    const cafehip::PruneOp* ops;
+    int n_ops;
+    const int32_t* counts;   // [Fu][n_leaves]
+    int Fu;
+    int n_leaves;
+    int C;                   // range_max + 1 (range_min == 0)
+    int R;                   // root_max - root_min + 1
+    int root_min;
+    int LD, KP, LDv;
+    int n_slots;
+    // error model (optional)
+    const double* err;       // [(mfs+1)^2] row = observed
+    int err_ld;
+    const uint8_t* leaf_has_err;  // [n_leaves] by count column
+    // per-row extents (batch mode; NULL in posterior mode)
+    const int32_t* root_lo;
+    const int32_t* root_hi;
+    const int32_t* col_max;
+    const int64_t* out_off;  // packed offsets of the root vectors
+    double* out_root;
+    // posterior outputs
+    double* max_lik;
+    int32_t* argmax;
+    double* max_post;
+};
+
+// ------------------------------------------------------------------------------------
+// K1: transition matrices.  One 16x16 tile of (s, c) entries per workgroup; the 16
+// consecutive s of a tile are the fast lane index so that the transposed store
+// PT[c][s] is 128 B contiguous.  The two ln C runs of each of the 16 rows are staged
+// in LDS (odd row stride -> conflict-free ds_read_b64).
+// Arithmetic follows libtree/birthdeath.c:52-73 / :34-50 term by term, j ascending,
+// running product for coeff^j, clamp to [0,1]; contraction is off so each term is the
+// same sequence of IEEE operations as the reference's x86-64 build.
+// ------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __restrict__ ep,
+                                                         const double* __restrict__ lncA,
+                                                         const double* __restrict__ lncB,
+                                                         int ld_lnc, double* __restrict__ PT,
+                                                         int M, int LD, int KP, int use_lds)
+{
+    extern __shared__ double k1_smem[];
+    const int key = blockIdx.z;
+    const int s0 = blockIdx.y * 16;
+    const int c0 = blockIdx.x * 16;
+    const int tx = threadIdx.x & 15;  // s within tile
+    const int ty = threadIdx.x >> 4;  // c within tile
+    const int s = s0 + tx;
+    const int c = c0 + ty;
+    const KeyParam kp = ep->keys[key];
+    double* P = PT + (size_t)key * KP * LD;
+
+    if (kp.mode < 2) {
+        // zero / identity matrices; row 0 is e_0 in every mode (libtree/birthdeath.c:244, :212-215)
+        if (s <= M && c <= M) {
+            double v = 0.0;
+            if (s == 0)
+                v = (c == 0) ? 1.0 : 0.0;
+            else if (kp.mode == 1)
+                v = (s == c) ? 1.0 : 0.0;
+            P[(size_t)c * LD + s] = v;
+        }
+        return;
+    }
+    // stage lnC runs: A needs j <= min(s, c) <= min(s0, c0) + 15; B needs i = c - j <= c0 + 15
+    const int nA = min(min(s0, c0) + 16, M + 1);
+    const int nB = min(c0 + 16, M + 1);
+    double* sA = k1_smem;                      // [16][ld_lnc]
+    double* sB = k1_smem + 16 * (size_t)ld_lnc;  // [16][ld_lnc]
+    if (use_lds) {
+        for (int r = 0; r < 16; ++r) {
+            const int sr = s0 + r;
+            if (sr > M) break;
+            const double* ga = lncA + (size_t)sr * ld_lnc;
+            const double* gb = lncB + (size_t)sr * ld_lnc;
+            for (int i = threadIdx.x; i < nA; i += 256) sA[r * ld_lnc + i] = ga[i];
+            for (int i = threadIdx.x; i < nB; i += 256) sB[r * ld_lnc + i] = gb[i];
+        }
+        __syncthreads();
+    }
+    if (s > M || c > M) return;
+    double p;
+    if (s == 0) {
+        p = (c == 0) ? 1.0 : 0.0;
+    } else {
+        const double* a = use_lds ? sA + tx * ld_lnc : lncA + (size_t)s * ld_lnc;
+        const double* b = use_lds ? sB + tx * ld_lnc : lncB + (size_t)s * ld_lnc;
+        const int m = min(s, c);
+        p = 0.0;
+        if (kp.mode == 2) {
+            double lastterm = 1.0;
+            const int s_add_c = s + c;
+            for (int j = 0; j <= m; ++j) {
+                const double t = a[j] + b[c - j] + (double)(s_add_c - 2 * j) * kp.log_alpha;
+                p += exp(t) * lastterm;
+                lastterm *= kp.coeff;
+            }
+        } else {
+            for (int j = 0; j <= m; ++j) {
+                const double t = a[j] + b[c - j] + (double)(s - j) * kp.log_alpha +
+                                 (double)(c - j) * kp.log_beta + (double)j * kp.log_coeff;
+                p += exp(t);
+            }
+        }
+        p = fmax(fmin(p, 1.0), 0.0);  // MAX(MIN(p,1),0)
+    }
+    P[(size_t)c * LD + s] = p;
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------------------------
+// K2 (v1, vector FMA): one workgroup carries NF families through the whole tree.
+// Thread r owns output row r of every node vector; node vectors live in LDS slots
+// [slot][fam][LDv].  Per child edge the thread streams its column of the transposed
+// matrix PT[k][row_lo + r] (coalesced across the workgroup, L2 resident, shared by
+// all families) and accumulates NF dot products with the child's vectors, which are
+// LDS broadcasts.  k runs ascending, i.e. in the reference's summation order
+// (libtree/birthdeath.c:173-180).  A one-hot leaf (cafe/cafe_tree.c:208-209) turns
+// the product into the gather PT[count][row].
+// ------------------------------------------------------------------------------------
+template <int NF>
+__global__ __launch_bounds__(1024) void k2_prune_v1(K2Args a)
+{
+    extern __shared__ double smem[];
+    __shared__ int s_cnt[NF][kMaxLeaves];
+    __shared__ int s_colmax[NF];
+
+    const int tid = threadIdx.x;
+    const int r = tid;
+    const int fam0 = blockIdx.x * NF;
+    const size_t slot_stride = (size_t)NF * a.LDv;
+    const bool batch = (a.col_max != nullptr);
+
+    for (int i = tid; i < NF * a.n_leaves; i += blockDim.x) {
+        const int f = i / a.n_leaves, j = i - f * a.n_leaves;
+        const int u = fam0 + f;
+        s_cnt[f][j] = (u < a.Fu) ? a.counts[(size_t)u * a.n_leaves + j] : 0;
+    }
+    if (tid < NF) {
+        const int u = fam0 + tid;
+        s_colmax[tid] = (batch && u < a.Fu) ? a.col_max[u] : (a.C - 1);
+    }
+    __syncthreads();
+
+    const int err_slot = a.n_slots;  // scratch slot for error-model leaf vectors
+    int root_slot = 0;
+
+    for (int oi = 0; oi < a.n_ops; ++oi) {
+        const cafehip::PruneOp op = a.ops[oi];
+        const int rows = op.is_root ? a.R : a.C;
+        const int row_lo = op.is_root ? a.root_min : 0;
+        double y[2][NF];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const double* PTc =
+                a.PT + (size_t)a.ep->node_key[op.child[ch]] * a.KP * a.LD + row_lo + r;
+            const bool errleaf =
+                (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.src[ch]];
+            if (op.kind[ch] == 0 && !errleaf) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const int cnt = s_cnt[f][op.src[ch]];
+                    y[ch][f] = (r < rows && cnt <= s_colmax[f]) ? PTc[(size_t)cnt * a.LD] : 0.0;
+                }
+            } else {
+                const double* src;
+                if (errleaf) {
+                    // leaf vector = errormatrix[observed][0..C) (cafe/cafe_tree.c:196-203)
+                    double* es = smem + (size_t)err_slot * slot_stride;
+                    __syncthreads();
+                    for (int i = tid; i < NF * a.LDv; i += blockDim.x) {
+                        const int f = i / a.LDv, k = i - f * a.LDv;
+                        const int cnt = s_cnt[f][op.src[ch]];
+                        es[i] = (k < a.C && k <= s_colmax[f]) ? a.err[(size_t)cnt * a.err_ld + k] : 0.0;
+                    }
+                    __syncthreads();
+                    src = es;
+                } else {
+                    src = smem + (size_t)op.src[ch] * slot_stride;
+                }
+#pragma unroll
+                for (int f = 0; f < NF; ++f) y[ch][f] = 0.0;
+                if (r < rows) {
+                    for (int k = 0; k < a.C; k += 2) {
+                        const double p0 = PTc[(size_t)k * a.LD];
+                        const double p1 = PTc[(size_t)(k + 1) * a.LD];
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            const double2 l = *reinterpret_cast<const double2*>(src + f * a.LDv + k);
+                            y[ch][f] = fma(p0, l.x, y[ch][f]);
+                            y[ch][f] = fma(p1, l.y, y[ch][f]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every read of the source slots is done: dst may alias a source
+        double* dst = smem + (size_t)op.dst * slot_stride;
+        for (int rr = tid; rr < a.LDv; rr += blockDim.x) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                double v = 0.0;
+                if (rr == r && r < rows) {
+                    v = y[0][f] * y[1][f];
+                    // rows beyond this family's column range do not exist in the reference
+                    // (range.max is per call there); zero them so they add exact zeros upstream
+                    if (!op.is_root && r > s_colmax[f]) v = 0.0;
+                }
+                dst[f * a.LDv + rr] = v;
+            }
+        }
+        __syncthreads();
+        root_slot = op.dst;
+    }
+
+    // ---- root vector -> posterior (cafe/lambda.cpp:657-689) or packed root rows ----
+    const double* Lr = smem + (size_t)root_slot * slot_stride;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    for (int f = wave; f < NF; f += nwaves) {
+        const int u = fam0 + f;
+        if (u >= a.Fu) continue;
+        const double* L = Lr + f * a.LDv;
+        if (batch) {
+            const int lo = a.root_lo[u] - a.root_min, hi = a.root_hi[u] - a.root_min;
+            double* o = a.out_root + a.out_off[u];
+            for (int i = lo + lane; i <= hi; i += 64) o[i - lo] = L[i];
+            continue;
+        }
+        double best = -INFINITY, bestp = -INFINITY;
+        int bi = INT_MAX;  // INT_MAX = this lane has seen no element yet
+        for (int i = lane; i < a.R; i += 64) {
+            const double v = L[i];
+            if (bi == INT_MAX || v > best) {
+                best = v;
+                bi = i;
+            }
+            const double p = exp(log(v) + a.ep->logprior[i]);
+            bestp = fmax(bestp, p);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(best, off);
+            const int oi2 = __shfl_xor(bi, off);
+            const double op2 = __shfl_xor(bestp, off);
+            // first maximum wins (libcommon/mathfunc.c:9-24): larger value, then lower index
+            if (oi2 != INT_MAX && (bi == INT_MAX || ov > best || (ov == best && oi2 < bi))) {
+                best = ov;
+                bi = oi2;
+            }
+            bestp = fmax(bestp, op2);
+        }
+        if (lane == 0) {
+            a.max_lik[u] = best;
+            a.argmax[u] = bi;
+            a.max_post[u] = bestp;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K3: score.  One workgroup per chunk of CAFEHIP_CHUNK families in FAMILY order
+// (duplicates expanded through fam2u), fixed-shape tree sum -> chunk_sums[chunk].
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(const double* __restrict__ max_post_u,
+                                                          const double* __restrict__ max_lik_u,
+                                                          const int32_t* __restrict__ fam2u, int F,
+                                                          double* __restrict__ chunk_sums,
+                                                          int32_t* __restrict__ first_zero)
+{
+    __shared__ double red[CAFEHIP_CHUNK];
+    const int i = blockIdx.x * CAFEHIP_CHUNK + threadIdx.x;
+    double v = 0.0;
+    if (i < F) {
+        const int u = fam2u[i];
+        v = log(max_post_u[u]);                                   // cafe/lambda.cpp:721
+        if (max_lik_u[u] == 0.0) atomicMin(first_zero, i);        // cafe/lambda.cpp:715-720
+    }
+    red[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = CAFEHIP_CHUNK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = red[0];
+}
+
+__global__ void k_fill_i32(int32_t* p, int32_t v) { *p = v; }
+
+}  // namespace
+
+// ====================================================================================
+// context
+// ====================================================================================
+struct cafehip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    int lds_limit = 64 * 1024;
+    int n_cu = 0;
+
+    // tree
+    int n_nodes = 0, root = -1;
+    std::vector<int> parent, left, right, bl_int;
+    std::vector<double> bl;
+    cafehip::Schedule sched;
+    cafehip::PruneOp* d_ops = nullptr;
+
+    // families
+    int F = 0, Fu = 0, n_leaves = 0;
+    int range_min = 0, range_max = 0, root_min = 0, root_max = 0;
+    int M = -1, S = 0, C = 0, R = 0, LD = 0, KP = 0, LDv = 0;
+    int32_t* d_counts = nullptr;  // unique rows
+    int32_t* d_fam2u = nullptr;
+    double *d_max_lik = nullptr, *d_max_post = nullptr;
+    int32_t* d_argmax = nullptr;
+    double* d_chunk_sums = nullptr;
+    int32_t* d_first_zero = nullptr;
+    int n_chunks = 0;
+    std::vector<int32_t> fam2u;
+
+    // tables + matrices
+    cafehip::LnCTables lnc;
+    double *d_lncA = nullptr, *d_lncB = nullptr;
+    double* d_PT = nullptr;
+    size_t pt_keys_cap = 0;
+
+    // per-evaluation parameters (ring of pinned staging buffers)
+    EvalParams* h_params[kParamRing] = {};
+    hipEvent_t h_params_ev[kParamRing] = {};
+    int ring_pos = 0;
+    EvalParams* d_params = nullptr;
+    std::vector<int> node_key;
+    int nkeys = 0;
+    bool have_matrices = false;
+
+    // error model
+    double* d_err = nullptr;
+    int err_mfs = -1;
+    uint8_t* d_leaf_has_err = nullptr;
+
+    // pinned result staging
+    double* h_chunk = nullptr;
+    size_t h_chunk_cap = 0;
+    int32_t* h_fz = nullptr;
+
+    // timing
+    bool timing = false;
+    hipEvent_t ev[4] = {};
+    double last_ms[3] = {0, 0, 0};
+    int k2_nf = 0, k2_block = 0;
+    size_t k2_lds = 0;
+    std::string desc;
+};
+
+namespace {
+
+void free_family_buffers(cafehip_ctx* c)
+{
+    hipFree(c->d_counts);
+    hipFree(c->d_fam2u);
+    hipFree(c->d_max_lik);
+    hipFree(c->d_max_post);
+    hipFree(c->d_argmax);
+    hipFree(c->d_chunk_sums);
+    c->d_counts = c->d_fam2u = c->d_argmax = nullptr;
+    c->d_max_lik = c->d_max_post = c->d_chunk_sums = nullptr;
+}
+
+int ensure_matrix_storage(cafehip_ctx* c)
+{
+    const size_t need_keys = (size_t)std::max(c->n_nodes, 1);
+    if (c->d_PT && c->pt_keys_cap >= need_keys) return 0;
+    hipFree(c->d_PT);
+    c->d_PT = nullptr;
+    const size_t bytes = need_keys * (size_t)c->KP * c->LD * sizeof(double);
+    HIP_TRY(hipMalloc(&c->d_PT, bytes));
+    HIP_TRY(hipMemset(c->d_PT, 0, bytes));  // padding rows/cols stay zero forever
+    c->pt_keys_cap = need_keys;
+    return 0;
+}
+
+// host part of reset_birthdeath_cache: unique keys over non-root nodes
+// (cafe/cafe_tree.c:374-391, 461-483) -> staged EvalParams
+int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_mu,
+                 const double* prior, EvalParams** out_h)
+{
+    if (c->n_nodes <= 0) return fail("no tree set");
+    if (c->M < 0) return fail("no families/ranges set");
+    const int slot = c->ring_pos;
+    c->ring_pos = (c->ring_pos + 1) % kParamRing;
+    HIP_TRY(hipEventSynchronize(c->h_params_ev[slot]));
+    EvalParams* h = c->h_params[slot];
+    c->node_key.assign(c->n_nodes, -1);
+    int nk = 0;
+    std::vector<double> kl, km;
+    std::vector<int> kb;
+    for (int i = 0; i < c->n_nodes; ++i) {
+        h->node_key[i] = 0;
+        if (i == c->root) continue;
+        if (!(c->bl[i] > 0))
+            return fail("node %d has branch length %g <= 0: the reference binds no matrix to it "
+                        "(cafe/cafe_tree.c:341-342)", i, c->bl[i]);
+        const int bl = c->bl_int[i];
+        int k = 0;
+        for (; k < nk; ++k)
+            if (kb[k] == bl && kl[k] == node_lambda[i] && km[k] == node_mu[i]) break;
+        if (k == nk) {
+            kb.push_back(bl);
+            kl.push_back(node_lambda[i]);
+            km.push_back(node_mu[i]);
+            const cafehip::KeyScalars ks = cafehip::key_scalars(bl, node_lambda[i], node_mu[i]);
+            h->keys[k].log_alpha = ks.log_alpha;
+            h->keys[k].log_beta = ks.log_beta;
+            h->keys[k].log_coeff = ks.log_coeff;
+            h->keys[k].coeff = ks.coeff;
+            h->keys[k].mode = ks.mode;
+            h->keys[k].bl = bl;
+            ++nk;
+        }
+        c->node_key[i] = k;
+        h->node_key[i] = k;
+    }
+    h->nkeys = nk;
+    c->nkeys = nk;
+    if (prior) {
+        // compute_posterior adds log(prior[j]) (cafe/lambda.cpp:681); the log is taken on the host
+        for (int j = 0; j < c->R; ++j) h->logprior[j] = std::log(prior[j]);
+    }
+    *out_h = h;
+    const size_t bytes = prior ? sizeof(EvalParams) : offsetof(EvalParams, logprior);
+    HIP_TRY(hipMemcpyAsync(c->d_params, h, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->h_params_ev[slot], c->stream));
+    return 0;
+}
+
+int launch_k1(cafehip_ctx* c)
+{
+    if (c->nkeys == 0) return 0;
+    dim3 grid((c->S + 15) / 16, (c->S + 15) / 16, c->nkeys);
+    size_t lds = 2 * 16 * (size_t)c->lnc.ld * sizeof(double);
+    const int use_lds = lds <= 60 * 1024;  // bigger tables are read through L1/L2 instead
+    if (!use_lds) lds = 0;
+    hipLaunchKernelGGL(k1_build_matrices, grid, dim3(256), lds, c->stream, c->d_params, c->d_lncA,
+                       c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, use_lds);
+    HIP_TRY(hipGetLastError());
+    c->have_matrices = true;
+    return 0;
+}
+
+template <int NF>
+int launch_k2_nf(cafehip_ctx* c, const K2Args& a, int n_items, int block, size_t lds)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_prune_v1<NF>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
+        attr_set = true;
+    }
+    const int grid = (n_items + NF - 1) / NF;
+    hipLaunchKernelGGL(k2_prune_v1<NF>, dim3(grid), dim3(block), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_k2(cafehip_ctx* c, K2Args& a, int n_items)
+{
+    if (n_items <= 0) return 0;
+    const int slots = c->sched.n_slots + (c->d_err ? 1 : 0);
+    const int rows_max = std::max(c->C, c->R);
+    int block = ((rows_max + 63) / 64) * 64;
+    if (block > 1024)
+        return fail("matrix side %d exceeds the 1024 rows this kernel handles", rows_max);
+    // static LDS of the kernel: s_cnt + s_colmax
+    int nf = 16;
+    size_t lds = 0;
+    for (; nf >= 1; nf >>= 1) {
+        const size_t stat = (size_t)nf * kMaxLeaves * 4 + nf * 4 + 64;
+        lds = (size_t)slots * nf * c->LDv * sizeof(double);
+        if (lds + stat <= (size_t)c->lds_limit) break;
+    }
+    if (nf < 1)
+        return fail("tree needs %d live node vectors of %d doubles: does not fit %d B of LDS",
+                    slots, c->LDv, c->lds_limit);
+    c->k2_nf = nf;
+    c->k2_block = block;
+    c->k2_lds = lds;
+    a.n_slots = c->sched.n_slots;
+    switch (nf) {
+        case 16: return launch_k2_nf<16>(c, a, n_items, block, lds);
+        case 8: return launch_k2_nf<8>(c, a, n_items, block, lds);
+        case 4: return launch_k2_nf<4>(c, a, n_items, block, lds);
+        case 2: return launch_k2_nf<2>(c, a, n_items, block, lds);
+        default: return launch_k2_nf<1>(c, a, n_items, block, lds);
+    }
+}
+
+void fill_common_k2(cafehip_ctx* c, K2Args& a)
+{
+    memset(&a, 0, sizeof a);
+    a.PT = c->d_PT;
+    a.ep = c->d_params;
+    a.ops = c->d_ops;
+    a.n_ops = (int)c->sched.ops.size();
+    a.n_leaves = c->n_leaves;
+    a.C = c->C;
+    a.R = c->R;
+    a.root_min = c->root_min;
+    a.LD = c->LD;
+    a.KP = c->KP;
+    a.LDv = c->LDv;
+}
+
+int check_ready(cafehip_ctx* c)
+{
+    if (!c) return fail("null context");
+    if (c->n_nodes <= 0) return fail("cafehip_set_tree has not been called");
+    if (c->M < 0) return fail("cafehip_set_families has not been called");
+    if (c->n_leaves != (c->n_nodes + 1) / 2)
+        return fail("count table has %d columns but the tree has %d leaves", c->n_leaves,
+                    (c->n_nodes + 1) / 2);
+    return 0;
+}
+
+int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu,
+                const double* prior, double* d_chunk_sums, int32_t* d_first_zero)
+{
+    if (check_ready(c)) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    EvalParams* h = nullptr;
+    if (stage_params(c, node_lambda, node_mu, prior, &h)) return -1;
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (launch_k1(c)) return -1;
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    K2Args a;
+    fill_common_k2(c, a);
+    a.counts = c->d_counts;
+    a.Fu = c->Fu;
+    a.max_lik = c->d_max_lik;
+    a.argmax = c->d_argmax;
+    a.max_post = c->d_max_post;
+    if (c->d_err) {
+        a.err = c->d_err;
+        a.err_ld = c->err_mfs + 1;
+        a.leaf_has_err = c->d_leaf_has_err;
+    }
+    if (launch_k2(c, a, c->Fu)) return -1;
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(1), 0, c->stream, d_first_zero, INT32_MAX);
+    if (c->n_chunks > 0) {
+        hipLaunchKernelGGL(k3_score, dim3(c->n_chunks), dim3(CAFEHIP_CHUNK), 0, c->stream,
+                           c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, d_chunk_sums,
+                           d_first_zero);
+    }
+    HIP_TRY(hipGetLastError());
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    return 0;
+}
+
+}  // namespace
+
+// ====================================================================================
+// C ABI
+// ====================================================================================
+extern "C" {
+
+int cafehip_abi_version(void) { return 1; }
+
+const char* cafehip_last_error(void) { return g_err.c_str(); }
+
+int cafehip_create(cafehip_ctx** out, int device_id)
+{
+    if (!out) return fail("null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail("no HIP device available (%s): cafehip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return fail("device %d out of range [0,%d)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    cafehip_ctx* c = new cafehip_ctx();
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount;
+    c->lds_limit = (int)prop.sharedMemPerBlock;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && v > c->lds_limit)
+            c->lds_limit = v;
+        // gfx950 has 160 KiB per CU; a single workgroup may use all of it
+        if (strstr(prop.gcnArchName, "gfx950") && c->lds_limit < 160 * 1024) c->lds_limit = 160 * 1024;
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipMalloc(&c->d_params, sizeof(EvalParams)));
+    for (int i = 0; i < kParamRing; ++i) {
+        HIP_TRY(hipHostMalloc(&c->h_params[i], sizeof(EvalParams), hipHostMallocDefault));
+        memset(c->h_params[i], 0, sizeof(EvalParams));
+        HIP_TRY(hipEventCreateWithFlags(&c->h_params_ev[i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
+    HIP_TRY(hipMalloc(&c->d_first_zero, sizeof(int32_t)));
+    HIP_TRY(hipHostMalloc(&c->h_fz, sizeof(int32_t), hipHostMallocDefault));
+    *out = c;
+    return 0;
+}
+
+void cafehip_destroy(cafehip_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_family_buffers(c);
+    hipFree(c->d_ops);
+    hipFree(c->d_lncA);
+    hipFree(c->d_lncB);
+    hipFree(c->d_PT);
+    hipFree(c->d_params);
+    hipFree(c->d_err);
+    hipFree(c->d_leaf_has_err);
+    hipFree(c->d_first_zero);
+    for (int i = 0; i < kParamRing; ++i) {
+        hipHostFree(c->h_params[i]);
+        hipEventDestroy(c->h_params_ev[i]);
+    }
+    for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
+    hipHostFree(c->h_chunk);
+    hipHostFree(c->h_fz);
+    hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int cafehip_set_stream(cafehip_ctx* c, void* hip_stream)
+{
+    if (!c) return fail("null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return 0;
+}
+
+int cafehip_set_tree(cafehip_ctx* c, int n_nodes, const int32_t* parent, const int32_t* left,
+                     const int32_t* right, const double* branchlength)
+{
+    if (!c) return fail("null context");
+    if (n_nodes < 3 || (n_nodes & 1) == 0) return fail("a binary tree has an odd number (>= 3) of nodes, got %d", n_nodes);
+    if (n_nodes > kMaxNodes - 1) return fail("at most %d nodes supported, got %d", kMaxNodes - 1, n_nodes);
+    HIP_TRY(hipSetDevice(c->device));
+    int root = -1;
+    for (int i = 0; i < n_nodes; ++i) {
+        const bool leaf = left[i] < 0;
+        if (leaf != (right[i] < 0)) return fail("node %d has exactly one child: tree must be binary", i);
+        if (leaf != ((i & 1) == 0))
+            return fail("node %d: even ids must be leaves and odd ids internal (nlist in-order numbering)", i);
+        if (!leaf && (left[i] >= n_nodes || right[i] >= n_nodes)) return fail("node %d: child out of range", i);
+        if (parent[i] < 0) {
+            if (root >= 0) return fail("two roots (%d and %d)", root, i);
+            root = i;
+        } else if (parent[i] >= n_nodes || (left[parent[i]] != i && right[parent[i]] != i)) {
+            return fail("node %d: parent %d does not list it as a child", i, parent[i]);
+        }
+    }
+    if (root < 0 || left[root] < 0) return fail("no internal root node");
+    c->n_nodes = n_nodes;
+    c->root = root;
+    c->parent.assign(parent, parent + n_nodes);
+    c->left.assign(left, left + n_nodes);
+    c->right.assign(right, right + n_nodes);
+    c->bl.assign(branchlength, branchlength + n_nodes);
+    c->bl_int.resize(n_nodes);
+    for (int i = 0; i < n_nodes; ++i) c->bl_int[i] = (int)branchlength[i];  // cafe/cafe_tree.c:376
+    c->sched = cafehip::build_schedule(n_nodes, root, c->left, c->right);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipFree(c->d_ops);
+    c->d_ops = nullptr;
+    HIP_TRY(hipMalloc(&c->d_ops, c->sched.ops.size() * sizeof(cafehip::PruneOp)));
+    HIP_TRY(hipMemcpy(c->d_ops, c->sched.ops.data(), c->sched.ops.size() * sizeof(cafehip::PruneOp),
+                      hipMemcpyHostToDevice));
+    c->have_matrices = false;
+    if (c->M >= 0 && ensure_matrix_storage(c)) return -1;
+    return 0;
+}
+
+int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* counts,
+                         const int32_t* ref, int range_min, int range_max, int root_min,
+                         int root_max)
+{
+    if (!c) return fail("null context");
+    if (F < 0 || n_leaves <= 0 || n_leaves > kMaxLeaves) return fail("bad table shape %d x %d", F, n_leaves);
+    if (range_min != 0) return fail("range_min must be 0 (cafe/cafe_family.c:357-364), got %d", range_min);
+    if (range_max < 0 || root_min < 0 || root_max < root_min) return fail("bad ranges");
+    const int R = root_max - root_min + 1;
+    if (R > kMaxPrior) return fail("root range %d exceeds FAMILYSIZEMAX %d", R, kMaxPrior);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // the reference asserts 0 <= familysize < size_of_factor (cafe/cafe_tree.c:207)
+    const int sof = std::max(R, range_max + 1);
+    for (size_t i = 0; i < (size_t)F * n_leaves; ++i)
+        if (counts[i] < 0 || counts[i] >= sof)
+            return fail("count %d at row %zu col %zu outside [0,%d)", counts[i], i / n_leaves, i % n_leaves, sof);
+
+    // duplicate rows: ref = lowest identical index (cafe/cafe_family.c:9-34), hashed
+    std::vector<int32_t> uniq_rows;
+    c->fam2u.assign(F, 0);
+    {
+        std::unordered_map<std::string, int> seen;
+        seen.reserve((size_t)F * 2);
+        for (int i = 0; i < F; ++i) {
+            int rep;
+            if (ref) {
+                rep = (ref[i] < 0) ? i : ref[i];
+                if (rep > i || rep < 0) return fail("ref[%d] = %d is not a lower-or-equal index", i, ref[i]);
+                if (rep != i && memcmp(counts + (size_t)rep * n_leaves, counts + (size_t)i * n_leaves,
+                                       sizeof(int32_t) * n_leaves) != 0)
+                    return fail("ref[%d] = %d points at a different row", i, ref[i]);
+            } else {
+                std::string key((const char*)(counts + (size_t)i * n_leaves), sizeof(int32_t) * n_leaves);
+                auto it = seen.find(key);
+                if (it == seen.end()) {
+                    seen.emplace(std::move(key), i);
+                    rep = i;
+                } else {
+                    rep = it->second;
+                }
+            }
+            if (rep == i) {
+                c->fam2u[i] = (int32_t)uniq_rows.size();
+                uniq_rows.push_back(i);
+            } else {
+                c->fam2u[i] = c->fam2u[rep];
+            }
+        }
+    }
+    const int Fu = (int)uniq_rows.size();
+    std::vector<int32_t> ucounts((size_t)std::max(Fu, 1) * n_leaves, 0);
+    for (int u = 0; u < Fu; ++u)
+        memcpy(&ucounts[(size_t)u * n_leaves], counts + (size_t)uniq_rows[u] * n_leaves, sizeof(int32_t) * n_leaves);
+
+    free_family_buffers(c);
+    c->F = F;
+    c->Fu = Fu;
+    c->n_leaves = n_leaves;
+    c->range_min = range_min;
+    c->range_max = range_max;
+    c->root_min = root_min;
+    c->root_max = root_max;
+    const int M = std::max(range_max, root_max);  // cafe/cafe_main.c:325
+    const bool new_M = (M != c->M);
+    c->M = M;
+    c->S = M + 1;
+    c->C = range_max - range_min + 1;
+    c->R = R;
+    c->KP = ((c->S + 3) / 4) * 4;
+    c->LD = ((c->S + 15) / 16) * 16 + 16;  // room for the root row offset + a 16-row tile overrun
+    {
+        // node-vector stride: >= max(C, R) rounded to even, congruent 2 mod 32 (conflict-free
+        // 16-family x 2-k LDS reads)
+        const int need = ((std::max(c->C, c->R) + 1) / 2) * 2;
+        c->LDv = 32 * ((std::max(need - 2, 0) + 31) / 32) + 2;
+    }
+    c->n_chunks = (F + CAFEHIP_CHUNK - 1) / CAFEHIP_CHUNK;
+
+    HIP_TRY(hipMalloc(&c->d_counts, std::max<size_t>(ucounts.size(), 1) * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(c->d_counts, ucounts.data(), ucounts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&c->d_fam2u, std::max(F, 1) * sizeof(int32_t)));
+    if (F) HIP_TRY(hipMemcpy(c->d_fam2u, c->fam2u.data(), F * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&c->d_max_lik, std::max(Fu, 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_max_post, std::max(Fu, 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_argmax, std::max(Fu, 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->d_chunk_sums, std::max(c->n_chunks, 1) * sizeof(double)));
+    if ((size_t)c->n_chunks > c->h_chunk_cap) {
+        hipHostFree(c->h_chunk);
+        c->h_chunk = nullptr;
+        HIP_TRY(hipHostMalloc(&c->h_chunk, std::max(c->n_chunks, 1) * sizeof(double), hipHostMallocDefault));
+        c->h_chunk_cap = c->n_chunks;
+    }
+    if (new_M) {
+        c->lnc.build(M);
+        hipFree(c->d_lncA);
+        hipFree(c->d_lncB);
+        c->d_lncA = c->d_lncB = nullptr;
+        HIP_TRY(hipMalloc(&c->d_lncA, c->lnc.A.size() * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_lncB, c->lnc.B.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(c->d_lncA, c->lnc.A.data(), c->lnc.A.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_lncB, c->lnc.B.data(), c->lnc.B.size() * sizeof(double), hipMemcpyHostToDevice));
+        hipFree(c->d_PT);
+        c->d_PT = nullptr;
+        c->pt_keys_cap = 0;
+        c->have_matrices = false;
+    }
+    if (c->n_nodes > 0 && ensure_matrix_storage(c)) return -1;
+    return 0;
+}
+
+int cafehip_set_error_model(cafehip_ctx* c, int mfs, const double* errormatrix,
+                            const uint8_t* leaf_has_model)
+{
+    if (!c) return fail("null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipFree(c->d_err);
+    hipFree(c->d_leaf_has_err);
+    c->d_err = nullptr;
+    c->d_leaf_has_err = nullptr;
+    c->err_mfs = -1;
+    if (!errormatrix) return 0;
+    if (c->n_nodes <= 0) return fail("set the tree before the error model");
+    if (mfs < 0) return fail("bad error-model size %d", mfs);
+    const size_t n = (size_t)(mfs + 1) * (mfs + 1);
+    HIP_TRY(hipMalloc(&c->d_err, n * sizeof(double)));
+    HIP_TRY(hipMemcpy(c->d_err, errormatrix, n * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<uint8_t> by_col((c->n_nodes + 1) / 2, 0);
+    for (int i = 0; i < c->n_nodes; i += 2) by_col[i / 2] = leaf_has_model ? leaf_has_model[i] : 1;
+    HIP_TRY(hipMalloc(&c->d_leaf_has_err, by_col.size()));
+    HIP_TRY(hipMemcpy(c->d_leaf_has_err, by_col.data(), by_col.size(), hipMemcpyHostToDevice));
+    c->err_mfs = mfs;
+    return 0;
+}
+
+int cafehip_num_chunks(cafehip_ctx* c) { return c ? c->n_chunks : fail("null context"); }
+int cafehip_matrix_size(cafehip_ctx* c) { return c ? c->S : fail("null context"); }
+
+int cafehip_eval_posterior_async(cafehip_ctx* c, const double* node_lambda, const double* node_mu,
+                                 const double* prior, double* d_chunk_sums, int32_t* d_first_zero)
+{
+    if (!c) return fail("null context");
+    if (!node_lambda || !node_mu || !prior || !d_chunk_sums || !d_first_zero) return fail("null argument");
+    if (c->d_err && c->err_mfs < c->range_max)
+        return fail("error model covers sizes 0..%d but range_max is %d", c->err_mfs, c->range_max);
+    return eval_device(c, node_lambda, node_mu, prior, d_chunk_sums, d_first_zero);
+}
+
+int cafehip_eval_posterior(cafehip_ctx* c, const double* node_lambda, const double* node_mu,
+                           const double* prior, double* score, int32_t* first_zero_family,
+                           double* max_lik, int32_t* argmax_root, double* max_post)
+{
+    if (!c) return fail("null context");
+    if (!node_lambda || !node_mu || !prior || !score) return fail("null argument");
+    if (cafehip_eval_posterior_async(c, node_lambda, node_mu, prior, c->d_chunk_sums, c->d_first_zero)) return -1;
+    if (c->n_chunks)
+        HIP_TRY(hipMemcpyAsync(c->h_chunk, c->d_chunk_sums, c->n_chunks * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_fz, c->d_first_zero, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->timing) {
+        for (int i = 0; i < 3; ++i) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+            c->last_ms[i] = ms;
+        }
+    }
+    // fixed-order final sum over chunks (independent of how chunks were produced)
+    double s = 0.0;
+    for (int i = 0; i < c->n_chunks; ++i) s += c->h_chunk[i];
+    const int fz = (*c->h_fz >= 0 && *c->h_fz < c->F) ? *c->h_fz : -1;
+    *score = (fz >= 0) ? -INFINITY : s;  // cafe/lambda.cpp:753-760
+    if (first_zero_family) *first_zero_family = fz;
+    if (max_lik || argmax_root || max_post) {
+        std::vector<double> ml(c->Fu), mp(c->Fu);
+        std::vector<int32_t> am(c->Fu);
+        if (c->Fu) {
+            HIP_TRY(hipMemcpy(ml.data(), c->d_max_lik, c->Fu * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(mp.data(), c->d_max_post, c->Fu * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(am.data(), c->d_argmax, c->Fu * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+        for (int i = 0; i < c->F; ++i) {
+            const int u = c->fam2u[i];
+            if (max_lik) max_lik[i] = ml[u];
+            if (max_post) max_post[i] = mp[u];
+            if (argmax_root) argmax_root[i] = am[u];
+        }
+    }
+    return 0;
+}
+
+int cafehip_reset_birthdeath_cache(cafehip_ctx* c, const double* node_lambda, const double* node_mu)
+{
+    if (check_ready(c)) return -1;
+    if (!node_lambda || !node_mu) return fail("null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    EvalParams* h = nullptr;
+    if (stage_params(c, node_lambda, node_mu, nullptr, &h)) return -1;
+    if (launch_k1(c)) return -1;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int cafehip_get_matrix(cafehip_ctx* c, int node, double* out, int* S_out)
+{
+    if (check_ready(c)) return -1;
+    if (!c->have_matrices) return fail("no matrices built yet");
+    if (node < 0 || node >= c->n_nodes || c->node_key[node] < 0) return fail("node %d has no matrix", node);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->KP * c->LD;
+    std::vector<double> pt(n);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(pt.data(), c->d_PT + (size_t)c->node_key[node] * n, n * sizeof(double), hipMemcpyDeviceToHost));
+    for (int s = 0; s < c->S; ++s)
+        for (int k = 0; k < c->S; ++k) out[(size_t)s * c->S + k] = pt[(size_t)k * c->LD + s];
+    if (S_out) *S_out = c->S;
+    return 0;
+}
+
+int cafehip_eval_root_likelihoods(cafehip_ctx* c, int B, const int32_t* counts, const int32_t* root_lo,
+                                  const int32_t* root_hi, const int32_t* col_max, double* out)
+{
+    if (check_ready(c)) return -1;
+    if (!c->have_matrices) return fail("no matrices built yet (call cafehip_eval_posterior or cafehip_reset_birthdeath_cache)");
+    if (B <= 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<int64_t> off(B);
+    int64_t total = 0;
+    for (int b = 0; b < B; ++b) {
+        if (root_lo[b] < c->root_min || root_hi[b] > c->root_max || root_hi[b] < root_lo[b])
+            return fail("row %d: root range [%d,%d] outside [%d,%d]", b, root_lo[b], root_hi[b], c->root_min, c->root_max);
+        if (col_max[b] < 0 || col_max[b] > c->range_max)
+            return fail("row %d: col_max %d outside [0,%d]", b, col_max[b], c->range_max);
+        for (int j = 0; j < c->n_leaves; ++j)
+            if (counts[(size_t)b * c->n_leaves + j] < 0) return fail("row %d: negative count", b);
+        off[b] = total;
+        total += root_hi[b] - root_lo[b] + 1;
+    }
+    int32_t *d_cnt = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_cm = nullptr;
+    int64_t* d_off = nullptr;
+    double* d_out = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        hipFree(d_cnt); hipFree(d_lo); hipFree(d_hi); hipFree(d_cm); hipFree(d_off); hipFree(d_out);
+    };
+#define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail("%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    TRY2(hipMalloc(&d_cnt, (size_t)B * c->n_leaves * sizeof(int32_t)));
+    TRY2(hipMalloc(&d_lo, B * sizeof(int32_t)));
+    TRY2(hipMalloc(&d_hi, B * sizeof(int32_t)));
+    TRY2(hipMalloc(&d_cm, B * sizeof(int32_t)));
+    TRY2(hipMalloc(&d_off, B * sizeof(int64_t)));
+    TRY2(hipMalloc(&d_out, total * sizeof(double)));
+    TRY2(hipMemcpyAsync(d_cnt, counts, (size_t)B * c->n_leaves * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    TRY2(hipMemcpyAsync(d_lo, root_lo, B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    TRY2(hipMemcpyAsync(d_hi, root_hi, B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    TRY2(hipMemcpyAsync(d_cm, col_max, B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    TRY2(hipMemcpyAsync(d_off, off.data(), B * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    K2Args a;
+    fill_common_k2(c, a);
+    a.counts = d_cnt;
+    a.Fu = B;
+    a.root_lo = d_lo;
+    a.root_hi = d_hi;
+    a.col_max = d_cm;
+    a.out_off = d_off;
+    a.out_root = d_out;
+    // the reference drops the error model on tree copies (cafe/cafe_tree.c:485-494): not applied here
+    double* saved_err = c->d_err;
+    c->d_err = nullptr;
+    rc = launch_k2(c, a, B);
+    c->d_err = saved_err;
+    if (rc) { cleanup(); return -1; }
+    TRY2(hipMemcpyAsync(out, d_out, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TRY2(hipStreamSynchronize(c->stream));
+#undef TRY2
+    cleanup();
+    return 0;
+}
+
+int cafehip_enable_timing(cafehip_ctx* c, int on)
+{
+    if (!c) return fail("null context");
+    c->timing = on != 0;
+    return 0;
+}
+
+int cafehip_last_kernel_ms(cafehip_ctx* c, double ms[3])
+{
+    if (!c) return fail("null context");
+    for (int i = 0; i < 3; ++i) ms[i] = c->last_ms[i];
+    return 0;
+}
+
+const char* cafehip_describe(cafehip_ctx* c)
+{
+    if (!c) return "";
+    char buf[512];
+    snprintf(buf, sizeof buf,
+             "device=%d cus=%d F=%d Fu=%d n_leaves=%d S=%d C=%d R=%d LD=%d KP=%d LDv=%d nkeys=%d "
+             "n_ops=%zu n_slots=%d k2:NF=%d block=%d lds=%zu",
+             c->device, c->n_cu, c->F, c->Fu, c->n_leaves, c->S, c->C, c->R, c->LD, c->KP, c->LDv,
+             c->nkeys, c->sched.ops.size(), c->sched.n_slots, c->k2_nf, c->k2_block, c->k2_lds);
+    c->desc = buf;
+    return c->desc.c_str();
+}
+
+}  // extern "C"

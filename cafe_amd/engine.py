@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference's per-evaluation interface over the C ABI.
+
+Names follow the reference: ``reset_birthdeath_cache`` (cafe/cafe_main.c:319-326),
+``get_posterior`` (cafe/lambda.cpp:691-724), ``init_family_size`` (cafe/cafe_family.c:357-364).
+Everything numerical happens in libcafehip.so on the GPU; this file only marshals arrays.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+@dataclass
+class FamilySizeRange:
+    """family_size_range, libtree/family.h:10-15."""
+    min: int
+    max: int
+    root_min: int
+    root_max: int
+
+
+def init_family_size(max_count):
+    """init_family_size, cafe/cafe_family.c:357-364."""
+    m = int(max_count)
+    # rint() rounds half to even, as Python's round() does
+    return FamilySizeRange(0, m + max(50, m // 5), 1, max(30, int(round(m * 1.25))))
+
+
+class Engine:
+    """One GPU context (one process per GPU)."""
+
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._L.cafehip_create(C.byref(h), int(device)))
+        self._h = h
+        self.n_nodes = 0
+        self.F = 0
+        self.range = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cafehip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup -------------------------------------------------------------------------
+    def set_stream(self, hip_stream_handle):
+        _lib.check(self._L.cafehip_set_stream(self._h, C.c_void_p(hip_stream_handle or 0)))
+
+    def set_tree(self, parent, left, right, branchlength):
+        p = np.ascontiguousarray(parent, np.int32)
+        l = np.ascontiguousarray(left, np.int32)
+        r = np.ascontiguousarray(right, np.int32)
+        b = np.ascontiguousarray(branchlength, np.float64)
+        _lib.check(self._L.cafehip_set_tree(self._h, len(p), _i(p), _i(l), _i(r), _d(b)))
+        self.n_nodes = len(p)
+
+    def set_families(self, counts, rng, ref=None):
+        c = np.ascontiguousarray(counts, np.int32)
+        if c.ndim != 2:
+            raise ValueError("counts must be F x n_leaves")
+        refp = None
+        if ref is not None:
+            ref = np.ascontiguousarray(ref, np.int32)
+            refp = _i(ref)
+        _lib.check(self._L.cafehip_set_families(self._h, c.shape[0], c.shape[1], _i(c), refp, rng.min, rng.max,
+                                                rng.root_min, rng.root_max))
+        self.F = c.shape[0]
+        self.range = rng
+
+    def set_error_model(self, errormatrix, leaf_has_model=None):
+        if errormatrix is None:
+            _lib.check(self._L.cafehip_set_error_model(self._h, 0, None, None))
+            return
+        e = np.ascontiguousarray(errormatrix, np.float64)
+        assert e.ndim == 2 and e.shape[0] == e.shape[1]
+        lh = None
+        if leaf_has_model is not None:
+            lh_arr = np.ascontiguousarray(leaf_has_model, np.uint8)
+            lh = lh_arr.ctypes.data_as(C.POINTER(C.c_uint8))
+        _lib.check(self._L.cafehip_set_error_model(self._h, e.shape[0] - 1, _d(e), lh))
+
+    # ---- per evaluation ----------------------------------------------------------------
+    def get_posterior(self, node_lambda, node_mu, prior, per_family=False):
+        """reset_birthdeath_cache + get_posterior.  Returns (score, first_zero_family[, max_lik,
+        argmax_root, max_post])."""
+        nl = np.ascontiguousarray(node_lambda, np.float64)
+        nm = np.ascontiguousarray(node_mu, np.float64)
+        pr = np.ascontiguousarray(prior, np.float64)
+        R = self.range.root_max - self.range.root_min + 1
+        if len(nl) != self.n_nodes or len(nm) != self.n_nodes or len(pr) < R:
+            raise ValueError("node_lambda/node_mu need n_nodes entries and prior >= R entries")
+        score = C.c_double()
+        fz = C.c_int32(-1)
+        if per_family:
+            ml = np.zeros(self.F)
+            mp = np.zeros(self.F)
+            am = np.zeros(self.F, np.int32)
+            _lib.check(self._L.cafehip_eval_posterior(self._h, _d(nl), _d(nm), _d(pr), C.byref(score), C.byref(fz),
+                                                      _d(ml), _i(am), _d(mp)))
+            return score.value, fz.value, ml, am, mp
+        _lib.check(self._L.cafehip_eval_posterior(self._h, _d(nl), _d(nm), _d(pr), C.byref(score), C.byref(fz),
+                                                  None, None, None))
+        return score.value, fz.value
+
+    def eval_posterior_async(self, node_lambda, node_mu, prior, d_chunk_sums_ptr, d_first_zero_ptr):
+        nl = np.ascontiguousarray(node_lambda, np.float64)
+        nm = np.ascontiguousarray(node_mu, np.float64)
+        pr = np.ascontiguousarray(prior, np.float64)
+        _lib.check(self._L.cafehip_eval_posterior_async(self._h, _d(nl), _d(nm), _d(pr), C.c_void_p(d_chunk_sums_ptr),
+                                                        C.c_void_p(d_first_zero_ptr)))
+
+    def num_chunks(self):
+        return self._L.cafehip_num_chunks(self._h)
+
+    def reset_birthdeath_cache(self, node_lambda, node_mu):
+        nl = np.ascontiguousarray(node_lambda, np.float64)
+        nm = np.ascontiguousarray(node_mu, np.float64)
+        _lib.check(self._L.cafehip_reset_birthdeath_cache(self._h, _d(nl), _d(nm)))
+
+    def get_matrix(self, node):
+        S = self._L.cafehip_matrix_size(self._h)
+        out = np.zeros((S, S))
+        s_out = C.c_int()
+        _lib.check(self._L.cafehip_get_matrix(self._h, int(node), _d(out), C.byref(s_out)))
+        return out
+
+    def eval_root_likelihoods(self, counts, root_lo, root_hi, col_max):
+        c = np.ascontiguousarray(counts, np.int32)
+        lo = np.ascontiguousarray(root_lo, np.int32)
+        hi = np.ascontiguousarray(root_hi, np.int32)
+        cm = np.ascontiguousarray(col_max, np.int32)
+        n = int((hi - lo + 1).sum())
+        out = np.zeros(n)
+        _lib.check(self._L.cafehip_eval_root_likelihoods(self._h, c.shape[0], _i(c), _i(lo), _i(hi), _i(cm), _d(out)))
+        return out
+
+    def enable_timing(self, on=True):
+        _lib.check(self._L.cafehip_enable_timing(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = (C.c_double * 3)()
+        _lib.check(self._L.cafehip_last_kernel_ms(self._h, ms))
+        return list(ms)
+
+    def describe(self):
+        return self._L.cafehip_describe(self._h).decode()

@@ -1,0 +1,143 @@
+/*
+ * cafehip.h -- C ABI of the MI355X (gfx950) likelihood engine for CAFE's
+ * per-family birth-death hot path.
+ *
+ * The reference (hahnlab/CAFE v4.2.1) has no FFI; the seam a maintainer would cut
+ * is the pair of plain functions its optimiser objectives call once per
+ * evaluation:
+ *
+ *   void   reset_birthdeath_cache(pCafeTree, int k, family_size_range*)   cafe/cafe.h:90, cafe/cafe_main.c:319-326
+ *   double get_posterior(pCafeFamily, pCafeTree, std::vector<double>&)    cafe/lambda.h:75, cafe/lambda.cpp:691-724
+ *
+ * plus, for the Monte-Carlo null / report phase,
+ *
+ *   matrix cafe_conditional_distribution(pCafeTree, family_size_range*, int, int)  cafe/conditional_distribution.h:15
+ *   void   cafe_tree_p_values(pCafeTree, std::vector<double>&, matrix&, int)       cafe/pvalue.h:16
+ *
+ * Every entry point below names the reference interface it replaces.
+ * Conventions: plain pointers and sizes only; all host arrays are caller-owned;
+ * the context owns all device memory; no exception crosses the ABI; functions
+ * returning int give 0 on success and <0 on error with the message available
+ * from cafehip_last_error().  One context drives ONE GPU (one process per GPU;
+ * families are sharded above this layer).  A context is not
+ * re-entrant.  There is no CPU fallback: without a usable HIP device
+ * cafehip_create fails.
+ */
+#ifndef CAFEHIP_H
+#define CAFEHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cafehip_ctx cafehip_ctx;
+
+/* Families per partial-sum chunk of the score reduction (fixed so that the
+ * summation order does not depend on how families are sharded over GPUs). */
+#define CAFEHIP_CHUNK 256
+
+/* ABI version of this header (bumped on any signature change). */
+int cafehip_abi_version(void);
+
+/* Create a context on HIP device `device_id` (hipSetDevice ordinal).
+ * Replaces: the process-global state the reference keeps in `probability_cache`
+ * (cafe/cafe_main.c:16) and `cache` (libtree/birthdeath.c:32). */
+int cafehip_create(cafehip_ctx **out, int device_id);
+void cafehip_destroy(cafehip_ctx *ctx);
+
+/* Run all subsequent work of this context on the caller's HIP stream
+ * (a hipStream_t passed as void*; NULL = the context's own stream). */
+int cafehip_set_stream(cafehip_ctx *ctx, void *hip_stream);
+
+/* Tree topology in the reference's nlist numbering (in-order: even ids are
+ * leaves, odd ids internal; cafe/cafe_commands.cpp:2028-2051).  parent[root] = -1,
+ * left/right = -1 for leaves.  Branch lengths are truncated to int inside, as the
+ * reference's cache key does (libtree/birthdeath.h:26-31, cafe/cafe_tree.c:376).
+ * Replaces: cafe_tree_new + tree_build_node_list as consumed by
+ * cafe_tree_set_birthdeath (cafe/cafe_tree.c:461-483). */
+int cafehip_set_tree(cafehip_ctx *ctx, int n_nodes, const int32_t *parent, const int32_t *left,
+                     const int32_t *right, const double *branchlength);
+
+/* Count table: F x n_leaves int32, row-major, column j <-> leaf node id 2*j.
+ * ref[i] = lowest index with an identical row (cafe/cafe_family.c:9-34), or NULL
+ * to have it computed (hashed, same result).  Ranges as libtree/family.h:10-15 /
+ * init_family_size (cafe/cafe_family.c:357-364); range_min must be 0.
+ * Replaces: the pCafeFamily argument of get_posterior + copy_range_to_tree
+ * (cafe/cafe_main.c:52-60) + cafe_family_set_size (cafe/cafe_family.c:211-234). */
+int cafehip_set_families(cafehip_ctx *ctx, int F, int n_leaves, const int32_t *counts,
+                         const int32_t *ref, int range_min, int range_max, int root_min,
+                         int root_max);
+
+/* Error model: errormatrix[(mfs+1) x (mfs+1)] row = observed, col = true
+ * (libtree/family.h:31-38), leaf_has_model[n_nodes] marks leaves that carry it
+ * (cafe/error_model.cpp:206-229).  Pass errormatrix = NULL to remove.
+ * Replaces: the errormodel branch of initialize_leaf_likelihoods
+ * (cafe/cafe_tree.c:196-203). */
+int cafehip_set_error_model(cafehip_ctx *ctx, int mfs, const double *errormatrix,
+                            const uint8_t *leaf_has_model);
+
+/* One objective evaluation == reset_birthdeath_cache + get_posterior
+ * (cafe/cafe_main.c:319-326, cafe/lambda.cpp:691-724).
+ * node_lambda/node_mu[n_nodes] exactly as cafe_shell_set_lambdas leaves them
+ * (cafe/cafe_shell.c:31-38; mu < 0 selects the lambda-only form).  prior[R] =
+ * prior_rfsize[0..R), R = root_max-root_min+1.
+ * Outputs: *score = sum_i log(max_posterior_i) in family order, or -inf when some
+ * family has max_likelihood == 0, in which case *first_zero_family is the lowest
+ * such index (mirrors the throw at cafe/lambda.cpp:715-720), else -1.
+ * Optional per-family arrays (NULL to skip): max_lik[F], argmax_root[F]
+ * (index into the root range, as pitem->maxlh, cafe/lambda.cpp:673-676),
+ * max_post[F]. */
+int cafehip_eval_posterior(cafehip_ctx *ctx, const double *node_lambda, const double *node_mu,
+                           const double *prior, double *score, int32_t *first_zero_family,
+                           double *max_lik, int32_t *argmax_root, double *max_post);
+
+/* Same evaluation, but nothing is copied back and nothing synchronises: the
+ * per-chunk partial sums (cafehip_num_chunks doubles; chunk c covers families
+ * [c*CAFEHIP_CHUNK, (c+1)*CAFEHIP_CHUNK)) and the first-zero index (INT32_MAX if
+ * none) are left in caller-provided DEVICE buffers on the context's stream, ready
+ * for an RCCL all-gather/all-reduce.  Used by the multi-GPU driver. */
+int cafehip_eval_posterior_async(cafehip_ctx *ctx, const double *node_lambda,
+                                 const double *node_mu, const double *prior,
+                                 double *d_chunk_sums, int32_t *d_first_zero);
+int cafehip_num_chunks(cafehip_ctx *ctx);
+
+/* S x S row-major transition matrix bound to `node`'s edge by the last evaluation
+ * (== node->birthdeath_matrix->values, libtree/birthdeath.h:8-22).  *S_out = M+1. */
+int cafehip_get_matrix(cafehip_ctx *ctx, int node, double *out, int *S_out);
+/* Side of the matrices of this context (M+1, M = max(range_max, root_max)). */
+int cafehip_matrix_size(cafehip_ctx *ctx);
+
+/* Rebuild the matrices for (node_lambda, node_mu) without scoring
+ * (== reset_birthdeath_cache alone, cafe/cafe_main.c:319-326). */
+int cafehip_reset_birthdeath_cache(cafehip_ctx *ctx, const double *node_lambda,
+                                   const double *node_mu);
+
+/* Root likelihood vectors for a batch of B count rows with per-row extents, using
+ * the matrices of the last evaluation / reset: row b is scored with root rows
+ * [root_lo[b], root_hi[b]] and columns [0, col_max[b]].  out is packed,
+ * sum_b (root_hi[b]-root_lo[b]+1) doubles.  The error model is NOT applied
+ * (the reference drops it on tree copies, cafe/cafe_tree.c:485-494).
+ * Replaces: compute_tree_likelihoods + get_likelihoods as called from
+ * get_random_probabilities (cafe/conditional_distribution.cpp:10-44) and
+ * cafe_tree_p_values (cafe/pvalue.cpp:143-154). */
+int cafehip_eval_root_likelihoods(cafehip_ctx *ctx, int B, const int32_t *counts,
+                                  const int32_t *root_lo, const int32_t *root_hi,
+                                  const int32_t *col_max, double *out);
+
+/* Timing of the kernels of the last cafehip_eval_posterior call, measured with HIP
+ * events on the context's stream: ms[0] = matrix build, ms[1] = pruning+posterior,
+ * ms[2] = score reduction.  Enabled by cafehip_enable_timing(ctx, 1). */
+int cafehip_enable_timing(cafehip_ctx *ctx, int on);
+int cafehip_last_kernel_ms(cafehip_ctx *ctx, double ms[3]);
+
+/* Human-readable description of the last launch geometry (for logs/tests). */
+const char *cafehip_describe(cafehip_ctx *ctx);
+
+const char *cafehip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,289 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on the same inputs.
+
+Tolerances: matrices 1e-12 relative (same formula, device exp/log within an ulp or two of
+glibc's); per-family likelihood / posterior 1e-9 relative (north_star asks 1e-6); argmax exact.
+"""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from tests import _orc as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TR = json.load(open(os.path.join(GOLD, "transcripts.json")))
+
+MAT_RTOL = 1e-12
+FAM_RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import cafe_amd
+    e = cafe_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def setup(eng, newick, counts, rng):
+    import cafe_amd
+    t = O.PyTree(newick)
+    eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+    eng.set_families(counts, cafe_amd.FamilySizeRange(rng.min, rng.max, rng.root_min, rng.root_max))
+    return t
+
+
+def rel_close(a, b, rtol, atol=0.0):
+    a = np.asarray(a, float)
+    b = np.asarray(b, float)
+    both_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+    ok = both_inf | (np.abs(a - b) <= atol + rtol * np.abs(b))
+    return bool(np.all(ok)), float(np.max(np.where(both_inf | (b == 0), 0, np.abs(a - b) / np.maximum(np.abs(b), 1e-300))))
+
+
+def check_families(eng, t, counts, rng, lam, mu, prior, **kw):
+    score_o, fz_o, ml_o, am_o, mp_o = O.eval_posterior(t, counts, rng, lam, mu, prior, **kw)
+    score_g, fz_g, ml_g, am_g, mp_g = eng.get_posterior(lam, mu, prior, per_family=True)
+    ok, worst = rel_close(ml_g, ml_o, FAM_RTOL)
+    assert ok, "max_lik worst rel err %g" % worst
+    ok, worst = rel_close(mp_g, mp_o, FAM_RTOL)
+    assert ok, "max_post worst rel err %g" % worst
+    # argmax: identical unless two root sizes tie within rounding
+    diff = np.nonzero(am_g != am_o)[0]
+    assert diff.size == 0, "argmax differs at %s" % diff[:5]
+    assert fz_g == fz_o
+    if math.isinf(score_o):
+        assert score_g == score_o
+    else:
+        assert score_g == pytest.approx(score_o, rel=1e-10)
+    return score_g
+
+
+def test_matrices_all_branches(eng):
+    # lambda-only sum, alpha/beta sum, lambda == mu >= 0 (alpha/beta form), identity (int bl = 0),
+    # zero matrix (lambda * t >= 1): libtree/birthdeath.c:238-286
+    t = O.PyTree("(((A:6,B:6.9):81,(C:17,D:0.5):70):6,E:93)")
+    counts = np.array([[1, 2, 3, 4, 5]], np.int32)
+    rng = O.range_from_max(34)
+    setup(eng, "(((A:6,B:6.9):81,(C:17,D:0.5):70):6,E:93)", counts, rng)
+    M = max(rng.max, rng.root_max)
+    cases = [
+        (np.full(t.n_nodes, 0.0017), np.full(t.n_nodes, -1.0)),
+        (np.full(t.n_nodes, 0.002), np.full(t.n_nodes, 0.0015)),
+        (np.full(t.n_nodes, 0.003), np.full(t.n_nodes, 0.003)),
+        (np.full(t.n_nodes, 0.0123), np.full(t.n_nodes, -1.0)),  # 0.0123 * 93 > 1 -> zero matrix on E
+        (np.linspace(0.001, 0.004, t.n_nodes), np.linspace(0.002, 0.0005, t.n_nodes)),
+    ]
+    for lam, mu in cases:
+        eng.reset_birthdeath_cache(lam, mu)
+        for node in range(t.n_nodes):
+            if node == t.root:
+                continue
+            ref = O.birthdeath_matrix(int(t.branchlength[node]), lam[node], mu[node], M)
+            got = eng.get_matrix(node)
+            assert got.shape == ref.shape
+            ok, worst = rel_close(got, ref, MAT_RTOL, atol=1e-300)
+            assert ok, "node %d worst rel err %g" % (node, worst)
+            assert np.array_equal(got == 0, ref == 0)  # exact zeros in the same places
+            assert got[0, 0] == 1 and np.all(got[0, 1:] == 0)
+
+
+def test_example_data_and_survey_pins(eng):
+    g = TR["survey_8c_example"]
+    sp, ids, counts = O.load_family_table(os.path.join(GOLD, "example_data.tab"))
+    t = O.PyTree(g["newick"])
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    setup(eng, g["newick"], counts, rng)
+    prior = O.prior_poisson(1000, rng.root_min, g["poisson_lambda"])
+    lam = np.full(t.n_nodes, g["lambda"])
+    mu = np.full(t.n_nodes, -1.0)
+    check_families(eng, t, counts, rng, lam, mu, prior)
+    score, fz, ml, am, mp = eng.get_posterior(lam, mu, prior, per_family=True)
+    for fid, (exp_ml, exp_lp) in g["families"].items():
+        i = ids.index(fid)
+        assert ml[i] == pytest.approx(exp_ml, rel=1e-12)
+        assert math.log(mp[i]) == pytest.approx(exp_lp, rel=1e-12)
+    assert eng.get_matrix(0)[5, 5] == pytest.approx(g["P_bl6_5_5"], rel=1e-13)
+    # the single-lambda fit converges onto lambda ~ 1/93 where dog's matrix is all zero
+    # (SURVEY.md section 7): score must be -inf with the first family reported
+    lam2 = np.full(t.n_nodes, 0.0108)
+    s2, fz2 = eng.get_posterior(lam2, mu, prior)
+    so, fzo, *_ = O.eval_posterior(t, counts, rng, lam2, mu, prior)
+    assert s2 == so == -math.inf and fz2 == fzo == 0
+
+
+def test_transcript_test2(eng):
+    g = TR["test2"]
+    sp, ids, counts = O.load_family_table(os.path.join(GOLD, "test2_families.txt"), max_size=g["max_size"])
+    t = O.PyTree(g["newick"])
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    setup(eng, g["newick"], counts, rng)
+    prior = O.prior_poisson(1000, rng.root_min, g["poisson_lambda"])
+    mu = np.full(t.n_nodes, -1.0)
+    for lam_v, exp in g["lambda_score"]:
+        if lam_v < 0:
+            continue
+        score, fz = eng.get_posterior(np.full(t.n_nodes, lam_v), mu, prior)
+        assert score == pytest.approx(exp, abs=2e-6)
+
+
+def test_transcript_test1_14787_families(eng):
+    g = TR["test1"]
+    sp, ids, counts = O.load_family_table(os.path.join(GOLD, "test1_families.txt.gz"), max_size=g["max_size"])
+    t = O.PyTree(g["newick"])
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    setup(eng, g["newick"], counts, rng)
+    prior = O.prior_poisson(1000, rng.root_min, g["poisson_lambda"])
+    mu = np.full(t.n_nodes, -1.0)
+    for lam_v, exp in g["lambda_score"][::7]:
+        score, fz = eng.get_posterior(np.full(t.n_nodes, lam_v), mu, prior)
+        assert fz == -1
+        assert score == pytest.approx(exp, abs=5e-3)
+    # and one full per-family comparison against the oracle
+    lam = np.full(t.n_nodes, g["search_result"]["lambda"])
+    import cafe_amd
+    eng.set_families(counts[:3000], cafe_amd.FamilySizeRange(rng.min, rng.max, rng.root_min, rng.root_max))
+    check_families(eng, t, counts[:3000], rng, lam, mu, prior, nthreads=os.cpu_count() or 1)
+
+
+@pytest.mark.parametrize("name,F", [("cfg2", 300), ("cfg3", 48)])
+def test_synthetic_configs_small(eng, name, F):
+    from cafe_amd import synth
+    tree, counts, cfg = synth.make_config(name, F=F)
+    rng = O.range_from_max(cfg["m"])
+    t = setup(eng, cfg["newick"], counts, rng)
+    prior = O.prior_poisson(1000, rng.root_min, 8.0)
+    lam = np.full(t.n_nodes, cfg["lam"])
+    mu = np.full(t.n_nodes, cfg["mu"])
+    check_families(eng, t, counts, rng, lam, mu, prior, nthreads=os.cpu_count() or 1)
+
+
+def test_per_clade_lambda_and_lambdamu(eng):
+    from cafe_amd import synth
+    tree, counts, cfg = synth.make_config("cfg2", F=100)
+    rng = O.range_from_max(cfg["m"])
+    t = setup(eng, cfg["newick"], counts, rng)
+    prior = O.prior_poisson(1000, rng.root_min, 8.0)
+    rs = np.random.RandomState(5)
+    cls = rs.randint(0, 3, t.n_nodes)
+    lam = np.array([0.0015, 0.002, 0.0031])[cls]
+    mu = np.full(t.n_nodes, -1.0)
+    check_families(eng, t, counts, rng, lam, mu, prior, nthreads=os.cpu_count() or 1)
+    mu2 = np.array([0.001, 0.0025, 0.0031])[cls]
+    check_families(eng, t, counts, rng, lam, mu2, prior, nthreads=os.cpu_count() or 1)
+
+
+def test_duplicates_ref_and_ragged_shapes(eng):
+    t = O.PyTree("((A:10,B:10):5,C:15)")
+    base = np.array([[1, 2, 3], [4, 4, 4], [1, 2, 3], [0, 0, 0], [4, 4, 4], [7, 0, 1]], np.int32)
+    rng = O.range_from_max(7)
+    prior = O.prior_poisson(1000, 1, 2.0)
+    lam = np.full(t.n_nodes, 0.01)
+    mu = np.full(t.n_nodes, -1.0)
+    for F in (1, 5, 6, 17, 257, 600):  # tile and chunk boundaries
+        counts = np.ascontiguousarray(np.resize(base, (F, 3)))
+        setup(eng, "((A:10,B:10):5,C:15)", counts, rng)
+        check_families(eng, t, counts, rng, lam, mu, prior)
+    # explicit ref == computed ref
+    counts = np.ascontiguousarray(np.resize(base, (40, 3)))
+    ref = np.zeros(40, np.int32)
+    O.lib().orc_family_check_the_pattern(40, 3, O.iptr(counts), O.iptr(ref))
+    import cafe_amd
+    eng.set_families(counts, cafe_amd.FamilySizeRange(rng.min, rng.max, rng.root_min, rng.root_max), ref=ref)
+    s1, _ = eng.get_posterior(lam, mu, prior)
+    eng.set_families(counts, cafe_amd.FamilySizeRange(rng.min, rng.max, rng.root_min, rng.root_max))
+    s2, _ = eng.get_posterior(lam, mu, prior)
+    assert s1 == s2
+    # empty table
+    eng.set_families(np.zeros((0, 3), np.int32), cafe_amd.FamilySizeRange(rng.min, rng.max, rng.root_min, rng.root_max))
+    s0, fz0 = eng.get_posterior(lam, mu, prior)
+    assert s0 == 0.0 and fz0 == -1
+
+
+def test_zero_likelihood_reports_first_family(eng):
+    t = O.PyTree("((A:10,B:10):5,C:15)")
+    counts = np.array([[1, 2, 3], [2, 2, 2], [0, 0, 0], [3, 3, 3]] * 100, np.int32)
+    rng = O.range_from_max(4)
+    setup(eng, "((A:10,B:10):5,C:15)", counts, rng)
+    prior = O.prior_poisson(1000, 1, 2.0)
+    mu = np.full(t.n_nodes, -1.0)
+    lam_big = np.full(t.n_nodes, 0.2)  # lambda * t >= 1 -> zero matrices
+    check_families(eng, t, counts, rng, lam_big, mu, prior)
+    s, fz = eng.get_posterior(lam_big, mu, prior)
+    assert s == -math.inf and fz == 0
+
+
+def test_error_model_leaves(eng):
+    # banded model as example/errormodel/error1.txt: P(obs = true + d), d = -2..2 = 0,0,.94,.05,.01,
+    # columns renormalised at the upper edge (cafe/cafe_shell.c:585-622)
+    from cafe_amd import synth
+    tree, counts, cfg = synth.make_config("cfg2", F=64)
+    rng = O.range_from_max(cfg["m"])
+    t = setup(eng, cfg["newick"], counts, rng)
+    mfs = rng.max
+    E = np.zeros((mfs + 1, mfs + 1))
+    for j in range(mfs + 1):
+        for d, p in zip(range(-2, 3), (0.0, 0.0, 0.94, 0.05, 0.01)):
+            if 0 <= j + d <= mfs:
+                E[j + d, j] = p
+        E[:, j] /= E[:, j].sum()
+    has = np.zeros(t.n_nodes, np.uint8)
+    has[0::2] = 1
+    has[4] = 0  # one species without a model (errormodel -sp ...)
+    eng.set_error_model(E, has)
+    prior = O.prior_poisson(1000, rng.root_min, 8.0)
+    lam = np.full(t.n_nodes, 0.002)
+    mu = np.full(t.n_nodes, -1.0)
+    try:
+        check_families(eng, t, counts, rng, lam, mu, prior, errormatrix=E, err_mfs=mfs, leaf_has_err=has,
+                       nthreads=os.cpu_count() or 1)
+    finally:
+        eng.set_error_model(None)
+
+
+def test_root_likelihood_batch_with_extents(eng):
+    # cafe/conditional_distribution.cpp:16-32 (root fixed to one size, running-min range.max) and
+    # cafe/cafe_family.c:236-255 (per-family ranges)
+    from cafe_amd import synth
+    tree, counts, cfg = synth.make_config("cfg2", F=40)
+    rng = O.range_from_max(cfg["m"])
+    t = setup(eng, cfg["newick"], counts, rng)
+    lam = np.full(t.n_nodes, 0.002)
+    mu = np.full(t.n_nodes, -1.0)
+    eng.reset_birthdeath_cache(lam, mu)
+    B = counts.shape[0]
+    mx = counts.max(axis=1)
+    lo = np.ones(B, np.int32)
+    hi = np.maximum(np.rint(mx * 1.25).astype(np.int32), 1)
+    cm = (mx + np.maximum(50, mx // 5)).astype(np.int32)
+    lo[::2] = hi[::2] = np.minimum(hi[::2], 1 + np.arange(len(lo[::2])))  # single-root-size rows
+    got = eng.eval_root_likelihoods(counts, lo, hi, cm)
+    ct = t.ctree()
+    M = max(rng.max, rng.root_max)
+    h = O.lib().orc_matrices_build(C.byref(ct), O.dptr(lam), O.dptr(mu), M, 1)
+    exp = np.zeros(int((hi - lo + 1).sum()))
+    O.lib().orc_eval_root_likelihoods(C.byref(ct), B, counts.shape[1], O.iptr(counts), O.iptr(lo), O.iptr(hi),
+                                      O.iptr(cm), h, O.dptr(exp))
+    O.lib().orc_matrices_free(h)
+    ok, worst = rel_close(got, exp, FAM_RTOL)
+    assert ok, "worst rel err %g" % worst
+
+
+def test_bad_inputs_fail_loudly(eng):
+    import cafe_amd
+    with pytest.raises(cafe_amd.CafeHipError):
+        eng.set_tree([-1, 0], [-1, -1], [-1, -1], [1.0, 1.0])  # even node count
+    t = O.PyTree("((A:10,B:10):5,C:15)")
+    eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+    with pytest.raises(cafe_amd.CafeHipError):
+        eng.set_families(np.array([[1, -2, 3]], np.int32), cafe_amd.FamilySizeRange(0, 60, 1, 30))
+    with pytest.raises(cafe_amd.CafeHipError):
+        eng.set_families(np.array([[1, 2, 3]], np.int32), cafe_amd.FamilySizeRange(1, 60, 1, 30))
