@@ -197,10 +197,11 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
 // (libtree/birthdeath.c:173-180).  A one-hot leaf (cafe/cafe_tree.c:208-209) turns
 // the product into the gather PT[count][row].
 // ------------------------------------------------------------------------------------
-template <int NF>
+template <int NF, int SMEM_DOUBLES>
 __global__ __launch_bounds__(1024) void k2_prune_v1(K2Args a)
 {
-    extern __shared__ double smem[];
+    // static LDS: gfx950 admits up to 160 KiB per workgroup when declared statically
+    __shared__ double smem[SMEM_DOUBLES];
     __shared__ int s_cnt[NF][kMaxLeaves];
     __shared__ int s_colmax[NF];
 
@@ -529,17 +530,17 @@ int launch_k1(cafehip_ctx* c)
     return 0;
 }
 
+constexpr int kSmemSmall = 7680;    // 60 KiB of node-vector slots (several workgroups per CU)
+constexpr int kSmemLarge = 19200;   // 150 KiB (one workgroup per CU)
+
 template <int NF>
 int launch_k2_nf(cafehip_ctx* c, const K2Args& a, int n_items, int block, size_t lds)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_prune_v1<NF>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
-        attr_set = true;
-    }
     const int grid = (n_items + NF - 1) / NF;
-    hipLaunchKernelGGL(k2_prune_v1<NF>, dim3(grid), dim3(block), lds, c->stream, a);
+    if (lds <= kSmemSmall * sizeof(double))
+        hipLaunchKernelGGL((k2_prune_v1<NF, kSmemSmall>), dim3(grid), dim3(block), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL((k2_prune_v1<NF, kSmemLarge>), dim3(grid), dim3(block), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -552,17 +553,15 @@ int launch_k2(cafehip_ctx* c, K2Args& a, int n_items)
     int block = ((rows_max + 63) / 64) * 64;
     if (block > 1024)
         return fail("matrix side %d exceeds the 1024 rows this kernel handles", rows_max);
-    // static LDS of the kernel: s_cnt + s_colmax
     int nf = 16;
     size_t lds = 0;
     for (; nf >= 1; nf >>= 1) {
-        const size_t stat = (size_t)nf * kMaxLeaves * 4 + nf * 4 + 64;
         lds = (size_t)slots * nf * c->LDv * sizeof(double);
-        if (lds + stat <= (size_t)c->lds_limit) break;
+        if (lds <= kSmemLarge * sizeof(double)) break;
     }
     if (nf < 1)
-        return fail("tree needs %d live node vectors of %d doubles: does not fit %d B of LDS",
-                    slots, c->LDv, c->lds_limit);
+        return fail("tree needs %d live node vectors of %d doubles: does not fit %zu B of LDS",
+                    slots, c->LDv, kSmemLarge * sizeof(double));
     c->k2_nf = nf;
     c->k2_block = block;
     c->k2_lds = lds;
