@@ -19,6 +19,7 @@
 #include <cstdarg>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -369,6 +370,8 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(const double* __restri
 
 __global__ void k_fill_i32(int32_t* p, int32_t v) { *p = v; }
 
+#include "k2_mfma.hpp"
+
 }  // namespace
 
 // ====================================================================================
@@ -387,6 +390,12 @@ struct cafehip_ctx {
     std::vector<double> bl;
     cafehip::Schedule sched;
     cafehip::PruneOp* d_ops = nullptr;
+    cafehip::MfmaSchedule msched;
+    cafehip::MfmaOp* d_mops = nullptr;
+    double* d_park = nullptr;
+    size_t park_cap = 0;
+    int k2_cfg[4] = {0, 0, 0, 0};  // NFT_W, NRT_W, Wf, Wr of the last MFMA launch
+    bool k2_used_mfma = false;
 
     // families
     int F = 0, Fu = 0, n_leaves = 0;
@@ -545,7 +554,7 @@ int launch_k2_nf(cafehip_ctx* c, const K2Args& a, int n_items, int block, size_t
     return 0;
 }
 
-int launch_k2(cafehip_ctx* c, K2Args& a, int n_items)
+int launch_k2_v1(cafehip_ctx* c, K2Args& a, int n_items)
 {
     if (n_items <= 0) return 0;
     const int slots = c->sched.n_slots + (c->d_err ? 1 : 0);
@@ -573,6 +582,170 @@ int launch_k2(cafehip_ctx* c, K2Args& a, int n_items)
         case 2: return launch_k2_nf<2>(c, a, n_items, block, lds);
         default: return launch_k2_nf<1>(c, a, n_items, block, lds);
     }
+}
+
+
+// ---- MFMA launcher -------------------------------------------------------------------
+struct K2Cfg {
+    int nft_w, nrt_w, wf, wr;
+};
+
+template <int NFT_W, int NRT_W>
+int launch_mfma_inst(cafehip_ctx* c, const K2MfmaArgs& a, int grid, int block, size_t lds)
+{
+    static size_t attr_bytes = 0;
+    if (lds > 64 * 1024 && lds > attr_bytes) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_prune_mfma<NFT_W, NRT_W>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    hipLaunchKernelGGL((k2_prune_mfma<NFT_W, NRT_W>), dim3(grid), dim3(block), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int NFT_W>
+int launch_mfma_nrt(cafehip_ctx* c, const K2MfmaArgs& a, int nrt_w, int grid, int block, size_t lds)
+{
+    switch (nrt_w) {
+        case 1: return launch_mfma_inst<NFT_W, 1>(c, a, grid, block, lds);
+        case 2: return launch_mfma_inst<NFT_W, 2>(c, a, grid, block, lds);
+        case 3: return launch_mfma_inst<NFT_W, 3>(c, a, grid, block, lds);
+        case 4: return launch_mfma_inst<NFT_W, 4>(c, a, grid, block, lds);
+        case 5: return launch_mfma_inst<NFT_W, 5>(c, a, grid, block, lds);
+        case 6: return launch_mfma_inst<NFT_W, 6>(c, a, grid, block, lds);
+        case 7: return launch_mfma_inst<NFT_W, 7>(c, a, grid, block, lds);
+        case 8: return launch_mfma_inst<NFT_W, 8>(c, a, grid, block, lds);
+    }
+    return fail("unsupported NRT_W %d", nrt_w);
+}
+
+size_t mfma_lds_bytes(const cafehip_ctx* c, int nf)
+{
+    return (size_t)nf * c->LDv * sizeof(double) + (size_t)nf * c->n_leaves * 4 + (size_t)nf * 4;
+}
+
+// Pick the wave grid: minimise (rounds of waves over the SIMDs) x (tiles per wave), then
+// prefer fewer, larger workgroups (less matrix re-streaming).  CAFEHIP_K2CFG="nftw,nrtw,wf,wr"
+// overrides (tuning sweeps).
+bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out)
+{
+    const int RT = (std::max(c->C, c->R) + 15) / 16;
+    const int RTc = (c->C + 15) / 16;
+    if (const char* e = getenv("CAFEHIP_K2CFG")) {
+        K2Cfg k;
+        if (sscanf(e, "%d,%d,%d,%d", &k.nft_w, &k.nrt_w, &k.wf, &k.wr) == 4 && k.nft_w >= 1 && k.nft_w <= 2 &&
+            k.nrt_w >= 1 && k.nrt_w <= 7 && k.nft_w * k.nrt_w <= 8 && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 && k.wr * k.nrt_w >= RT &&
+            mfma_lds_bytes(c, 16 * k.nft_w * k.wf) <= (size_t)c->lds_limit) {
+            *out = k;
+            return true;
+        }
+    }
+    const long simd_slots = 4L * std::max(c->n_cu, 1);
+    double best = 1e300;
+    bool found = false;
+    for (int wr = 1; wr <= 8; wr *= 2) {
+        const int nrt_w = (RT + wr - 1) / wr;
+        if (nrt_w > 7) continue;  // register budget: NFT_W * NRT_W <= 8 accumulator tiles, no spills
+        for (int nft_w = 1; nft_w <= 2; ++nft_w) {
+            if (nft_w * nrt_w > 8) continue;
+            for (int wf = 1; wf * wr <= 8; wf *= 2) {
+                const int nf = 16 * nft_w * wf;
+                if (mfma_lds_bytes(c, nf) > (size_t)c->lds_limit) continue;
+                const long n_wg = (n_items + nf - 1) / nf;
+                const long act = (long)wf * ((RTc + nrt_w - 1) / nrt_w);  // active waves per workgroup
+                const long waves = n_wg * act;
+                const long rounds = (waves + simd_slots - 1) / simd_slots;
+                double cost = (double)rounds * nft_w * nrt_w;
+                cost *= 1.0 + 0.02 * wf / (double)nft_w;          // matrix re-streaming per family tile column
+                cost *= 1.0 + 0.01 * (wf * wr);                   // barrier width
+                if (nf > n_items + 15) cost *= 1.5;               // mostly empty workgroup
+                if (cost < best) {
+                    best = cost;
+                    *out = K2Cfg{nft_w, nrt_w, wf, wr};
+                    found = true;
+                }
+            }
+        }
+    }
+    return found;
+}
+
+int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
+{
+    if (n_items <= 0) return 0;
+    K2Cfg k;
+    if (!choose_mfma_cfg(c, n_items, &k)) {
+        // matrices too large for the MFMA wave grids: the row-per-thread kernel handles them
+        c->k2_used_mfma = false;
+        K2Args a1 = v1;
+        return launch_k2_v1(c, a1, n_items);
+    }
+    const int nf = 16 * k.nft_w * k.wf;
+    const int grid = (n_items + nf - 1) / nf;
+    const int block = 64 * k.wf * k.wr;
+    const size_t lds = mfma_lds_bytes(c, nf);
+    const size_t park_bytes = (size_t)grid * std::max(c->msched.n_parks, 1) * nf * c->LDv * sizeof(double);
+    if (park_bytes > c->park_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->d_park);
+        c->d_park = nullptr;
+        c->park_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_park, park_bytes));
+        c->park_cap = park_bytes;
+    }
+    K2MfmaArgs a;
+    memset(&a, 0, sizeof a);
+    a.PT = v1.PT;
+    a.ep = v1.ep;
+    a.ops = c->d_mops;
+    a.n_ops = (int)c->msched.ops.size();
+    a.counts = v1.counts;
+    a.Fu = v1.Fu;
+    a.n_leaves = v1.n_leaves;
+    a.C = v1.C;
+    a.R = v1.R;
+    a.root_min = v1.root_min;
+    a.LD = v1.LD;
+    a.KP = v1.KP;
+    a.LDv = v1.LDv;
+    a.ksteps = (c->C + 3) / 4;
+    a.Wf = k.wf;
+    a.Wr = k.wr;
+    a.NF = nf;
+    a.park = c->d_park;
+    a.n_parks = std::max(c->msched.n_parks, 1);
+    a.err = v1.err;
+    a.err_ld = v1.err_ld;
+    a.leaf_has_err = v1.leaf_has_err;
+    a.root_lo = v1.root_lo;
+    a.root_hi = v1.root_hi;
+    a.col_max = v1.col_max;
+    a.out_off = v1.out_off;
+    a.out_root = v1.out_root;
+    a.max_lik = v1.max_lik;
+    a.argmax = v1.argmax;
+    a.max_post = v1.max_post;
+    c->k2_cfg[0] = k.nft_w;
+    c->k2_cfg[1] = k.nrt_w;
+    c->k2_cfg[2] = k.wf;
+    c->k2_cfg[3] = k.wr;
+    c->k2_nf = nf;
+    c->k2_block = block;
+    c->k2_lds = lds;
+    c->k2_used_mfma = true;
+    if (k.nft_w == 1) return launch_mfma_nrt<1>(c, a, k.nrt_w, grid, block, lds);
+    return launch_mfma_nrt<2>(c, a, k.nrt_w, grid, block, lds);
+}
+
+int launch_k2(cafehip_ctx* c, K2Args& a, int n_items)
+{
+    const char* e = getenv("CAFEHIP_K2");
+    if (e && strcmp(e, "v1") == 0) {
+        c->k2_used_mfma = false;
+        return launch_k2_v1(c, a, n_items);
+    }
+    return launch_k2_mfma(c, a, n_items);
 }
 
 void fill_common_k2(cafehip_ctx* c, K2Args& a)
@@ -694,6 +867,8 @@ void cafehip_destroy(cafehip_ctx* c)
     hipStreamSynchronize(c->stream);
     free_family_buffers(c);
     hipFree(c->d_ops);
+    hipFree(c->d_mops);
+    hipFree(c->d_park);
     hipFree(c->d_lncA);
     hipFree(c->d_lncB);
     hipFree(c->d_PT);
@@ -756,6 +931,12 @@ int cafehip_set_tree(cafehip_ctx* c, int n_nodes, const int32_t* parent, const i
     c->d_ops = nullptr;
     HIP_TRY(hipMalloc(&c->d_ops, c->sched.ops.size() * sizeof(cafehip::PruneOp)));
     HIP_TRY(hipMemcpy(c->d_ops, c->sched.ops.data(), c->sched.ops.size() * sizeof(cafehip::PruneOp),
+                      hipMemcpyHostToDevice));
+    c->msched = cafehip::build_mfma_schedule(n_nodes, root, c->left, c->right);
+    hipFree(c->d_mops);
+    c->d_mops = nullptr;
+    HIP_TRY(hipMalloc(&c->d_mops, c->msched.ops.size() * sizeof(cafehip::MfmaOp)));
+    HIP_TRY(hipMemcpy(c->d_mops, c->msched.ops.data(), c->msched.ops.size() * sizeof(cafehip::MfmaOp),
                       hipMemcpyHostToDevice));
     c->have_matrices = false;
     if (c->M >= 0 && ensure_matrix_storage(c)) return -1;
@@ -1061,9 +1242,11 @@ const char* cafehip_describe(cafehip_ctx* c)
     char buf[512];
     snprintf(buf, sizeof buf,
              "device=%d cus=%d F=%d Fu=%d n_leaves=%d S=%d C=%d R=%d LD=%d KP=%d LDv=%d nkeys=%d "
-             "n_ops=%zu n_slots=%d k2:NF=%d block=%d lds=%zu",
+             "n_ops=%zu n_slots=%d n_parks=%d k2:%s NF=%d block=%d lds=%zu cfg(nftw,nrtw,wf,wr)=%d,%d,%d,%d",
              c->device, c->n_cu, c->F, c->Fu, c->n_leaves, c->S, c->C, c->R, c->LD, c->KP, c->LDv,
-             c->nkeys, c->sched.ops.size(), c->sched.n_slots, c->k2_nf, c->k2_block, c->k2_lds);
+             c->nkeys, c->sched.ops.size(), c->sched.n_slots, c->msched.n_parks,
+             c->k2_used_mfma ? "mfma" : "v1", c->k2_nf, c->k2_block, c->k2_lds, c->k2_cfg[0], c->k2_cfg[1],
+             c->k2_cfg[2], c->k2_cfg[3]);
     c->desc = buf;
     return c->desc.c_str();
 }

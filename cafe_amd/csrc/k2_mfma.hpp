@@ -1,0 +1,280 @@
+// k2_mfma.hpp -- K2 on the gfx950 matrix cores (included by cafehip.hip).
+//
+// Because the transition matrix of an edge is shared by every family
+// (libtree/birthdeath.h:26-31), the per-family mat-vecs of one edge
+// (cafe/cafe_tree.c:213-224) are the FP64 GEMM
+//        Y[fam][row] = sum_k L[fam][k] * PT[k][row]
+// issued as v_mfma_f64_16x16x4_f64 tiles: A = 16 families x 4 k from the LDS node
+// buffer, B = 4 k x 16 rows straight from the transposed matrix in L2 (4 x 128 B
+// segments per wave load), D = 16 families x 16 rows in registers.
+//
+// One workgroup owns NF = 16*NFT families and walks the whole tree for them:
+//   * ONE node-vector buffer Lbuf[NF][LDv] in LDS; results that are not consumed by the
+//     next step are parked in a per-workgroup global scratch region (MfmaSchedule);
+//   * waves are arranged Wf x Wr: wave (wf, wr) owns family tiles [wf*NFT_W, +NFT_W) and
+//     row tiles [wr*NRT_W, +NRT_W): NFT_W*NRT_W accumulator tiles (4 f64 per lane each);
+//   * leaf children are column gathers PT[count][row] in the D layout; the Hadamard
+//     product of the two child factors is taken in registers (cafe/cafe_tree.c:261-266).
+// Layouts (lane l of a wave): A lane holds L[fam0 + (l&15)][k0 + (l>>4)];
+// B lane holds PT[k0 + (l>>4)][row0 + (l&15)]; D reg r holds
+// Y[fam0 + (l>>4) + 4r][row0 + (l&15)]   (verified by tools/mfma_f64_probe.hip).
+#pragma once
+
+typedef double cafe_d4 __attribute__((ext_vector_type(4)));
+
+struct K2MfmaArgs {
+    const double* PT;
+    const EvalParams* ep;
+    const cafehip::MfmaOp* ops;
+    int n_ops;
+    const int32_t* counts;
+    int Fu;
+    int n_leaves;
+    int C, R, root_min;
+    int LD, KP, LDv;
+    int ksteps;            // ceil(C / 4)
+    int Wf, Wr;            // wave grid
+    int NF;                // families per workgroup = 16 * Wf * NFT_W
+    double* park;          // [grid][n_parks][NF][LDv]
+    int n_parks;
+    // error model
+    const double* err;
+    int err_ld;
+    const uint8_t* leaf_has_err;
+    // batch mode (per-row extents)
+    const int32_t* root_lo;
+    const int32_t* root_hi;
+    const int32_t* col_max;
+    const int64_t* out_off;
+    double* out_root;
+    // posterior outputs
+    double* max_lik;
+    int32_t* argmax;
+    double* max_post;
+};
+
+// One edge: acc[i][j] += L-tile(i) x PT-tile(j) over all k-steps, operands double-buffered in
+// registers one k-step ahead of the MFMAs.
+template <int NFT_W, int NRT_W>
+__device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const int (&boff)[NRT_W],
+                                          size_t kstride, const double* ap, int astride, int ksteps,
+                                          cafe_d4 (&acc)[NFT_W][NRT_W])
+{
+    double a0[NFT_W], a1[NFT_W], b0[NRT_W], b1[NRT_W];
+#pragma unroll
+    for (int i = 0; i < NFT_W; ++i) a0[i] = ap[i * astride];
+#pragma unroll
+    for (int j = 0; j < NRT_W; ++j) b0[j] = bp[boff[j]];
+    int ks = 0;
+    for (; ks + 2 <= ksteps; ks += 2) {
+        const double* bp1 = bp + (size_t)(ks + 1) * kstride;
+        const double* ap1 = ap + (ks + 1) * 4;
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i) a1[i] = ap1[i * astride];
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j) b1[j] = bp1[boff[j]];
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+            for (int j = 0; j < NRT_W; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+        // operands of step ks+2 (clamped to the last step: harmless reload)
+        const int kn = (ks + 2 < ksteps) ? ks + 2 : ksteps - 1;
+        const double* bp2 = bp + (size_t)kn * kstride;
+        const double* ap2 = ap + kn * 4;
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i) a0[i] = ap2[i * astride];
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j) b0[j] = bp2[boff[j]];
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+            for (int j = 0; j < NRT_W; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    }
+    if (ks < ksteps) {
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+            for (int j = 0; j < NRT_W; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <int NFT_W, int NRT_W>
+__global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
+{
+    extern __shared__ double Lbuf[];                          // [NF][LDv]
+    int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv);  // [NF][n_leaves]
+    int* s_colmax = s_cnt + a.NF * a.n_leaves;                // [NF]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15;   // row within a tile (B/D) or family within a tile (A)
+    const int lk = lane >> 4;   // k within a step (A/B) or family group within a tile (D)
+    const int wf = wave % a.Wf;
+    const int wr = wave / a.Wf;
+    const int ft0 = wf * NFT_W;
+    const int rt0 = wr * NRT_W;
+    const int fam0 = blockIdx.x * a.NF;
+    const bool batch = (a.col_max != nullptr);
+    const size_t park_stride = (size_t)a.NF * a.LDv;
+    double* my_park = a.park + (size_t)blockIdx.x * a.n_parks * park_stride;
+
+    for (int i = tid; i < a.NF * a.n_leaves; i += blockDim.x) {
+        const int f = i / a.n_leaves, j = i - f * a.n_leaves;
+        const int u = fam0 + f;
+        s_cnt[i] = (u < a.Fu) ? a.counts[(size_t)u * a.n_leaves + j] : 0;
+    }
+    for (int f = tid; f < a.NF; f += blockDim.x) {
+        const int u = fam0 + f;
+        s_colmax[f] = (batch && u < a.Fu) ? a.col_max[u] : (a.C - 1);
+    }
+    __syncthreads();
+
+    cafe_d4 hold[NFT_W][NRT_W];
+
+    for (int oi = 0; oi < a.n_ops; ++oi) {
+        const cafehip::MfmaOp op = a.ops[oi];
+        const int rows = op.is_root ? a.R : a.C;
+        const int row_lo = op.is_root ? a.root_min : 0;
+        const int RT = (rows + 15) >> 4;           // active row tiles of this step
+        const bool wave_active = rt0 < RT;
+
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const double* PTe = a.PT + (size_t)a.ep->node_key[op.child[ch]] * a.KP * a.LD + row_lo;
+            const bool errleaf = (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.leafcol[ch]];
+            cafe_d4 fac[NFT_W][NRT_W];
+            if (op.kind[ch] == 0 && !errleaf) {
+                // one-hot leaf: factor = PT[count][row]  (cafe/cafe_tree.c:208-209)
+#pragma unroll
+                for (int i = 0; i < NFT_W; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = (ft0 + i) * 16 + lk + 4 * r;
+                        const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
+                        const bool ok = cnt <= s_colmax[f];
+#pragma unroll
+                        for (int j = 0; j < NRT_W; ++j) {
+                            const bool act = (rt0 + j) < RT;
+                            fac[i][j][r] = (ok && act) ? PTe[(size_t)cnt * a.LD + (rt0 + j) * 16 + li] : 0.0;
+                        }
+                    }
+                }
+            } else {
+                if (op.kind[ch] == 1 && op.src_park[ch] >= 0) {
+                    // fetch the parked vector into the LDS buffer
+                    __syncthreads();
+                    const double* src = my_park + (size_t)op.src_park[ch] * park_stride;
+                    for (int i = tid; i < a.NF * a.LDv; i += blockDim.x) Lbuf[i] = src[i];
+                    __syncthreads();
+                } else if (errleaf) {
+                    // leaf vector = errormatrix[observed][0..C)  (cafe/cafe_tree.c:196-203)
+                    __syncthreads();
+                    for (int i = tid; i < a.NF * a.LDv; i += blockDim.x) {
+                        const int f = i / a.LDv, k = i - f * a.LDv;
+                        const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
+                        Lbuf[i] = (k < a.C && k <= s_colmax[f]) ? a.err[(size_t)cnt * a.err_ld + k] : 0.0;
+                    }
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+                    for (int j = 0; j < NRT_W; ++j) fac[i][j] = cafe_d4{0.0, 0.0, 0.0, 0.0};
+                if (wave_active) {
+                    int boff[NRT_W];
+#pragma unroll
+                    for (int j = 0; j < NRT_W; ++j)
+                        boff[j] = (((rt0 + j) < RT) ? (rt0 + j) : rt0) * 16;  // inactive tiles re-read tile rt0
+                    const double* bp = PTe + (size_t)lk * a.LD + li;
+                    const double* ap = Lbuf + (size_t)(ft0 * 16 + li) * a.LDv + lk;
+                    mfma_edge<NFT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                }
+            }
+            if (ch == 0) {
+#pragma unroll
+                for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+                    for (int j = 0; j < NRT_W; ++j) hold[i][j] = fac[i][j];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+                    for (int j = 0; j < NRT_W; ++j) hold[i][j] *= fac[i][j];
+            }
+        }
+
+        // ---- result: Hadamard product in `hold` (D layout) -> LDS buffer or park ----
+        double* dst;
+        if (op.dst_park >= 0) {
+            dst = my_park + (size_t)op.dst_park * park_stride;
+        } else {
+            __syncthreads();  // every wave is done reading the buffer: overwrite in place
+            dst = Lbuf;
+        }
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = (ft0 + i) * 16 + lk + 4 * r;
+                const int cm = s_colmax[f];
+#pragma unroll
+                for (int j = 0; j < NRT_W; ++j) {
+                    if ((rt0 + j) < RT) {
+                        const int row = (rt0 + j) * 16 + li;
+                        double v = hold[i][j][r];
+                        // rows beyond this family's column range do not exist in the reference
+                        if (!op.is_root && row > cm) v = 0.0;
+                        dst[(size_t)f * a.LDv + row] = v;
+                    }
+                }
+            }
+        }
+        if (op.dst_park < 0) __syncthreads();
+    }
+
+    // ---- root vector (in Lbuf) -> posterior (cafe/lambda.cpp:657-689) or packed root rows ----
+    const int nwaves = blockDim.x >> 6;
+    for (int f = wave; f < a.NF; f += nwaves) {
+        const int u = fam0 + f;
+        if (u >= a.Fu) continue;
+        const double* L = Lbuf + (size_t)f * a.LDv;
+        if (batch) {
+            const int lo = a.root_lo[u] - a.root_min, hi = a.root_hi[u] - a.root_min;
+            double* o = a.out_root + a.out_off[u];
+            for (int i = lo + lane; i <= hi; i += 64) o[i - lo] = L[i];
+            continue;
+        }
+        double best = -INFINITY, bestp = -INFINITY;
+        int bi = INT_MAX;  // INT_MAX = this lane has seen no element yet
+        for (int i = lane; i < a.R; i += 64) {
+            const double v = L[i];
+            if (bi == INT_MAX || v > best) {
+                best = v;
+                bi = i;
+            }
+            const double p = exp(log(v) + a.ep->logprior[i]);
+            bestp = fmax(bestp, p);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(best, off);
+            const int oi2 = __shfl_xor(bi, off);
+            const double op2 = __shfl_xor(bestp, off);
+            // first maximum wins (libcommon/mathfunc.c:9-24): larger value, then lower index
+            if (oi2 != INT_MAX && (bi == INT_MAX || ov > best || (ov == best && oi2 < bi))) {
+                best = ov;
+                bi = oi2;
+            }
+            bestp = fmax(bestp, op2);
+        }
+        if (lane == 0) {
+            a.max_lik[u] = best;
+            a.argmax[u] = bi;
+            a.max_post[u] = bestp;
+        }
+    }
+}

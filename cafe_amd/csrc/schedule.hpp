@@ -139,4 +139,150 @@ inline Schedule build_schedule(int n_nodes, int root, const std::vector<int>& le
     return sch;
 }
 
+
+// ---------------------------------------------------------------------------------
+// Schedule for the MFMA kernel: ONE node-vector buffer in LDS per workgroup.  A node's
+// result stays in the buffer when the very next step consumes it (its parent), and is
+// "parked" in a per-workgroup global scratch region otherwise (the next step starts the
+// sibling subtree).  Children are ordered so that the LDS-resident one is multiplied first.
+// Visiting the child whose subtree needs more parks first keeps the park count at the
+// Sethi-Ullman minimum (<= log2 #internal nodes).
+// ---------------------------------------------------------------------------------
+struct MfmaOp {
+    int32_t node;
+    int32_t is_root;
+    int32_t child[2];     // child node ids, in processing order
+    int32_t kind[2];      // 0 = leaf (column gather), 1 = internal (vector in LDS or parked)
+    int32_t leafcol[2];   // count-table column for leaves
+    int32_t src_park[2];  // internal child: -1 = vector is in the LDS buffer, else park index
+    int32_t dst_park;     // -1 = keep the result in the LDS buffer, else park index
+    int32_t pad;
+};
+
+struct MfmaSchedule {
+    std::vector<MfmaOp> ops;
+    int n_parks = 0;
+};
+
+inline MfmaSchedule build_mfma_schedule(int n_nodes, int root, const std::vector<int>& left,
+                                        const std::vector<int>& right)
+{
+    MfmaSchedule sch;
+    // parks needed by each subtree
+    std::vector<int> need(n_nodes, 0);
+    std::vector<int> post;
+    {
+        std::vector<std::pair<int, int>> st;
+        st.push_back({root, 0});
+        while (!st.empty()) {
+            auto& top = st.back();
+            const int v = top.first;
+            if (left[v] < 0) {
+                post.push_back(v);
+                st.pop_back();
+            } else if (top.second == 0) {
+                top.second = 1;
+                st.push_back({left[v], 0});
+            } else if (top.second == 1) {
+                top.second = 2;
+                st.push_back({right[v], 0});
+            } else {
+                post.push_back(v);
+                st.pop_back();
+            }
+        }
+    }
+    auto internal = [&](int v) { return left[v] >= 0; };
+    for (int v : post) {
+        if (!internal(v)) continue;
+        const int a = left[v], b = right[v];
+        if (internal(a) && internal(b)) {
+            const int hi = std::max(need[a], need[b]), lo = std::min(need[a], need[b]);
+            need[v] = std::max(hi, lo + 1);
+        } else if (internal(a) || internal(b)) {
+            need[v] = internal(a) ? need[a] : need[b];
+        } else {
+            need[v] = 0;
+        }
+    }
+    // emission order (iterative DFS, larger-need internal child first)
+    std::vector<int> order;
+    {
+        struct Fr { int v, stage, first, second; };
+        std::vector<Fr> st;
+        st.push_back({root, 0, -1, -1});
+        while (!st.empty()) {
+            Fr f = st.back();
+            const int v = f.v;
+            if (!internal(v)) { st.pop_back(); continue; }
+            if (f.stage == 0) {
+                int a = left[v], b = right[v];
+                // internal before leaf is irrelevant (leaves emit nothing); among two internal
+                // children take the larger need first
+                if (internal(a) && internal(b) && need[b] > need[a]) std::swap(a, b);
+                st.back().stage = 1;
+                st.back().first = a;
+                st.back().second = b;
+                st.push_back({a, 0, -1, -1});
+            } else if (f.stage == 1) {
+                st.back().stage = 2;
+                st.push_back({f.second, 0, -1, -1});
+            } else {
+                order.push_back(v);
+                st.pop_back();
+            }
+        }
+    }
+    std::vector<int> parent(n_nodes, -1);
+    for (int v = 0; v < n_nodes; ++v)
+        if (internal(v)) { parent[left[v]] = v; parent[right[v]] = v; }
+    std::vector<int> park_of(n_nodes, -1);
+    std::vector<int> free_parks;
+    int next_park = 0;
+    int in_lds = -1;  // node whose vector currently sits in the LDS buffer
+    for (size_t oi = 0; oi < order.size(); ++oi) {
+        const int v = order[oi];
+        MfmaOp op{};
+        op.node = v;
+        op.is_root = (v == root);
+        int ch[2] = {left[v], right[v]};
+        // LDS-resident internal child first
+        if (internal(ch[1]) && ch[1] == in_lds) std::swap(ch[0], ch[1]);
+        for (int c = 0; c < 2; ++c) {
+            op.child[c] = ch[c];
+            op.src_park[c] = -1;
+            op.leafcol[c] = 0;
+            if (!internal(ch[c])) {
+                op.kind[c] = 0;
+                op.leafcol[c] = ch[c] / 2;
+            } else {
+                op.kind[c] = 1;
+                if (ch[c] != in_lds) {
+                    op.src_park[c] = park_of[ch[c]];
+                    free_parks.push_back(park_of[ch[c]]);
+                    park_of[ch[c]] = -1;
+                }
+            }
+        }
+        const bool next_is_parent = (oi + 1 < order.size()) && (order[oi + 1] == parent[v]);
+        if (v == root || next_is_parent) {
+            op.dst_park = -1;
+            in_lds = v;
+        } else {
+            int p;
+            if (!free_parks.empty()) { p = free_parks.back(); free_parks.pop_back(); }
+            else p = next_park++;
+            op.dst_park = p;
+            park_of[v] = p;
+            // in_lds unchanged only if this op did not touch the buffer; a parked result never
+            // lands in LDS, but fetching a parked child overwrote the buffer:
+            if (op.src_park[0] >= 0 || op.src_park[1] >= 0) in_lds = -1;
+            else if (in_lds == ch[0] || in_lds == ch[1]) in_lds = -1;  // consumed
+        }
+        sch.ops.push_back(op);
+    }
+    sch.n_parks = next_park;
+    return sch;
+}
+
 }  // namespace cafehip
