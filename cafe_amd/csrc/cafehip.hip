@@ -641,7 +641,11 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out)
             return true;
         }
     }
-    const long simd_slots = 4L * std::max(c->n_cu, 1);
+    // Cost model fitted to sweeps on MI355X (tools/sweep_k2.py): every workgroup is resident at
+    // once, block b lands on CU b % n_cu, its waves go to consecutive SIMDs from a rotating start;
+    // the kernel takes as long as the busiest SIMD (in accumulator tiles per k-step), times a
+    // per-wave-count factor (1-2 waves hide less latency, 8 waves pay wider barriers).
+    const int n_cu = std::max(c->n_cu, 1);
     double best = 1e300;
     bool found = false;
     for (int wr = 1; wr <= 8; wr *= 2) {
@@ -652,14 +656,20 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out)
             for (int wf = 1; wf * wr <= 8; wf *= 2) {
                 const int nf = 16 * nft_w * wf;
                 if (mfma_lds_bytes(c, nf) > (size_t)c->lds_limit) continue;
+                const int W = wf * wr;
                 const long n_wg = (n_items + nf - 1) / nf;
-                const long act = (long)wf * ((RTc + nrt_w - 1) / nrt_w);  // active waves per workgroup
-                const long waves = n_wg * act;
-                const long rounds = (waves + simd_slots - 1) / simd_slots;
-                double cost = (double)rounds * nft_w * nrt_w;
-                cost *= 1.0 + 0.02 * wf / (double)nft_w;          // matrix re-streaming per family tile column
-                cost *= 1.0 + 0.01 * (wf * wr);                   // barrier width
-                if (nf > n_items + 15) cost *= 1.5;               // mostly empty workgroup
+                const int wg_on_cu = (int)((n_wg + n_cu - 1) / n_cu);  // busiest CU
+                int load[4] = {0, 0, 0, 0};
+                for (int g = 0; g < wg_on_cu; ++g)
+                    for (int w = 0; w < W; ++w) {
+                        const int wrow = w / wf;
+                        const int act = std::min(std::max(RTc - wrow * nrt_w, 0), nrt_w);
+                        load[(g + w) & 3] += act * nft_w;
+                    }
+                const int maxload = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));
+                static const double wpen[9] = {0, 1.25, 1.09, 1.05, 1.0, 1.1, 1.2, 1.25, 1.3};
+                double cost = maxload * wpen[W];
+                cost *= 1.0 + 0.002 * (n_wg * wf) / (double)n_cu;  // matrix re-streaming
                 if (cost < best) {
                     best = cost;
                     *out = K2Cfg{nft_w, nrt_w, wf, wr};
