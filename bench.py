@@ -64,6 +64,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import cafe_amd
+    from cafe_amd import distributed as D
     from cafe_amd import prior as cprior
     from cafe_amd import synth
     from cafe_amd import tree as ctree
@@ -90,8 +91,6 @@ def main():
 
     d_chunks = torch.zeros(n_chunks, dtype=torch.float64, device="cuda")
     d_fz = torch.zeros(1, dtype=torch.int32, device="cuda")
-    if world > 1:
-        d_all = torch.zeros(n_chunks * world, dtype=torch.float64, device="cuda")
     has_mu = cfg["mu"] >= 0
 
     def node_rates(step):
@@ -109,13 +108,9 @@ def main():
             kernel_ms.append(eng.last_kernel_ms())
             return score
         eng.eval_posterior_async(nl, nm, prior, d_chunks.data_ptr(), d_fz.data_ptr())
-        dist.all_gather_into_tensor(d_all, d_chunks)
-        fzg = torch.where(d_fz < F_local, d_fz + rank * F_local, torch.full_like(d_fz, 2**31 - 1))
-        dist.all_reduce(fzg, op=dist.ReduceOp.MIN)
-        host = d_all.cpu()                    # the optimiser needs the value on the host
-        fz = int(fzg.item())
-        score = float(host.numpy().sum()) if fz == 2**31 - 1 else -math.inf
-        return score
+        # the one exchange step: RCCL all_gather of the chunk sums + all_reduce(min) of the first zero
+        all_sums, fz = D.exchange(dist, torch, d_chunks, d_fz, rank * F_local, F_local, n_chunks, "cuda")
+        return D.final_score(all_sums, fz)    # host value, as the optimiser needs it
 
     def barrier():
         if world > 1:

@@ -1,0 +1,77 @@
+"""Family sharding and the single exchange step of the multi-GPU path (one process per GPU).
+
+Families are independent given the transition matrices (cafe/lambda.cpp:698-722 is a map + sum), so
+each rank scores a contiguous block of the count table and the ranks exchange only the per-chunk
+partial sums of log max-posterior (CAFEHIP_CHUNK = 256 families per chunk, in family order) and the
+index of the first zero-likelihood family.  Blocks are chunk-aligned and the final sum runs over the
+gathered chunk list in chunk order on every rank, so the score is bit-identical for any number of
+ranks.
+
+Backend-agnostic: "nccl" (= RCCL over xGMI) on the GPUs, "gloo" in the CPU tests.
+"""
+import math
+
+import numpy as np
+
+CHUNK = 256
+NO_ZERO = 2 ** 31 - 1
+
+
+def shard_bounds(F, world, chunk=CHUNK):
+    """Contiguous chunk-aligned blocks: [(lo, hi)] per rank covering [0, F)."""
+    n_chunks = (F + chunk - 1) // chunk
+    base, extra = divmod(n_chunks, world)
+    out = []
+    c0 = 0
+    for r in range(world):
+        nc = base + (1 if r < extra else 0)
+        lo = min(c0 * chunk, F)
+        hi = min((c0 + nc) * chunk, F)
+        out.append((lo, hi))
+        c0 += nc
+    return out
+
+
+def max_chunks_per_rank(F, world, chunk=CHUNK):
+    return max((hi - lo + chunk - 1) // chunk for lo, hi in shard_bounds(F, world, chunk))
+
+
+def chunk_tree_sums(values, chunk=CHUNK):
+    """Per-chunk sums with the fixed halving tree of the k3_score kernel (cafe_amd/csrc/cafehip.hip):
+    red[t] += red[t + s] for s = chunk/2 ... 1.  Host mirror used by the CPU tests."""
+    v = np.asarray(values, np.float64)
+    n_chunks = (len(v) + chunk - 1) // chunk
+    pad = np.zeros(n_chunks * chunk)
+    pad[:len(v)] = v
+    red = pad.reshape(n_chunks, chunk).copy()
+    s = chunk // 2
+    while s > 0:
+        red[:, :s] += red[:, s:2 * s]
+        s //= 2
+    return red[:, 0].copy()
+
+
+def final_score(all_chunk_sums, first_zero):
+    """Fixed-order sum over the gathered chunk list; -inf when any family has likelihood 0
+    (cafe/lambda.cpp:715-720, 753-760)."""
+    if first_zero != NO_ZERO:
+        return -math.inf
+    s = 0.0
+    for x in np.asarray(all_chunk_sums, np.float64):
+        s += float(x)
+    return s
+
+
+def exchange(dist, torch, chunk_sums, first_zero_local, lo, n_local, slots, device):
+    """all_gather the (zero-padded) chunk sums, all_reduce(min) the global first-zero index.
+    chunk_sums: 1-D float64 tensor of this rank's chunks; first_zero_local: int tensor[1] holding a
+    LOCAL index or any value >= n_local for none.  Returns (host array of world*slots sums, fz)."""
+    world = dist.get_world_size()
+    padded = torch.zeros(slots, dtype=torch.float64, device=device)
+    padded[:chunk_sums.numel()] = chunk_sums
+    gathered = torch.zeros(slots * world, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(gathered, padded)
+    fz = first_zero_local.to(torch.int64)
+    fzg = torch.where(fz < n_local, fz + lo, torch.full_like(fz, NO_ZERO))
+    dist.all_reduce(fzg, op=dist.ReduceOp.MIN)
+    return gathered.cpu().numpy(), int(fzg.item())
