@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--families", type=int, default=None, help="families per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for debugging)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="debug: all ranks share GPU 0 (functional check of the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -58,10 +61,15 @@ def main():
                          % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     import cafe_amd
     from cafe_amd import distributed as D
@@ -89,8 +97,9 @@ def main():
     n_chunks = eng.num_chunks()
     eng.enable_timing(True)
 
-    d_chunks = torch.zeros(n_chunks, dtype=torch.float64, device="cuda")
-    d_fz = torch.zeros(1, dtype=torch.int32, device="cuda")
+    packed, p_chunks, p_fz = D.packed_buffer(torch, n_chunks, "cuda")
+    gathered = torch.zeros((n_chunks + 1) * world, dtype=torch.float64, device="cuda")
+    bounds = [(r * F_local, (r + 1) * F_local) for r in range(world)]
     has_mu = cfg["mu"] >= 0
 
     def node_rates(step):
@@ -107,10 +116,10 @@ def main():
             score, fz = eng.get_posterior(nl, nm, prior)
             kernel_ms.append(eng.last_kernel_ms())
             return score
-        eng.eval_posterior_async(nl, nm, prior, d_chunks.data_ptr(), d_fz.data_ptr())
-        # the one exchange step: RCCL all_gather of the chunk sums + all_reduce(min) of the first zero
-        all_sums, fz = D.exchange(dist, torch, d_chunks, d_fz, rank * F_local, F_local, n_chunks, "cuda")
-        return D.final_score(all_sums, fz)    # host value, as the optimiser needs it
+        eng.eval_posterior_async(nl, nm, prior, p_chunks, p_fz)
+        # the one exchange step: a single RCCL all_gather of (chunk sums, first-zero index) per rank
+        score, fz = D.exchange_packed(dist, torch, packed, gathered, n_chunks, bounds)
+        return score
 
     def barrier():
         if world > 1:

@@ -75,3 +75,26 @@ def exchange(dist, torch, chunk_sums, first_zero_local, lo, n_local, slots, devi
     fzg = torch.where(fz < n_local, fz + lo, torch.full_like(fz, NO_ZERO))
     dist.all_reduce(fzg, op=dist.ReduceOp.MIN)
     return gathered.cpu().numpy(), int(fzg.item())
+
+
+def packed_buffer(torch, slots, device):
+    """One float64 tensor per rank: [0, slots) chunk sums (unused slots stay 0), element `slots` holds
+    the LOCAL first-zero index as an int32 in its low 4 bytes (written by the k3 kernel through the
+    d_first_zero pointer).  Returns (tensor, chunk_sums_ptr, first_zero_ptr)."""
+    t = torch.zeros(slots + 1, dtype=torch.float64, device=device)
+    return t, t.data_ptr(), t.data_ptr() + 8 * slots
+
+
+def exchange_packed(dist, torch, packed, gathered, slots, bounds):
+    """The whole exchange step as ONE collective: all_gather of the packed per-rank buffers, then on the
+    host the fixed-order sum over chunks and the global first-zero index.  bounds[r] = (lo, hi) of rank r."""
+    dist.all_gather_into_tensor(gathered, packed)
+    host = gathered.cpu().numpy()                      # the optimiser needs the value on the host
+    world = len(bounds)
+    rows = host.reshape(world, slots + 1)
+    fz_local = rows[:, slots].copy().view(np.int32)[0::2]
+    fz = NO_ZERO
+    for r, (lo, hi) in enumerate(bounds):
+        if 0 <= fz_local[r] < hi - lo:
+            fz = min(fz, lo + int(fz_local[r]))
+    return final_score(rows[:, :slots].reshape(-1), fz), fz

@@ -45,6 +45,13 @@ def _worker(rank, world, port, F, lam_v, q):
     slots = D.max_chunks_per_rank(F, world)
     all_sums, fzg = D.exchange(dist, torch, torch.from_numpy(sums), torch.tensor([fz_local], dtype=torch.int32), lo,
                                hi - lo, slots, "cpu")
+    # the packed single-collective variant used by bench.py must agree
+    packed, _, _ = D.packed_buffer(torch, slots, "cpu")
+    packed[:len(sums)] = torch.from_numpy(sums)
+    packed[slots:].view(torch.int32)[0] = int(fz_local)
+    gathered = torch.zeros((slots + 1) * world, dtype=torch.float64)
+    score2, fz2 = D.exchange_packed(dist, torch, packed, gathered, slots, D.shard_bounds(F, world))
+    assert fz2 == fzg and (score2 == D.final_score(all_sums, fzg))
     q.put((rank, D.final_score(all_sums, fzg), fzg))
     dist.destroy_process_group()
 
