@@ -34,6 +34,23 @@ SIGNATURES = {
     "cafehip_last_error": (C.c_char_p, []),
 }
 
+# include/cafehost.h (host driver above the kernel boundary)
+HOST_SIGNATURES = {
+    "cafehost_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_char_p]),
+    "cafehost_destroy": (None, [C.c_void_p]),
+    "cafehost_dispatch": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "cafehost_run_script": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "cafehost_num_params": (C.c_int, [C.c_void_p]),
+    "cafehost_get_params": (C.c_int, [C.c_void_p, _dp, C.c_int]),
+    "cafehost_last_score": (C.c_double, [C.c_void_p]),
+    "cafehost_search_iterations": (C.c_int, [C.c_void_p]),
+    "cafehost_num_evaluations": (C.c_int, [C.c_void_p]),
+    "cafehost_search_seconds": (C.c_double, [C.c_void_p]),
+    "cafehost_poisson_lambda": (C.c_double, [C.c_void_p]),
+    "cafehost_get_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
+    "cafehost_last_error": (C.c_char_p, []),
+}
+
 CHUNK = 256  # CAFEHIP_CHUNK
 
 _lib = None
@@ -50,10 +67,11 @@ def load():
         return _lib
     path = _build.build()
     L = C.CDLL(path)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
-        fn.restype = res
-        fn.argtypes = args
+    for table in (SIGNATURES, HOST_SIGNATURES):
+        for name, (res, args) in table.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
     _lib = L
     return L
 

@@ -11,8 +11,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcafehip.so")
 
-SOURCES = ["cafehip.hip"]
-DEPS = ["cafehip.hip", "host_math.hpp", "schedule.hpp", os.path.join("..", "..", "include", "cafehip.h")]
+SOURCES = ["cafehip.hip", os.path.join("host", "cafe_host.cpp")]
+BINDIR = os.path.join(HERE, "bin")
+CLI = os.path.join(BINDIR, "cafehip")
+DEPS = ["cafehip.hip", "k2_mfma.hpp", "host_math.hpp", "schedule.hpp", os.path.join("host", "cafe_host.cpp"),
+        os.path.join("host", "main.cpp"), os.path.join("..", "..", "include", "cafehip.h"),
+        os.path.join("..", "..", "include", "cafehost.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
          "-Wno-unused-result"]
 
@@ -25,7 +29,7 @@ def hipcc():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(CLI):
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
@@ -39,6 +43,13 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    # command-line front end (host C++ only), linked against the in-tree library
+    os.makedirs(BINDIR, exist_ok=True)
+    cli = [hipcc(), "-O2", "-std=c++17", "-o", CLI, os.path.join(CSRC, "host", "main.cpp"), "-L" + LIBDIR, "-lcafehip",
+           "-Wl,-rpath,$ORIGIN/../lib"]
+    if verbose:
+        print(" ".join(cli))
+    subprocess.check_call(cli)
     return LIB
 
 

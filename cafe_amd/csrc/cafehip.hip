@@ -113,11 +113,12 @@ struct K2Args {
 // same sequence of IEEE operations as the reference's x86-64 build.
 // ------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
+template <bool USE_LDS>
 __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __restrict__ ep,
                                                          const double* __restrict__ lncA,
                                                          const double* __restrict__ lncB,
                                                          int ld_lnc, double* __restrict__ PT,
-                                                         int M, int LD, int KP, int use_lds)
+                                                         int M, int LD, int KP)
 {
     extern __shared__ double k1_smem[];
     const int key = blockIdx.z;
@@ -143,11 +144,13 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
         return;
     }
     // stage lnC runs: A needs j <= min(s, c) <= min(s0, c0) + 15; B needs i = c - j <= c0 + 15
-    const int nA = min(min(s0, c0) + 16, M + 1);
-    const int nB = min(c0 + 16, M + 1);
-    double* sA = k1_smem;                      // [16][ld_lnc]
-    double* sB = k1_smem + 16 * (size_t)ld_lnc;  // [16][ld_lnc]
-    if (use_lds) {
+    const double* a;
+    const double* b;
+    if (USE_LDS) {
+        const int nA = min(min(s0, c0) + 16, M + 1);
+        const int nB = min(c0 + 16, M + 1);
+        double* sA = k1_smem;                        // [16][ld_lnc]
+        double* sB = k1_smem + 16 * (size_t)ld_lnc;  // [16][ld_lnc]
         for (int r = 0; r < 16; ++r) {
             const int sr = s0 + r;
             if (sr > M) break;
@@ -157,25 +160,32 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
             for (int i = threadIdx.x; i < nB; i += 256) sB[r * ld_lnc + i] = gb[i];
         }
         __syncthreads();
+        a = sA + tx * ld_lnc;
+        b = sB + tx * ld_lnc;
+    } else {
+        a = lncA + (size_t)min(s, M) * ld_lnc;
+        b = lncB + (size_t)min(s, M) * ld_lnc;
     }
     if (s > M || c > M) return;
     double p;
     if (s == 0) {
         p = (c == 0) ? 1.0 : 0.0;
     } else {
-        const double* a = use_lds ? sA + tx * ld_lnc : lncA + (size_t)s * ld_lnc;
-        const double* b = use_lds ? sB + tx * ld_lnc : lncB + (size_t)s * ld_lnc;
         const int m = min(s, c);
         p = 0.0;
+        // terms are accumulated strictly in j order (the reference's order); the loads of the next
+        // terms are independent of the running sum, so unrolling lets them overlap the exp chain
         if (kp.mode == 2) {
             double lastterm = 1.0;
             const int s_add_c = s + c;
+#pragma unroll 4
             for (int j = 0; j <= m; ++j) {
                 const double t = a[j] + b[c - j] + (double)(s_add_c - 2 * j) * kp.log_alpha;
                 p += exp(t) * lastterm;
                 lastterm *= kp.coeff;
             }
         } else {
+#pragma unroll 4
             for (int j = 0; j <= m; ++j) {
                 const double t = a[j] + b[c - j] + (double)(s - j) * kp.log_alpha +
                                  (double)(c - j) * kp.log_beta + (double)j * kp.log_coeff;
@@ -532,8 +542,12 @@ int launch_k1(cafehip_ctx* c)
     size_t lds = 2 * 16 * (size_t)c->lnc.ld * sizeof(double);
     const int use_lds = lds <= 60 * 1024;  // bigger tables are read through L1/L2 instead
     if (!use_lds) lds = 0;
-    hipLaunchKernelGGL(k1_build_matrices, grid, dim3(256), lds, c->stream, c->d_params, c->d_lncA,
-                       c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, use_lds);
+    if (use_lds)
+        hipLaunchKernelGGL(k1_build_matrices<true>, grid, dim3(256), lds, c->stream, c->d_params,
+                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP);
+    else
+        hipLaunchKernelGGL(k1_build_matrices<false>, grid, dim3(256), 0, c->stream, c->d_params,
+                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP);
     HIP_TRY(hipGetLastError());
     c->have_matrices = true;
     return 0;
@@ -663,7 +677,7 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out)
                 for (int g = 0; g < wg_on_cu; ++g)
                     for (int w = 0; w < W; ++w) {
                         const int wrow = w / wf;
-                        const int act = std::min(std::max(RTc - wrow * nrt_w, 0), nrt_w);
+                        const int act = RTc / wr + (wrow < RTc % wr ? 1 : 0);  // even deal of the row tiles
                         load[(g + w) & 3] += act * nft_w;
                     }
                 const int maxload = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));

@@ -1,0 +1,1011 @@
+// cafe_host.cpp -- host-side driver above the kernel boundary (include/cafehost.h).
+//
+// CAFE's command language for the hot path, restated in C++17: tree / family-table
+// ingest, the Poisson root prior, the parameter scatter, the Nelder-Mead search and the
+// log lines of `lambda` and `lambdamu`.  Every objective evaluation is ONE call of
+// cafehip_eval_posterior (include/cafehip.h) on the GPU; nothing here computes a
+// likelihood.  Each function cites the reference behaviour it reproduces (file:line).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <functional>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/cafehip.h"
+#include "../../../include/cafehost.h"
+#include "../host_math.hpp"
+
+namespace {
+
+thread_local std::string g_host_err;
+
+int host_fail(const std::string& msg)
+{
+    g_host_err = msg;
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------
+// tree: Newick -> nlist arrays (tree_build_node_list, cafe/cafe_commands.cpp:2028-2051)
+// ------------------------------------------------------------------------------------
+struct HostTree {
+    int n = 0, root = -1;
+    std::vector<int32_t> parent, left, right;
+    std::vector<double> bl;
+    std::vector<std::string> name;
+    std::string newick;  // as typed
+
+    int n_leaves() const { return (n + 1) / 2; }
+
+    static HostTree parse(const std::string& text)
+    {
+        std::string s = text;
+        while (!s.empty() && (s.back() == ';' || isspace((unsigned char)s.back()))) s.pop_back();
+        struct Raw {
+            std::string name;
+            double bl = -1.0;  // the root keeps -1 (libtree/phylogeny.c)
+            std::vector<int> kids;
+        };
+        std::vector<Raw> raw;
+        size_t pos = 0;
+        std::function<int()> rec = [&]() -> int {
+            const int me = (int)raw.size();
+            raw.emplace_back();
+            if (pos < s.size() && s[pos] == '(') {
+                ++pos;
+                while (true) {
+                    const int ch = rec();
+                    raw[me].kids.push_back(ch);
+                    if (pos < s.size() && s[pos] == ',') {
+                        ++pos;
+                        continue;
+                    }
+                    if (pos >= s.size() || s[pos] != ')') throw std::runtime_error("Failed to load tree from provided string");
+                    ++pos;
+                    break;
+                }
+            }
+            size_t j = pos;
+            while (j < s.size() && s[j] != ',' && s[j] != '(' && s[j] != ')' && s[j] != ':') ++j;
+            raw[me].name = s.substr(pos, j - pos);
+            pos = j;
+            if (pos < s.size() && s[pos] == ':') {
+                size_t k = pos + 1;
+                while (k < s.size() && s[k] != ',' && s[k] != '(' && s[k] != ')') ++k;
+                raw[me].bl = atof(s.substr(pos + 1, k - pos - 1).c_str());
+                pos = k;
+            }
+            return me;
+        };
+        const int r = rec();
+        if (pos != s.size()) throw std::runtime_error("Failed to load tree from provided string");
+        // in-order numbering: even = leaf, odd = internal
+        std::vector<int> order;
+        std::vector<std::pair<int, int>> st;
+        st.push_back({r, 0});
+        while (!st.empty()) {
+            auto [v, stage] = st.back();
+            st.pop_back();
+            if (raw[v].kids.empty()) {
+                order.push_back(v);
+            } else if (stage == 0) {
+                if (raw[v].kids.size() != 2) throw std::runtime_error("Tree must be binary");
+                st.push_back({v, 1});
+                st.push_back({raw[v].kids[0], 0});
+            } else {
+                order.push_back(v);
+                st.push_back({raw[v].kids[1], 0});
+            }
+        }
+        HostTree t;
+        t.n = (int)order.size();
+        std::vector<int> id(raw.size());
+        for (int i = 0; i < t.n; ++i) id[order[i]] = i;
+        t.parent.assign(t.n, -1);
+        t.left.assign(t.n, -1);
+        t.right.assign(t.n, -1);
+        t.bl.assign(t.n, -1.0);
+        t.name.assign(t.n, "");
+        for (size_t v = 0; v < raw.size(); ++v) {
+            const int i = id[v];
+            t.name[i] = raw[v].name;
+            t.bl[i] = raw[v].bl;
+            if (!raw[v].kids.empty()) {
+                t.left[i] = id[raw[v].kids[0]];
+                t.right[i] = id[raw[v].kids[1]];
+                t.parent[t.left[i]] = i;
+                t.parent[t.right[i]] = i;
+            }
+        }
+        t.root = id[r];
+        t.newick = s;
+        return t;
+    }
+
+    double max_branch_length() const
+    {
+        double m = 0;
+        for (double b : bl) m = std::max(m, b);
+        return m;
+    }
+};
+
+bool iequals(const std::string& a, const std::string& b)
+{
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); ++i)
+        if (tolower((unsigned char)a[i]) != tolower((unsigned char)b[i])) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------
+// family table (load_gene_families, cafe/gene_family.cpp:186-225)
+// ------------------------------------------------------------------------------------
+struct HostFamilies {
+    std::string path;
+    std::vector<std::string> species, ids, desc;
+    std::vector<int32_t> counts;  // F x species.size(), file column order
+    int max_size = 0;
+    int F() const { return (int)ids.size(); }
+
+    static std::vector<std::string> split(const std::string& s, char sep)
+    {
+        std::vector<std::string> out;
+        std::string cur;
+        for (char ch : s) {
+            if (ch == sep) {
+                out.push_back(cur);
+                cur.clear();
+            } else {
+                cur.push_back(ch);
+            }
+        }
+        out.push_back(cur);
+        return out;
+    }
+
+    void load(const std::string& file, int max_size_filter)
+    {
+        std::ifstream in(file);
+        if (!in) throw std::runtime_error("ERROR(load): Cannot open " + file + " in read mode.");
+        path = file;
+        std::string line;
+        if (!std::getline(in, line)) throw std::runtime_error("Failed to identify species for gene families");
+        while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+        const char sep = (line.find('\t') != std::string::npos) ? '\t' : ',';
+        auto head = split(line, sep);
+        if (head.size() < 3) throw std::runtime_error("Failed to identify species for gene families");
+        species.assign(head.begin() + 2, head.end());
+        ids.clear();
+        desc.clear();
+        counts.clear();
+        max_size = 0;
+        while (std::getline(in, line)) {
+            while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+            if (line.empty()) continue;
+            auto v = split(line, sep);
+            if (v.size() != species.size() + 2)
+                throw std::runtime_error("Inconsistency in column count: expected " + std::to_string(species.size() + 2) +
+                                         ", but found " + std::to_string(v.size()));
+            std::vector<int32_t> row(species.size());
+            int mx = 0;
+            for (size_t i = 0; i < species.size(); ++i) {
+                char* end = nullptr;
+                const long val = strtol(v[i + 2].c_str(), &end, 10);
+                if (end == v[i + 2].c_str()) throw std::runtime_error("Error reading family '" + v[1] + "'");
+                row[i] = (int32_t)val;
+                mx = std::max(mx, (int)val);
+            }
+            // cafe/gene_family.cpp:217: keep the row when max_size < 0 or max(row) <= max_size
+            if (max_size_filter < 0 || mx <= max_size_filter) {
+                desc.push_back(v[0]);
+                ids.push_back(v[1]);
+                counts.insert(counts.end(), row.begin(), row.end());
+                max_size = std::max(max_size, mx);
+            }
+        }
+    }
+};
+
+struct HostRange {
+    int min = 0, max = 0, root_min = 1, root_max = 1;
+};
+
+// init_family_size, cafe/cafe_family.c:357-364
+HostRange init_family_size(int max)
+{
+    HostRange r;
+    r.root_min = 1;
+    r.root_max = (int)std::max(30.0, std::rint(max * 1.25));
+    r.max = max + std::max(50, max / 5);
+    r.min = 0;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------
+// Nelder-Mead exactly as libcommon/fminsearch.cpp (defaults :7-21, loop :264-302)
+// ------------------------------------------------------------------------------------
+struct FMinSearch {
+    int N = 0, N1 = 0, maxiters = 10000, iters = 0, bymax = 0;
+    double rho = 1, chi = 2, psi = 0.5, sigma = 0.5, tolx = 1e-6, tolf = 1e-6, delta = 0.05, zero_delta = 0.00025;
+    std::vector<std::vector<double>> v, vsort;
+    std::vector<double> fv, x_mean, x_r, x_tmp;
+    std::vector<int> idx;
+    std::function<double(const double*)> eq;
+
+    void init(int n)
+    {
+        N = n;
+        N1 = n + 1;
+        v.assign(N1, std::vector<double>(N, 0.0));
+        vsort = v;
+        fv.assign(N1, 0.0);
+        x_mean.assign(N, 0.0);
+        x_r.assign(N, 0.0);
+        x_tmp.assign(N, 0.0);
+        idx.assign(N1, 0);
+    }
+
+    // __qsort_double_with_index :77-107
+    void qsort_idx(int left, int right)
+    {
+        double pivot = fv[left];
+        int pivot_idx = idx[left];
+        int from = left, to = right;
+        while (from < to) {
+            while (pivot <= fv[to] && from < to) to--;
+            if (from != to) {
+                fv[from] = fv[to];
+                idx[from] = idx[to];
+                from++;
+            }
+            while (pivot >= fv[from] && from < to) from++;
+            if (from != to) {
+                fv[to] = fv[from];
+                idx[to] = idx[from];
+                to--;
+            }
+        }
+        fv[from] = pivot;
+        idx[from] = pivot_idx;
+        if (left < from) qsort_idx(left, from - 1);
+        if (right > from) qsort_idx(from + 1, right);
+    }
+
+    void sort()
+    {  // __fminsearch_sort :109-123
+        for (int i = 0; i < N1; ++i) idx[i] = i;
+        qsort_idx(0, N);
+        for (int i = 0; i < N1; ++i) vsort[i] = v[idx[i]];
+        v = vsort;
+    }
+
+    bool checkV() const
+    {  // :126-141
+        double mx = -1.7976931348623157e+308;
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) mx = std::max(mx, std::fabs(v[i + 1][j] - v[i][j]));
+        return mx <= tolx;
+    }
+
+    bool checkF() const
+    {  // :143-154
+        double mx = -1.7976931348623157e+308;
+        for (int i = 1; i < N1; ++i) mx = std::max(mx, std::fabs(fv[i] - fv[0]));
+        return mx <= tolf;
+    }
+
+    void set_last(const std::vector<double>& x, double f)
+    {  // :252-262
+        v[N] = x;
+        fv[N] = f;
+        sort();
+    }
+
+    void shrink()
+    {  // :238-250
+        for (int i = 1; i < N1; ++i) {
+            for (int j = 0; j < N; ++j) v[i][j] = v[0][j] + sigma * (v[i][j] - v[0][j]);
+            fv[i] = eq(v[i].data());
+        }
+        sort();
+    }
+
+    int minimize(const double* X0)
+    {
+        // __fminsearch_min_init :156-187 (note the isinf(previous vertex) rule)
+        for (int i = 0; i < N1; ++i) {
+            for (int j = 0; j < N; ++j) {
+                const bool big = (i > 1 && std::isinf(fv[i - 1]));
+                if ((i - 1) == j)
+                    v[i][j] = X0[j] ? (1 + (big ? delta * 100 : delta)) * X0[j] : zero_delta;
+                else
+                    v[i][j] = X0[j];
+            }
+            fv[i] = eq(v[i].data());
+        }
+        sort();
+        int i;
+        for (i = 0; i < maxiters; ++i) {
+            if (checkV() && checkF()) break;
+            for (int a = 0; a < N; ++a) {  // x_mean :189-201
+                x_mean[a] = 0;
+                for (int j = 0; j < N; ++j) x_mean[a] += v[j][a];
+                x_mean[a] /= N;
+            }
+            for (int a = 0; a < N; ++a) x_r[a] = x_mean[a] + rho * (x_mean[a] - v[N][a]);
+            const double fv_r = eq(x_r.data());
+            if (fv_r < fv[0]) {
+                for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + chi * (x_r[a] - x_mean[a]);
+                const double fv_e = eq(x_tmp.data());
+                if (fv_e < fv_r)
+                    set_last(x_tmp, fv_e);
+                else
+                    set_last(x_r, fv_r);
+            } else if (fv_r >= fv[N]) {
+                if (fv_r > fv[N]) {
+                    for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + psi * (x_mean[a] - v[N][a]);
+                    const double fv_cc = eq(x_tmp.data());
+                    if (fv_cc < fv[N])
+                        set_last(x_tmp, fv_cc);
+                    else
+                        shrink();
+                } else {
+                    for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + psi * (x_r[a] - x_mean[a]);
+                    const double fv_c = eq(x_tmp.data());
+                    if (fv_c <= fv_r)
+                        set_last(x_tmp, fv_c);
+                    else
+                        shrink();
+                }
+            } else {
+                set_last(x_r, fv_r);
+            }
+        }
+        bymax = (i == maxiters);
+        iters = i;
+        return bymax;
+    }
+};
+
+double unifrnd() { return rand() / (RAND_MAX + 1.0); }  // libcommon/mathfunc.c:91-94
+
+// poisspdf, libcommon/mathfunc.c:352-355
+double poisspdf(int x, double lambda) { return std::exp(x * std::log(lambda) - cafehip::gammaln(x + 1) - lambda); }
+
+std::string join_double(const double* v, int n)
+{  // string_pchar_join_double, libcommon/utils_string.c:227-237
+    std::string out;
+    char buf[64];
+    for (int i = 0; i < n; ++i) {
+        snprintf(buf, sizeof buf, "%15.14lf", v[i]);
+        out += buf;
+        if (i < n - 1) out += ",";
+    }
+    return out;
+}
+
+struct Argument {
+    std::string opt;
+    std::vector<std::string> argv;
+};
+
+bool is_number(const std::string& s)
+{
+    char* end = nullptr;
+    strtod(s.c_str(), &end);
+    return end != s.c_str() && *end == '\0';
+}
+
+// build_argument_list, cafe/cafe_commands.cpp:476-502: "-x" starts an option unless it is a number
+std::vector<Argument> build_argument_list(const std::vector<std::string>& tokens)
+{
+    std::vector<Argument> out;
+    for (size_t i = 1; i < tokens.size(); ++i) {
+        const std::string& t = tokens[i];
+        if (t.size() > 1 && t[0] == '-' && !is_number(t)) {
+            out.push_back(Argument{t, {}});
+        } else if (!out.empty()) {
+            out.back().argv.push_back(t);
+        }
+    }
+    return out;
+}
+
+}  // namespace
+
+// ====================================================================================
+// session == CafeParam
+// ====================================================================================
+struct cafehost_session {
+    cafehip_ctx* ctx = nullptr;
+    FILE* flog = stdout;
+    bool own_log = false;
+    std::string log_name = "stdout";
+    bool quiet = false;
+
+    bool have_tree = false, have_family = false;
+    HostTree tree;
+    HostTree lambda_tree;
+    bool have_lambda_tree = false;
+    std::vector<int> node_class;  // taxaid per node (cafe/cafe_shell.c:324-332), -1.. -> 0
+    HostFamilies fam;
+    std::vector<int> species_index;  // species -> node id, -1 if absent (cafe/gene_family.cpp:413-445)
+    HostRange range;
+    double pvalue = 0.01;
+    int num_threads = 1;
+    int num_random_samples = 1000;
+    bool device_families_current = false;
+
+    // model state
+    int num_lambdas = 1, num_mus = 0, num_params = 0;
+    bool has_mu = false, eqbg = false, checkconv = false;
+    std::vector<double> params;
+    std::vector<double> prior;  // FAMILYSIZEMAX entries
+    double poisson_lambda = 0, last_score = 0;
+    int search_iters = 0, n_evals = 0;
+    double search_seconds = 0;
+    std::vector<double> trace;
+
+    void log(const char* fmt, ...)
+    {  // cafe_log, cafe/cafe_main.c:26-44
+        va_list ap;
+        va_start(ap, fmt);
+        vfprintf(flog, fmt, ap);
+        va_end(ap);
+        fflush(flog);
+    }
+
+    void hip_check(int rc)
+    {
+        if (rc != 0) throw std::runtime_error(std::string("cafehip: ") + cafehip_last_error());
+    }
+
+    // cafe_family_set_species_index, cafe/gene_family.cpp:413-445
+    void sync_species_index()
+    {
+        if (!have_tree || !have_family) return;
+        species_index.assign(fam.species.size(), -1);
+        std::vector<bool> leaf_found(tree.n, false);
+        for (size_t s = 0; s < fam.species.size(); ++s) {
+            for (int i = 0; i < tree.n; i += 2) {
+                if (iequals(fam.species[s], tree.name[i])) {
+                    species_index[s] = i;
+                    leaf_found[i] = true;
+                    break;
+                }
+            }
+        }
+        for (int i = 0; i < tree.n; i += 2)
+            if (!leaf_found[i]) throw std::runtime_error("No species '" + tree.name[i] + "' was found in the tree");
+        device_families_current = false;
+    }
+
+    void upload()
+    {
+        if (device_families_current) return;
+        hip_check(cafehip_set_tree(ctx, tree.n, tree.parent.data(), tree.left.data(), tree.right.data(), tree.bl.data()));
+        const int nl = tree.n_leaves();
+        const int F = fam.F();
+        const int ns = (int)fam.species.size();
+        std::vector<int32_t> counts((size_t)std::max(F, 1) * nl, 0);
+        for (int i = 0; i < F; ++i)
+            for (int s = 0; s < ns; ++s)
+                if (species_index[s] >= 0) counts[(size_t)i * nl + species_index[s] / 2] = fam.counts[(size_t)i * ns + s];
+        hip_check(cafehip_set_families(ctx, F, nl, counts.data(), nullptr, range.min, range.max, range.root_min, range.root_max));
+        device_families_current = true;
+    }
+
+    // ---- prior: cafe_set_prior_rfsize_empirical, cafe/lambda.cpp:808-870 ----
+    void set_prior_rfsize_empirical()
+    {
+        std::vector<int> leaf_sizes;  // collect_leaf_sizes :789-806
+        const int ns = (int)fam.species.size();
+        for (int idx = 0; idx < fam.F(); ++idx)
+            for (int i = 0; i < ns; ++i) {
+                if (species_index[i] < 0) continue;
+                const int cnt = fam.counts[(size_t)idx * ns + i];
+                if (cnt > 0) leaf_sizes.push_back(cnt - 1);
+            }
+        FMinSearch pfm;
+        pfm.init(1);
+        pfm.tolx = 1e-6;
+        pfm.tolf = 1e-6;
+        pfm.eq = [&](const double* pl) {  // __lnLPoisson :771-787
+            double score = 0;
+            for (int x : leaf_sizes) {
+                double ll = poisspdf(x, pl[0]);
+                if (std::isnan(ll)) ll = 0;
+                score += std::log(ll);
+            }
+            return -score;
+        };
+        double start = unifrnd();
+        pfm.minimize(&start);
+        poisson_lambda = pfm.v[0][0];
+        log("Empirical Prior Estimation Result: (%d iterations)\n", pfm.iters);
+        log("Poisson lambda: %f & Score: %f\n", poisson_lambda, pfm.fv[0]);
+        prior.assign(1000, 0.0);  // cafe_set_prior_rfsize_poisson_lambda :841-852
+        for (int i = 0; i < 1000; ++i) prior[i] = poisspdf(range.root_min - 1 + i, poisson_lambda);
+    }
+
+    // ---- cafe_shell_set_lambdas (cafe/cafe_shell.c:31-38) -> per-node (lambda, mu) ----
+    void node_rates(const double* x, std::vector<double>& nl, std::vector<double>& nm) const
+    {
+        nl.assign(tree.n, 0.0);
+        nm.assign(tree.n, -1.0);
+        for (int i = 0; i < tree.n; ++i) {
+            int cls = have_lambda_tree ? node_class[i] : 0;
+            if (cls < 0) cls = 0;  // cafe/cafe_shell.c:150-156
+            if (!has_mu) {
+                nl[i] = x[cls];  // set_birth_death_probabilities4 :172-175
+                nm[i] = -1;
+            } else if (!have_lambda_tree) {
+                nl[i] = x[0];  // set_birth_death_probabilities :48-52
+                nm[i] = x[num_lambdas];
+            } else if (eqbg) {
+                nl[i] = x[cls];  // set_birth_death_probabilities2 :127-136
+                nm[i] = (cls == 0) ? nl[i] : x[num_lambdas + (cls - 1)];
+            } else {
+                nl[i] = x[cls];  // :138-141
+                nm[i] = x[num_lambdas + cls];
+            }
+        }
+    }
+
+    // __cafe_best_lambda_search (cafe/lambda.cpp:726-769) / cafe_best_lambda_mu_search (cafe/lambdamu.cpp:323-367)
+    double objective(const double* x)
+    {
+        double score = 0;
+        bool skip = false;
+        const int ncheck = has_mu ? num_params : num_lambdas;
+        for (int i = 0; i < ncheck; ++i)
+            if (x[i] < 0) {
+                skip = true;
+                score = std::log(0.0);
+                break;
+            }
+        if (!skip) {
+            std::vector<double> nl, nm;
+            node_rates(x, nl, nm);
+            int32_t zero = -1;
+            hip_check(cafehip_eval_posterior(ctx, nl.data(), nm.data(), prior.data(), &score, &zero, nullptr, nullptr, nullptr));
+            if (zero >= 0) {  // cafe/lambda.cpp:715-720, 753-760
+                if (!quiet)
+                    fprintf(stderr, "WARNING: Calculated posterior probability for family %s = 0\n", fam.ids[zero].c_str());
+                score = std::log(0.0);
+            }
+        }
+        ++n_evals;
+        for (int i = 0; i < num_params; ++i) trace.push_back(x[i]);
+        trace.push_back(score);
+        if (!has_mu) {
+            log("Lambda : %s & Score: %f\n", join_double(x, num_lambdas).c_str(), score);
+        } else {
+            log("Lambda : %s ", join_double(x, num_lambdas).c_str());
+            log("Mu : %s & Score: %f\n", join_double(x + num_lambdas, num_mus - (eqbg ? 1 : 0)).c_str(), score);
+        }
+        log(".");
+        return -score;
+    }
+
+    // cafe_best_lambda_by_fminsearch (cafe/lambda.cpp:525-647) / best_lambda_mu_by_fminsearch (cafe/lambdamu.cpp:370-474)
+    void search()
+    {
+        const int max_runs = 10;
+        std::vector<double> scores;
+        bool converged = false;
+        int runs = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        do {
+            // input_values_randomize, cafe/cafe_main.c:124-163 (k == 0 branch)
+            const double mbl = tree.max_branch_length();
+            params.assign(num_params, 0.0);
+            for (int i = 0; i < num_lambdas; ++i) params[i] = 1.0 / mbl * unifrnd();
+            const int mu_len = has_mu ? (num_mus - (eqbg ? 1 : 0)) : 0;
+            // the reference draws param->num_mus values here even with -eqbg (one more than it keeps)
+            for (int i = 0; i < (has_mu ? num_mus : 0); ++i) {
+                const double r = 1.0 / mbl * unifrnd();
+                if (i < mu_len) params[num_lambdas + i] = r;
+            }
+            FMinSearch pfm;
+            pfm.init(num_params);
+            pfm.tolx = 1e-6;
+            pfm.tolf = 1e-6;
+            pfm.eq = [&](const double* x) { return objective(x); };
+            std::vector<double> start = params;
+            pfm.minimize(start.data());
+            params = pfm.v[0];
+            search_iters = pfm.iters;
+            last_score = pfm.fv[0];
+            log("\n");
+            log("Lambda Search Result: %d\n", pfm.iters);
+            if (!has_mu) {
+                log("Lambda : %s & Score: %f\n", join_double(params.data(), num_lambdas).c_str(), pfm.fv[0]);
+            } else {
+                log("Lambda : %s & Score: %f", join_double(params.data(), num_lambdas).c_str(), pfm.fv[0]);
+                log("Mu : %s & Score: %f\n", join_double(params.data() + num_lambdas, mu_len).c_str(), pfm.fv[0]);
+            }
+            if (runs > 0) {
+                const double minscore = *std::min_element(scores.begin(), scores.end());
+                if (std::fabs(minscore - pfm.fv[0]) < 10 * pfm.tolf) converged = true;
+            }
+            scores.push_back(pfm.fv[0]);
+            ++runs;
+        } while (checkconv && !converged && runs < max_runs);
+        search_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (checkconv) {
+            if (converged)
+                log("score converged in %d runs.\n", runs);
+            else
+                log("score failed to converge in %d runs.\n", max_runs);
+        }
+    }
+
+    // __cafe_cmd_lambda_tree, cafe/cafe_shell.c:334-393
+    void set_lambda_tree(const std::string& text)
+    {
+        HostTree lt = HostTree::parse(text);
+        if (lt.n != tree.n) throw std::runtime_error("Lambda has a different topology from the tree");
+        node_class.assign(lt.n, -1);
+        int named = 0;
+        std::vector<int> seen;
+        for (int i = 0; i < lt.n; ++i) {
+            int taxaid = 0;
+            if (!lt.name[i].empty()) {
+                sscanf(lt.name[i].c_str(), "%d", &taxaid);
+                ++named;
+            }
+            node_class[i] = taxaid - 1;  // phylogeny_lambda_parse_func :324-332
+            if (node_class[i] >= 0 && std::find(seen.begin(), seen.end(), node_class[i]) == seen.end())
+                seen.push_back(node_class[i]);
+        }
+        if (named != lt.n - 1)
+            throw std::runtime_error("ERROR(lambda -t): Branch lambda classes not totally specified.\n" + text +
+                                     "\nYou have to specify lambda classes for all branches including the internal "
+                                     "branches of the tree.");
+        for (int c : seen)
+            if (c >= (int)seen.size()) throw std::runtime_error("lambda classes must be numbered 1.." + std::to_string(seen.size()));
+        lambda_tree = lt;
+        have_lambda_tree = true;
+        num_lambdas = (int)seen.size();
+        if (!quiet) printf("The number of lambdas is %d\n", num_lambdas);
+        log("Lambda Tree: %s\n", text.c_str());
+    }
+
+    void prereqs(bool need_family, bool need_tree)
+    {
+        if (need_family && !have_family) throw std::runtime_error("ERROR: The gene families were not loaded. Please load gene families with the 'load' command.\n");
+        if (need_tree && !have_tree) throw std::runtime_error("ERROR: The tree was not loaded. Please load a tree with the 'tree' command.\n");
+    }
+
+    // ---- commands ----------------------------------------------------------------------
+    int cmd_load(const std::vector<std::string>& tokens)
+    {  // cafe_cmd_load, cafe/cafe_commands.cpp:868-970; args :817-866
+        auto args = build_argument_list(tokens);
+        std::string file;
+        int max_size = -1;
+        for (auto& a : args) {
+            if (a.opt == "-t" && !a.argv.empty()) num_threads = atoi(a.argv[0].c_str());
+            if (a.opt == "-r" && !a.argv.empty()) num_random_samples = atoi(a.argv[0].c_str());
+            if (a.opt == "-max_size" && !a.argv.empty()) max_size = atoi(a.argv[0].c_str());
+            if (a.opt == "-p" && !a.argv.empty()) pvalue = atof(a.argv[0].c_str());
+            if (a.opt == "-l" && !a.argv.empty() && a.argv[0] != "stdout") {
+                std::string name;
+                for (size_t i = 0; i < a.argv.size(); ++i) name += (i ? " " : "") + a.argv[i];
+                FILE* f = fopen(name.c_str(), "a");
+                if (!f) throw std::runtime_error("ERROR(load): Cannot open log file: " + name);
+                if (own_log) fclose(flog);
+                flog = f;
+                own_log = true;
+                log_name = name;
+            }
+            if (a.opt == "-filter") throw std::runtime_error("load -filter (parsimony root filter, cafe/gene_family.cpp:273-353) is outside this build's scope");
+            if (a.opt == "-i") {
+                for (size_t i = 0; i < a.argv.size(); ++i) file += (i ? " " : "") + a.argv[i];
+            }
+        }
+        if (file.empty()) throw std::runtime_error("Usage(load): load <family file>");
+        fam.load(file, max_size);
+        have_family = true;
+        range = init_family_size(fam.max_size);  // set_range_from_family
+        sync_species_index();
+        device_families_current = false;
+        // log_param_values, cafe/cafe_commands.cpp:1918-1943
+        log("-----------------------------------------------------------\n");
+        log("Family information: %s\n", file.c_str());
+        log("Log: %s\n", log_name.c_str());
+        if (have_tree) log("Tree: %s\n", tree.newick.c_str());
+        log("The number of families is %d\n", fam.F());
+        log("Root Family size : %d ~ %d\n", range.root_min, range.root_max);
+        log("Family size : %d ~ %d\n", range.min, range.max);
+        log("P-value: %g\n", pvalue);
+        log("Num of Threads: %d\n", num_threads);
+        log("Num of Random: %d\n", num_random_samples);
+        return 0;
+    }
+
+    int cmd_tree(const std::vector<std::string>& tokens)
+    {  // cafe_cmd_tree, cafe/cafe_commands.cpp:1127-1190
+        std::string newick;
+        if (tokens.size() > 2 && tokens[1] == "-i") {
+            std::ifstream in(tokens[2]);
+            if (!in) throw std::runtime_error("Failed to read file '" + tokens[2] + "'");
+            std::stringstream ss;
+            ss << in.rdbuf();
+            newick = ss.str();
+        } else if (tokens.size() >= 2) {
+            for (size_t i = 1; i < tokens.size(); ++i) newick += tokens[i];
+        } else {
+            throw std::runtime_error("Usage(tree): tree <newick>");
+        }
+        tree = HostTree::parse(newick);
+        have_tree = true;
+        have_lambda_tree = false;
+        if (!quiet) log("%s\n", tree.newick.c_str());
+        sync_species_index();
+        device_families_current = false;
+        return 0;
+    }
+
+    static std::vector<double> doubles_of(const Argument& a)
+    {
+        std::vector<double> out;
+        for (auto& s : a.argv) out.push_back(atof(s.c_str()));
+        return out;
+    }
+
+    void finish_command(const std::vector<std::string>& tokens, const char* what)
+    {
+        // after lambda/lambdamu the cache is rebuilt for the final parameters and left resident
+        // (cafe/lambda.cpp:504-507, cafe/lambdamu.cpp:254-257)
+        std::vector<double> nl, nm;
+        node_rates(params.data(), nl, nm);
+        bool ok = true;
+        for (double v : nl) ok = ok && v >= 0;
+        if (ok) hip_check(cafehip_reset_birthdeath_cache(ctx, nl.data(), nm.data()));
+        log("DONE: %s Search or setting, for command:\n", what);
+        std::string cmd;
+        for (auto& t : tokens) cmd += t + " ";
+        log("%s\n", cmd.c_str());
+    }
+
+    int cmd_lambda(const std::vector<std::string>& tokens)
+    {  // cafe_cmd_lambda, cafe/lambda.cpp:369-515
+        prereqs(true, true);
+        auto args = build_argument_list(tokens);
+        has_mu = false;
+        eqbg = false;
+        num_mus = 0;
+        checkconv = false;
+        have_lambda_tree = false;
+        num_lambdas = 1;
+        bool search_flag = false, score_flag = false;
+        std::vector<double> lambdas;
+        for (auto& a : args) {
+            if (a.opt == "-s") search_flag = true;
+            else if (a.opt == "-checkconv") checkconv = true;
+            else if (a.opt == "-score") score_flag = true;
+            else if (a.opt == "-t") {
+                if (a.argv.empty()) throw std::runtime_error("lambda -t needs a lambda tree");
+                set_lambda_tree(a.argv.back());
+            } else if (a.opt == "-l") lambdas = doubles_of(a);
+            else
+                throw std::runtime_error("lambda " + a.opt + " is outside this build's scope (supported: -s -l -t -score -checkconv)");
+        }
+        upload();
+        n_evals = 0;
+        trace.clear();
+        set_prior_rfsize_empirical();
+        num_params = num_lambdas;
+        if (search_flag) {
+            search();
+        } else {
+            if ((int)lambdas.size() != num_lambdas)
+                throw std::runtime_error("ERROR(lambda): Number of parameters not correct. The number of -l lambdas are " +
+                                         std::to_string(lambdas.size()) + " they need to be " + std::to_string(num_lambdas));
+            params = lambdas;
+            if (score_flag) last_score = objective(params.data());
+        }
+        finish_command(tokens, "Lambda");
+        return 0;
+    }
+
+    int cmd_lambdamu(const std::vector<std::string>& tokens)
+    {  // cafe_cmd_lambdamu, cafe/lambdamu.cpp:218-269
+        prereqs(true, true);
+        auto args = build_argument_list(tokens);
+        has_mu = true;
+        eqbg = false;
+        checkconv = false;
+        have_lambda_tree = false;
+        num_lambdas = 1;
+        bool search_flag = false;
+        std::vector<double> lambdas, mus;
+        for (auto& a : args) {
+            if (a.opt == "-s") search_flag = true;
+            else if (a.opt == "-checkconv") checkconv = true;
+            else if (a.opt == "-eqbg") eqbg = true;
+            else if (a.opt == "-t") {
+                if (a.argv.empty()) throw std::runtime_error("lambdamu -t needs a lambda tree");
+                set_lambda_tree(a.argv.back());
+            } else if (a.opt == "-l") lambdas = doubles_of(a);
+            else if (a.opt == "-m") mus = doubles_of(a);
+            else
+                throw std::runtime_error("lambdamu " + a.opt + " is outside this build's scope (supported: -s -l -m -t -eqbg -checkconv)");
+        }
+        if (eqbg && !have_lambda_tree)
+            throw std::runtime_error("ERROR(lambdamu): Cannot use option eqbg without specifying a lambda tree. \n");
+        num_mus = num_lambdas;
+        num_params = num_lambdas + num_mus - (eqbg ? 1 : 0);
+        upload();
+        n_evals = 0;
+        trace.clear();
+        set_prior_rfsize_empirical();
+        if (search_flag) {
+            search();
+        } else {
+            if ((int)(lambdas.size() + mus.size()) != num_params)
+                throw std::runtime_error("ERROR(lambdamu): Number of parameters not correct.");
+            params = lambdas;
+            params.insert(params.end(), mus.begin(), mus.end());
+            last_score = objective(params.data());
+        }
+        finish_command(tokens, "Lamda,Mu");
+        return 0;
+    }
+
+    int dispatch(const std::string& line_in)
+    {
+        std::string line = line_in;
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r' || line.back() == ' ' || line.back() == '\t')) line.pop_back();
+        size_t b = 0;
+        while (b < line.size() && isspace((unsigned char)line[b])) ++b;
+        if (b >= line.size() || line[b] == '#') return 0;
+        std::vector<std::string> tokens;
+        {
+            std::istringstream ss(line.substr(b));
+            std::string t;
+            while (ss >> t) tokens.push_back(t);
+        }
+        const std::string& cmd = tokens[0];
+        if (cmd == "exit" || cmd == "quit") return 1;
+        if (cmd == "seed") {  // cafe/cafe_commands.cpp:1950-1965
+            if (tokens.size() < 2) throw std::runtime_error("Usage(seed): seed <value>");
+            srand((unsigned)atoi(tokens[1].c_str()));
+            return 0;
+        }
+        if (cmd == "date") {  // :262-270
+            time_t now = time(nullptr);
+            log("%s", ctime(&now));
+            return 0;
+        }
+        if (cmd == "echo") {
+            std::string out;
+            for (size_t i = 1; i < tokens.size(); ++i) out += (i > 1 ? " " : "") + tokens[i];
+            log("%s\n", out.c_str());
+            return 0;
+        }
+        if (cmd == "version") {
+            log("Version: cafehip 0.1 (MI355X hot path for CAFE 4.2.1 semantics)\n");
+            return 0;
+        }
+        if (cmd == "source") {
+            if (tokens.size() < 2) throw std::runtime_error("Usage(source): source <file>");
+            return run_script(tokens[1]);
+        }
+        if (cmd == "load") return cmd_load(tokens);
+        if (cmd == "tree") return cmd_tree(tokens);
+        if (cmd == "lambda") return cmd_lambda(tokens);
+        if (cmd == "lambdamu") return cmd_lambdamu(tokens);
+        throw std::runtime_error("command '" + cmd + "' is outside this build's scope (SURVEY.md section 8)");
+    }
+
+    int run_script(const std::string& path)
+    {
+        std::ifstream in(path);
+        if (!in) throw std::runtime_error("Error(source): Cannot open " + path);
+        std::string line;
+        while (std::getline(in, line)) {
+            const int rc = dispatch(line);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
+};
+
+// ====================================================================================
+// C API
+// ====================================================================================
+extern "C" {
+
+const char* cafehost_last_error(void) { return g_host_err.c_str(); }
+
+int cafehost_create(cafehost_session** out, int device_id, const char* log_path)
+{
+    if (!out) return host_fail("null out pointer");
+    *out = nullptr;
+    cafehost_session* s = new cafehost_session();
+    if (cafehip_create(&s->ctx, device_id) != 0) {
+        host_fail(std::string("cafehip: ") + cafehip_last_error());
+        delete s;
+        return -1;
+    }
+    if (log_path && strcmp(log_path, "stdout") != 0 && *log_path) {
+        s->flog = fopen(log_path, "w");
+        if (!s->flog) {
+            cafehip_destroy(s->ctx);
+            delete s;
+            return host_fail(std::string("cannot open log file ") + log_path);
+        }
+        s->own_log = true;
+        s->log_name = log_path;
+    }
+    *out = s;
+    return 0;
+}
+
+void cafehost_destroy(cafehost_session* s)
+{
+    if (!s) return;
+    if (s->own_log && s->flog) fclose(s->flog);
+    cafehip_destroy(s->ctx);
+    delete s;
+}
+
+int cafehost_dispatch(cafehost_session* s, const char* command_line)
+{
+    if (!s || !command_line) return host_fail("null argument");
+    try {
+        return s->dispatch(command_line);
+    } catch (const std::exception& e) {  // cafe/cafe_commands.cpp:531-535
+        return host_fail(e.what());
+    }
+}
+
+int cafehost_run_script(cafehost_session* s, const char* path)
+{
+    if (!s || !path) return host_fail("null argument");
+    try {
+        return s->run_script(path);
+    } catch (const std::exception& e) {
+        return host_fail(e.what());
+    }
+}
+
+int cafehost_num_params(cafehost_session* s) { return s ? s->num_params : -1; }
+
+int cafehost_get_params(cafehost_session* s, double* out, int n)
+{
+    if (!s || !out) return host_fail("null argument");
+    const int m = std::min<int>(n, (int)s->params.size());
+    for (int i = 0; i < m; ++i) out[i] = s->params[i];
+    return m;
+}
+
+double cafehost_last_score(cafehost_session* s) { return s ? s->last_score : NAN; }
+int cafehost_search_iterations(cafehost_session* s) { return s ? s->search_iters : -1; }
+int cafehost_num_evaluations(cafehost_session* s) { return s ? s->n_evals : -1; }
+double cafehost_search_seconds(cafehost_session* s) { return s ? s->search_seconds : NAN; }
+double cafehost_poisson_lambda(cafehost_session* s) { return s ? s->poisson_lambda : NAN; }
+
+int cafehost_get_trace(cafehost_session* s, double* out, int max_rows)
+{
+    if (!s || !out) return host_fail("null argument");
+    const int w = s->num_params + 1;
+    const int rows = std::min<int>(max_rows, w ? (int)s->trace.size() / w : 0);
+    std::copy(s->trace.begin(), s->trace.begin() + (size_t)rows * w, out);
+    return rows;
+}
+
+}  // extern "C"

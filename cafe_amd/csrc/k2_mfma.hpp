@@ -11,8 +11,8 @@
 // One workgroup owns NF = 16*NFT families and walks the whole tree for them:
 //   * ONE node-vector buffer Lbuf[NF][LDv] in LDS; results that are not consumed by the
 //     next step are parked in a per-workgroup global scratch region (MfmaSchedule);
-//   * waves are arranged Wf x Wr: wave (wf, wr) owns family tiles [wf*NFT_W, +NFT_W) and
-//     row tiles [wr*NRT_W, +NRT_W): NFT_W*NRT_W accumulator tiles (4 f64 per lane each);
+//   * waves are arranged Wf x Wr: wave (wf, wr) owns family tiles [wf*NFT_W, +NFT_W) and an even
+//     share (<= NRT_W) of the step's row tiles: NFT_W*NRT_W accumulator tiles (4 f64 per lane each);
 //   * leaf children are column gathers PT[count][row] in the D layout; the Hadamard
 //     product of the two child factors is taken in registers (cafe/cafe_tree.c:261-266).
 // Layouts (lane l of a wave): A lane holds L[fam0 + (l&15)][k0 + (l>>4)];
@@ -116,7 +116,6 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     const int wf = wave % a.Wf;
     const int wr = wave / a.Wf;
     const int ft0 = wf * NFT_W;
-    const int rt0 = wr * NRT_W;
     const int fam0 = blockIdx.x * a.NF;
     const bool batch = (a.col_max != nullptr);
     const size_t park_stride = (size_t)a.NF * a.LDv;
@@ -139,8 +138,11 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
         const cafehip::MfmaOp op = a.ops[oi];
         const int rows = op.is_root ? a.R : a.C;
         const int row_lo = op.is_root ? a.root_min : 0;
-        const int RT = (rows + 15) >> 4;           // active row tiles of this step
-        const bool wave_active = rt0 < RT;
+        const int RT = (rows + 15) >> 4;           // row tiles of this step, dealt evenly to the Wr wave rows
+        const int rt_base = RT / a.Wr, rt_rem = RT - rt_base * a.Wr;
+        const int ntile = rt_base + (wr < rt_rem ? 1 : 0);  // <= NRT_W
+        const int rt0 = wr * rt_base + min(wr, rt_rem);
+        const bool wave_active = ntile > 0;
 
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                         const bool ok = cnt <= s_colmax[f];
 #pragma unroll
                         for (int j = 0; j < NRT_W; ++j) {
-                            const bool act = (rt0 + j) < RT;
+                            const bool act = j < ntile;
                             fac[i][j][r] = (ok && act) ? PTe[(size_t)cnt * a.LD + (rt0 + j) * 16 + li] : 0.0;
                         }
                     }
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                     int boff[NRT_W];
 #pragma unroll
                     for (int j = 0; j < NRT_W; ++j)
-                        boff[j] = (((rt0 + j) < RT) ? (rt0 + j) : rt0) * 16;  // inactive tiles re-read tile rt0
+                        boff[j] = ((j < ntile) ? (rt0 + j) : rt0) * 16;  // inactive tiles re-read tile rt0
                     const double* bp = PTe + (size_t)lk * a.LD + li;
                     const double* ap = Lbuf + (size_t)(ft0 * 16 + li) * a.LDv + lk;
                     mfma_edge<NFT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                 const int cm = s_colmax[f];
 #pragma unroll
                 for (int j = 0; j < NRT_W; ++j) {
-                    if ((rt0 + j) < RT) {
+                    if (j < ntile) {
                         const int row = (rt0 + j) * 16 + li;
                         double v = hold[i][j][r];
                         // rows beyond this family's column range do not exist in the reference

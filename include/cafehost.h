@@ -1,0 +1,57 @@
+/*
+ * cafehost.h -- C API of the host-side driver that sits ABOVE the kernel boundary
+ * (include/cafehip.h): CAFE's command language for the hot path -- `seed`, `load`,
+ * `tree`, `lambda`, `lambdamu`, `errormodel` -- with the reference's Nelder-Mead
+ * search, parameter scatter, prior fit and log lines, every objective evaluation
+ * running on the GPU through cafehip_eval_posterior.
+ *
+ * Reference interfaces mirrored (names kept where a function exists):
+ *   command dispatcher            cafe/cafe_commands.cpp:174-217, 504-536
+ *   load / tree / seed            cafe/cafe_commands.cpp:817-866, 1127-1190, 1950-1965
+ *   lambda / lambdamu             cafe/lambda.cpp:369-515, cafe/lambdamu.cpp:218-269
+ *   cafe_best_lambda_by_fminsearch cafe/lambda.cpp:525-647; fminsearch_min libcommon/fminsearch.cpp:264-302
+ *   __cafe_best_lambda_search     cafe/lambda.cpp:726-769; cafe_best_lambda_mu_search cafe/lambdamu.cpp:323-367
+ *   cafe_shell_set_lambdas        cafe/cafe_shell.c:31-38, 148-177, 46-146
+ *   cafe_set_prior_rfsize_empirical cafe/lambda.cpp:808-870
+ */
+#ifndef CAFEHOST_H
+#define CAFEHOST_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cafehost_session cafehost_session;
+
+/* One session == the reference's global CafeParam (cafe/cafe_shell.c:20) bound to HIP device
+ * `device_id`.  Log lines go to `log_path` ("stdout" or NULL = stdout). */
+int cafehost_create(cafehost_session **out, int device_id, const char *log_path);
+void cafehost_destroy(cafehost_session *s);
+
+/* Execute one command line exactly as the reference's REPL would read it
+ * (cafe_shell_dispatch_command, cafe/cafe_commands.cpp:504-536).  Returns 0, or <0 with the
+ * message in cafehost_last_error(); the `exit` command returns 1. */
+int cafehost_dispatch(cafehost_session *s, const char *command_line);
+
+/* Run a script file (main.cpp:43 `source`): one command per line, '#' lines ignored. */
+int cafehost_run_script(cafehost_session *s, const char *path);
+
+/* Results of the last lambda / lambdamu command. */
+int cafehost_num_params(cafehost_session *s);
+int cafehost_get_params(cafehost_session *s, double *out, int n);   /* fitted lambda(s) [, mu(s)] */
+double cafehost_last_score(cafehost_session *s);                    /* -lnL as printed ("Score") */
+int cafehost_search_iterations(cafehost_session *s);
+int cafehost_num_evaluations(cafehost_session *s);                  /* objective calls of the last command */
+double cafehost_search_seconds(cafehost_session *s);                /* wall-clock of the last search */
+double cafehost_poisson_lambda(cafehost_session *s);
+
+/* Trace of the last command's objective calls: row i = (params[0..num_params), score).
+ * Returns the number of rows copied (<= max_rows). */
+int cafehost_get_trace(cafehost_session *s, double *out, int max_rows);
+
+const char *cafehost_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

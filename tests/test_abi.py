@@ -12,10 +12,10 @@ from cafe_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "cafehip.h")).read()
+def declared_symbols(header="cafehip.h", prefix="cafehip_"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(cafehip_[a-z_0-9]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z_0-9]+)\s*\(", txt)))
 
 
 def test_header_and_binding_agree():
@@ -24,9 +24,15 @@ def test_header_and_binding_agree():
     assert sorted(_lib.SIGNATURES) == syms
 
 
+def test_host_header_and_binding_agree():
+    syms = declared_symbols("cafehost.h", "cafehost_")
+    assert len(syms) >= 10
+    assert sorted(_lib.HOST_SIGNATURES) == syms
+
+
 def test_library_exports_every_declared_symbol():
     L = cafe_amd.load()
-    for s in declared_symbols():
+    for s in declared_symbols() + declared_symbols("cafehost.h", "cafehost_"):
         assert hasattr(L, s), s
     assert L.cafehip_abi_version() == 1
 

@@ -1,0 +1,137 @@
+"""End-to-end parity of the host driver (cafehost: seed/load/tree/lambda/lambdamu over the GPU
+objective) against the reference's golden transcripts tests/integration/test1.t and test2.t: the
+same commands must print the same sequence of (lambda, score) evaluations and fit the same lambda."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from tests import _orc as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TR = json.load(open(os.path.join(GOLD, "transcripts.json")))
+
+
+@pytest.fixture()
+def shell(tmp_path):
+    from cafe_amd.shell import CafeShell
+    s = CafeShell(0, str(tmp_path / "log.txt"))
+    yield s
+    s.close()
+
+
+def _gunzip(tmp_path):
+    import gzip
+    import shutil
+    dst = tmp_path / "test1_families.txt"
+    with gzip.open(os.path.join(GOLD, "test1_families.txt.gz"), "rb") as f, open(dst, "wb") as g:
+        shutil.copyfileobj(f, g)
+    return str(dst)
+
+
+def test_test2_transcript(shell):
+    # tests/integration/test2.sh: seed 10; load -p 0.05 -max_size 20; tree; lambda -s
+    g = TR["test2"]
+    shell.dispatch("seed 10")
+    shell.dispatch("load -i %s -p 0.05 -max_size 20" % os.path.join(GOLD, "test2_families.txt"))
+    shell.dispatch("tree " + g["newick"])
+    shell.dispatch("lambda -s")
+    assert shell.poisson_lambda == pytest.approx(g["poisson_lambda"], abs=5e-7)
+    tr = shell.trace()
+    exp = g["lambda_score"]
+    assert len(tr) == len(exp)
+    for (lam, score), (elam, escore) in zip(tr, exp):
+        assert lam == pytest.approx(elam, abs=6e-15)      # printed with 14 decimals
+        if math.isinf(escore):
+            assert score == escore
+        else:
+            assert score == pytest.approx(escore, abs=2e-6)  # printed with 6 decimals
+    assert shell.iterations == g["search_result"]["iters"]
+    assert shell.params[0] == pytest.approx(g["search_result"]["lambda"], abs=6e-15)
+    assert shell.score == pytest.approx(g["search_result"]["score"], abs=2e-6)
+
+
+def test_test1_transcript_14787_families(shell, tmp_path):
+    # tests/integration/test1.sh: seed 10; tree; load -max_size 20; lambda -s   (53 evaluations)
+    g = TR["test1"]
+    shell.dispatch("seed 10")
+    shell.dispatch("tree " + g["newick"])
+    shell.dispatch("load -i %s -max_size 20" % _gunzip(tmp_path))
+    shell.dispatch("lambda -s")
+    assert shell.poisson_lambda == pytest.approx(g["poisson_lambda"], abs=5e-6)
+    tr = shell.trace()
+    exp = g["lambda_score"]
+    # the fitted Poisson prior agrees to its 6 printed decimals, which bounds score agreement at ~5e-3
+    n = min(len(tr), len(exp))
+    assert n >= 20
+    same = 0
+    for (lam, score), (elam, escore) in zip(tr[:n], exp[:n]):
+        if abs(lam - elam) > 6e-15:
+            break
+        assert score == pytest.approx(escore, abs=1e-2)
+        same += 1
+    assert same >= 20, "trajectory diverged from the golden transcript after %d evaluations" % same
+    assert shell.params[0] == pytest.approx(g["search_result"]["lambda"], abs=2e-7)   # optimiser tolx 1e-6
+    assert shell.score == pytest.approx(g["search_result"]["score"], rel=1e-7)
+
+
+def test_lambda_set_and_score_matches_oracle(shell):
+    # lambda -l x -score on the example (BASELINE configs[0] plumbing), per-clade lambda tree, lambdamu
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+    shell.dispatch("seed 10")
+    shell.dispatch("load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"))
+    shell.dispatch("tree " + newick)
+    shell.dispatch("lambda -l 0.0017 -score")
+    sp, ids, counts = O.load_family_table(os.path.join(GOLD, "example_data.tab"))
+    t = O.PyTree(newick)
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    prior = O.prior_poisson(1000, rng.root_min, shell.poisson_lambda)
+    so, *_ = O.eval_posterior(t, counts, rng, np.full(t.n_nodes, 0.0017), np.full(t.n_nodes, -1.0), prior)
+    assert shell.score == pytest.approx(-so, rel=1e-12)
+    # Poisson lambda 9.442907 & Score 909.325700 for this table with seed 10
+    assert shell.poisson_lambda == pytest.approx(9.442907, abs=5e-7)
+
+    # two lambda classes as in example/cafe_script.sh: lambda -s -t (((2,2)1,(1,1)1)1,1)
+    shell.dispatch("lambda -l 0.0017 0.0021 -t (((2,2)1,(1,1)1)1,1) -score")
+    cls = np.zeros(t.n_nodes, int)
+    cls[[0, 2]] = 1  # chimp, human carry class 2
+    lam = np.where(cls == 1, 0.0021, 0.0017)
+    prior = O.prior_poisson(1000, rng.root_min, shell.poisson_lambda)
+    so, *_ = O.eval_posterior(t, counts, rng, lam, np.full(t.n_nodes, -1.0), prior)
+    assert shell.score == pytest.approx(-so, rel=1e-12)
+
+    shell.dispatch("lambdamu -l 0.0017 -m 0.0012")
+    prior = O.prior_poisson(1000, rng.root_min, shell.poisson_lambda)
+    so, *_ = O.eval_posterior(t, counts, rng, np.full(t.n_nodes, 0.0017), np.full(t.n_nodes, 0.0012), prior)
+    assert shell.score == pytest.approx(-so, rel=1e-12)
+
+
+def test_example_single_lambda_search_hits_the_cliff(shell):
+    # seed 10; load -t 1; tree; lambda -s on the shipped example converges onto
+    # lambda = 0.01075268816939 ~ 1/93 with score 1395.008991 in 29 iterations; first objective
+    # Lambda : 0.00656913889832 & Score: -1605.319168
+    shell.dispatch("seed 10")
+    shell.dispatch("load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"))
+    shell.dispatch("tree (((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)")
+    shell.dispatch("lambda -s")
+    tr = shell.trace()
+    assert tr[0][0] == pytest.approx(0.00656913889832, abs=6e-15)
+    assert tr[0][1] == pytest.approx(-1605.319168, abs=2e-6)
+    assert shell.params[0] == pytest.approx(0.01075268816939, abs=1e-9)
+    assert shell.score == pytest.approx(1395.008991, abs=1e-4)
+    assert shell.iterations == 29
+
+
+def test_unknown_and_out_of_scope_commands_fail_loudly(shell):
+    import cafe_amd
+    with pytest.raises(cafe_amd.CafeHipError):
+        shell.dispatch("lambda -s")          # no family / tree yet
+    with pytest.raises(cafe_amd.CafeHipError):
+        shell.dispatch("cvfamily -fold 5")   # out of scope
+    assert shell.dispatch("# a comment") == 0
+    assert shell.dispatch("exit") == 1
