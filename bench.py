@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--families", type=int, default=None, help="families per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-search", action="store_true", help="skip the lambda-search wall-clock leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for debugging)")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: all ranks share GPU 0 (functional check of the N>1 path on a 1-GPU box)")
@@ -210,6 +211,9 @@ def main():
                             "k3_score": float(km[:, 2].mean())}
         out["engine"] = eng.describe()
 
+    if rank == 0 and world == 1 and not args.no_search:
+        out["lambda_search"] = lambda_search_wallclock(newick, counts, tree, has_mu)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(newick, counts, rng, prior, cfg, eng, tree)
 
@@ -218,6 +222,32 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def lambda_search_wallclock(newick, counts, tree, has_mu):
+    """Second metric of BASELINE.json: wall-clock of the complete `lambda -s` (or `lambdamu -s`) command on
+    the bench table through the host driver -- prior fit + Nelder-Mead, every objective call on the GPU
+    (cafe/lambda.cpp:369-515)."""
+    import tempfile
+    from cafe_amd.shell import CafeShell
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "families.tab")
+        with open(path, "w") as f:
+            f.write("Desc\tFamily ID\t" + "\t".join(tree.leaf_names) + "\n")
+            for i, row in enumerate(counts):
+                f.write("NA\tF%06d\t" % i + "\t".join(str(int(x)) for x in row) + "\n")
+        sh = CafeShell(0, os.path.join(d, "log.txt"))
+        sh.dispatch("seed 10")
+        sh.dispatch("tree " + newick)
+        sh.dispatch("load -i " + path)
+        t0 = time.perf_counter()
+        sh.dispatch("lambdamu -s" if has_mu else "lambda -s")
+        wall = time.perf_counter() - t0
+        res = {"command": "lambdamu -s" if has_mu else "lambda -s", "wall_s": wall,
+               "search_s": sh.search_seconds, "iterations": sh.iterations, "evaluations": sh.evaluations,
+               "fitted": [float(x) for x in sh.params], "score": sh.score, "poisson_lambda": sh.poisson_lambda}
+        sh.close()
+    return res
 
 
 def cpu_baseline(newick, counts, rng, prior, cfg, eng, tree):
@@ -229,7 +259,10 @@ def cpu_baseline(newick, counts, rng, prior, cfg, eng, tree):
     orng = O.make_range(rng.min, rng.max, rng.root_min, rng.root_max)
     lam = np.full(t.n_nodes, cfg["lam"])
     mu = np.full(t.n_nodes, cfg["mu"] if cfg["mu"] >= 0 else -1.0)
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
     probe = counts[:64]
     t0 = time.perf_counter()
     O.eval_posterior(t, probe, orng, lam, mu, prior, nthreads=1)
@@ -239,10 +272,25 @@ def cpu_baseline(newick, counts, rng, prior, cfg, eng, tree):
     t0 = time.perf_counter()
     O.eval_posterior(t, counts[:n_1t], orng, lam, mu, prior, nthreads=1)
     rate_1t = n_1t / (time.perf_counter() - t0)
-    n_mt = int(max(256, min(len(counts), 8.0 * rate_1t * cores * 0.5)))
-    t0 = time.perf_counter()
-    so, fzo, mlo, amo, mpo = O.eval_posterior(t, counts[:n_mt], orng, lam, mu, prior, nthreads=cores)
-    rate_mt = n_mt / (time.perf_counter() - t0)
+    # the box may expose more hardware threads than its CPU quota: pick the team size that is fastest
+    best_threads, best_rate = 1, rate_1t
+    n_try = int(max(256, min(len(counts), 2000)))
+    for nt in sorted({avail, 128, 64, 32, 16, 8}, reverse=True):
+        if nt > avail or nt < 2:
+            continue
+        O.eval_posterior(t, counts[:256], orng, lam, mu, prior, nthreads=nt)  # spin the team up, untimed
+        t0 = time.perf_counter()
+        O.eval_posterior(t, counts[:n_try], orng, lam, mu, prior, nthreads=nt)
+        r = n_try / (time.perf_counter() - t0)
+        if r > best_rate:
+            best_threads, best_rate = nt, r
+    cores = best_threads
+    n_mt = int(max(256, min(len(counts), 6.0 * best_rate)))
+    rate_mt = 0.0
+    for _ in range(2):
+        t0 = time.perf_counter()
+        so, fzo, mlo, amo, mpo = O.eval_posterior(t, counts[:n_mt], orng, lam, mu, prior, nthreads=cores)
+        rate_mt = max(rate_mt, n_mt / (time.perf_counter() - t0))
     # parity of the same sample on the GPU
     eng.set_families(counts[:n_mt], rng)
     sg, fzg, mlg, amg, mpg = eng.get_posterior(lam, mu, prior, per_family=True)
@@ -253,7 +301,8 @@ def cpu_baseline(newick, counts, rng, prior, cfg, eng, tree):
         "cores": cores,
         "kind": "port",
         "sample": "one objective evaluation of the first %d families of the bench table, OpenMP over "
-                  "families on %d threads (includes the matrix build)" % (n_mt, cores),
+                  "families on %d threads (best of team sizes <= %d hardware threads; includes the matrix "
+                  "build)" % (n_mt, cores, avail),
         "single_thread_value": rate_1t,
         "single_thread_sample": "first %d families, 1 thread" % n_1t,
         "gpu_vs_oracle_max_rel_err_log_posterior": rel,
