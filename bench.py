@@ -186,7 +186,9 @@ def main():
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": pmc_traffic_bytes(args.config, F_local),
+            "traffic_unit": "bytes per launch (HBM-side, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
+                            "profiles/r01_pmc_traffic.json)",
             "algorithmic_flops_per_family": f_alg,
             "families_per_launch": F_local,
             "avg_launch_ms": k2_ms,
@@ -222,6 +224,19 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic_bytes(config, families):
+    """HBM-side bytes per K2 launch from the committed rocprofv3 PMC passes (collected in their own runs,
+    as the counters cannot be read from inside bench.py); None when the recorded workload differs."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if rec["workload"] != config or rec["families_per_launch"] != families:
+            return None
+        k = rec["kernels"]["k2_prune_mfma"]
+        return (k["fetch_kib_corrected"] + k["write_kib"]) * 1024.0
+    except Exception:
+        return None
 
 
 def lambda_search_wallclock(newick, counts, tree, has_mu):
