@@ -956,3 +956,132 @@ void orc_conditional_distribution(const orc_tree *t, const orc_range *range,
     free(L);
     free(fs);
 }
+
+/* ======================================================================== */
+/* Viterbi / p-values                                                        */
+/* ======================================================================== */
+
+/* cafe/cafe_family.c:236-255 */
+void orc_family_forced_range(orc_range *r, int n_leaves, const int *row)
+{
+    int max = 0;
+    for (int i = 0; i < n_leaves; i++)
+        if (max < row[i]) max = row[i];
+    r->min = 0;
+    r->root_min = 1;
+    r->root_max = (int)rint(max * 1.25);
+    r->max = max + ORC_MAX(50, max / 5);
+}
+
+static void viterbi_compute(const orc_tree *t, const orc_range *range, const orc_matrices *mats,
+                            const int *familysize, int *vit, double *L, int sof, int node,
+                            double *f0, double *f1)
+{
+    /* __cafe_tree_node_compute_viterbi cafe/viterbi.cpp:208-320, post-order */
+    double *Lv = L + (size_t)node * sof;
+    if (t->left[node] < 0) {
+        memset(Lv, 0, sizeof(double) * sof);
+        if (familysize[node] >= 0 && familysize[node] < sof) Lv[familysize[node]] = 1; /* :262-266 */
+        return;
+    }
+    viterbi_compute(t, range, mats, familysize, vit, L, sof, t->left[node], f0, f1);
+    viterbi_compute(t, range, mats, familysize, vit, L, sof, t->right[node], f0, f1);
+    int row_lo, row_hi;
+    if (node == t->root) {
+        row_lo = range->root_min;
+        row_hi = range->root_max;
+    } else {
+        row_lo = range->min;
+        row_hi = range->max;
+    }
+    int S = orc_matrices_size(mats);
+    int child[2] = {t->left[node], t->right[node]};
+    double *fac[2] = {f0, f1};
+    for (int idx = 0; idx < 2; idx++) {
+        const double *m = orc_matrices_get(mats, child[idx]);
+        const double *Lc = L + (size_t)child[idx] * sof;
+        int *vc = vit + (size_t)child[idx] * sof;
+        memset(fac[idx], 0, sizeof(double) * sof);
+        for (int s = row_lo, i = 0; s <= row_hi; s++, i++) {
+            for (int c = range->min, j = 0; c <= range->max; c++, j++) {
+                double tmp = m[(size_t)s * S + c] * Lc[j];
+                if (tmp > fac[idx][i]) { /* strict: first maximum wins :296-300 */
+                    fac[idx][i] = tmp;
+                    vc[i] = j;
+                }
+            }
+        }
+    }
+    int size = row_hi - row_lo + 1;
+    for (int i = 0; i < size; i++) Lv[i] = f0[i] * f1[i];
+}
+
+static void viterbi_backtrack(const orc_tree *t, const orc_range *range, int *familysize,
+                              const int *vit, const double *L, int sof, int node)
+{
+    /* __cafe_tree_node_backtrack_viterbi cafe/viterbi.cpp:322-351, prefix order */
+    if (!(t->left[node] < 0 && familysize[node] >= 0)) {
+        if (node == t->root) {
+            int rfsize = range->root_max - range->root_min + 1;
+            familysize[node] = range->root_min + (rfsize > 0 ? orc_maxidx(L + (size_t)node * sof, rfsize) : 0);
+        } else {
+            int parent = t->parent[node];
+            int base = (parent == t->root) ? range->root_min : range->min;
+            familysize[node] = vit[(size_t)node * sof + (familysize[parent] - base)] + range->min;
+        }
+    }
+    if (t->left[node] >= 0) {
+        viterbi_backtrack(t, range, familysize, vit, L, sof, t->left[node]);
+        viterbi_backtrack(t, range, familysize, vit, L, sof, t->right[node]);
+    }
+}
+
+void orc_tree_viterbi(const orc_tree *t, const orc_range *range, const orc_matrices *mats,
+                      int *familysize, int *vit, double *L, int sof)
+{
+    double *f0 = (double *)calloc(sof, sizeof(double));
+    double *f1 = (double *)calloc(sof, sizeof(double));
+    /* internal nodes start unknown */
+    for (int i = 0; i < t->n_nodes; i++)
+        if (t->left[i] >= 0) familysize[i] = -1;
+    viterbi_compute(t, range, mats, familysize, vit, L, sof, t->root, f0, f1);
+    viterbi_backtrack(t, range, familysize, vit, L, sof, t->root);
+    free(f0);
+    free(f1);
+}
+
+void orc_tree_p_values(const orc_tree *t, const orc_range *range, const orc_matrices *mats,
+                       const int *familysize, const double *cd, int trials, double *pvalues)
+{
+    int rfsize = range->root_max - range->root_min + 1;
+    int sof = ORC_MAX(orc_matrices_size(mats) + 1, ORC_MAX(rfsize, 1));
+    double *L = (double *)malloc(sizeof(double) * (size_t)t->n_nodes * sof);
+    orc_compute_tree_likelihoods(t, range, mats, familysize, NULL, 0, NULL, L, sof);
+    const double *obs = L + (size_t)t->root * sof;
+    for (int s = 0; s < rfsize; s++) pvalues[s] = orc_pvalue(obs[s], cd + (size_t)s * trials, trials);
+    free(L);
+}
+
+void orc_viterbi_sum_probabilities(const orc_tree *t, const orc_range *range, const orc_matrices *mats,
+                                   const int *familysize, double *out)
+{
+    int S = orc_matrices_size(mats);
+    int nnodes = (t->n_nodes - 1) / 2;
+    for (int j = 0; j < nnodes; j++) {
+        int node = 2 * j + 1;
+        int child[2] = {t->left[node], t->right[node]};
+        for (int k = 0; k < 2; k++) {
+            const double *m = orc_matrices_get(mats, child[k]);
+            double p = m[(size_t)familysize[node] * S + familysize[child[k]]];
+            double acc = 0;
+            for (int mm = 0; mm <= range->max; mm++) {
+                double v = m[(size_t)familysize[node] * S + mm];
+                if (v == p)
+                    acc += v / 2.0;
+                else if (v < p)
+                    acc += v;
+            }
+            out[2 * j + k] = acc;
+        }
+    }
+}

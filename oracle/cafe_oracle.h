@@ -175,6 +175,22 @@ void orc_conditional_distribution(const orc_tree *t, const orc_range *range,
 int orc_tree_random_familysize(const orc_tree *t, const orc_matrices *mats, int root_size,
                                int max_family_size, int *familysize);
 
+/* ---- Viterbi / p-values (cafe/viterbi.cpp, cafe/pvalue.cpp) ------------------------ */
+/* cafe_tree_viterbi (cafe/viterbi.cpp:494-516): max-product pass (:208-320) + backtrack (:322-351)
+ * for ONE family under `range`.  familysize[n_nodes]: leaf counts in, all node sizes out.
+ * vit: n_nodes * sof ints of persistent state (the reference never clears node->viterbi, so rows
+ * whose products are all zero keep whatever an earlier family left there); L: n_nodes*sof scratch. */
+void orc_tree_viterbi(const orc_tree *t, const orc_range *range, const orc_matrices *mats,
+                      int *familysize, int *vit, double *L, int sof);
+/* cafe_tree_p_values (cafe/pvalue.cpp:143-154): pvalues[s] for s < rfsize against cd (R x trials). */
+void orc_tree_p_values(const orc_tree *t, const orc_range *range, const orc_matrices *mats,
+                       const int *familysize, const double *cd, int trials, double *pvalues);
+/* viterbi_sum_probabilities (cafe/viterbi.cpp:44-71): out[2*j+k] for internal node 2j+1, child k. */
+void orc_viterbi_sum_probabilities(const orc_tree *t, const orc_range *range, const orc_matrices *mats,
+                                   const int *familysize, double *out);
+/* cafe_family_set_size_with_family_forced ranges (cafe/cafe_family.c:236-255) */
+void orc_family_forced_range(orc_range *r, int n_leaves, const int *row);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,14 @@ def lib():
     L.orc_conditional_distribution.argtypes = [C.POINTER(Tree), C.POINTER(Range), C.c_void_p, C.c_int, _dp]
     L.orc_tree_random_familysize.restype = C.c_int
     L.orc_tree_random_familysize.argtypes = [C.POINTER(Tree), C.c_void_p, C.c_int, C.c_int, _ip]
+    L.orc_tree_viterbi.restype = None
+    L.orc_tree_viterbi.argtypes = [C.POINTER(Tree), C.POINTER(Range), C.c_void_p, _ip, _ip, _dp, C.c_int]
+    L.orc_tree_p_values.restype = None
+    L.orc_tree_p_values.argtypes = [C.POINTER(Tree), C.POINTER(Range), C.c_void_p, _ip, _dp, C.c_int, _dp]
+    L.orc_viterbi_sum_probabilities.restype = None
+    L.orc_viterbi_sum_probabilities.argtypes = [C.POINTER(Tree), C.POINTER(Range), C.c_void_p, _ip, _dp]
+    L.orc_family_forced_range.restype = None
+    L.orc_family_forced_range.argtypes = [C.POINTER(Range), C.c_int, _ip]
     _lib = L
     return L
 
@@ -273,3 +281,60 @@ def reorder_to_tree(species, counts, tree):
     low = [s.lower() for s in species]
     cols = [low.index(nm.lower()) for nm in tree.leaf_names]
     return np.ascontiguousarray(counts[:, cols])
+
+
+def parse_cafe_report(path):
+    """Family rows of a `.cafe` text report (cafe/reports.cpp:357-388): id -> (sizes by node in
+    Newick order, family-wide p, [(p1, p2) or None per internal node])."""
+    import re
+    out = {}
+    for line in open(path):
+        parts = line.rstrip("\n").split("\t")
+        if len(parts) < 4 or not parts[1].startswith("(") or "_" not in parts[1]:
+            continue
+        sizes = [int(x) for x in re.findall(r"_(\d+)", parts[1])]
+        pairs = []
+        for a, b in re.findall(r"\(([^(),]+),([^(),]+)\)", parts[3]):
+            pairs.append(None if a == "-" else (float(a), float(b)))
+        out[parts[0]] = (sizes, float(parts[2]), pairs)
+    return out
+
+
+def report_with_oracle(tree, counts, rng, lam_value, trials=1000, pvalue_cut=0.05, rng_skip=2, seed=10):
+    """The report pipeline on the CPU oracle: MC null with libc rand() (seed, then `rng_skip` draws as the
+    Poisson-fit start and the Nelder-Mead start consume them), per-family p-values, Viterbi sizes and
+    branch p-values.  Returns per family (max_p, node sizes[n_nodes], branch p[n_nodes-1] or None)."""
+    L = lib()
+    libc = C.CDLL(None)
+    lam = np.full(tree.n_nodes, lam_value)
+    mu = np.full(tree.n_nodes, -1.0)
+    ct = tree.ctree()
+    M = max(rng.max, rng.root_max)
+    h = L.orc_matrices_build(C.byref(ct), dptr(lam), dptr(mu), M, 1)
+    libc.srand(seed)
+    for _ in range(rng_skip):
+        libc.rand()
+    R = rng.root_max - rng.root_min + 1
+    cd = np.zeros((R, trials))
+    L.orc_conditional_distribution(C.byref(ct), C.byref(rng), h, trials, dptr(cd))
+    sof = M + 2
+    vit = np.zeros(tree.n_nodes * sof, np.int32)
+    Lb = np.zeros(tree.n_nodes * sof)
+    out = []
+    for i in range(counts.shape[0]):
+        r = Range()
+        row = np.ascontiguousarray(counts[i], np.int32)
+        L.orc_family_forced_range(C.byref(r), counts.shape[1], iptr(row))
+        fs = np.full(tree.n_nodes, -1, np.int32)
+        fs[0::2] = row
+        pv = np.zeros(max(r.root_max, 1))
+        L.orc_tree_p_values(C.byref(ct), C.byref(r), h, iptr(fs), dptr(cd), trials, dptr(pv))
+        maxp = float(pv[:max(r.root_max, 0)].max()) if r.root_max >= 1 else 0.0
+        L.orc_tree_viterbi(C.byref(ct), C.byref(r), h, iptr(fs), iptr(vit), dptr(Lb), sof)
+        bp = None
+        if not (maxp > pvalue_cut):
+            bp = np.zeros(tree.n_nodes - 1)
+            L.orc_viterbi_sum_probabilities(C.byref(ct), C.byref(r), h, iptr(fs), dptr(bp))
+        out.append((maxp, fs.copy(), bp))
+    L.orc_matrices_free(h)
+    return out, cd

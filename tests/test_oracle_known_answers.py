@@ -257,3 +257,28 @@ def test_ref_duplicates_and_zero_family():
     lam_big = np.full(t.n_nodes, 0.2)
     s3, fz3, ml3, *_ = O.eval_posterior(t, counts, rng, lam_big, mu, prior)
     assert s3 == -math.inf and fz3 == 0 and ml3[0] == 0.0
+
+
+def test_report_golden_test2_cafe():
+    # tests/integration/test2.cafe (golden report of test2.sh, seed 10, -p 0.05): family-wide p-values,
+    # Viterbi ancestral sizes and branch p-values -- pins the MC null (libc rand() stream), pvalue(),
+    # the max-product pass and viterbi_sum_probabilities.
+    g = TR["test2"]
+    t = O.PyTree(g["newick"])
+    sp, ids, counts = O.load_family_table(os.path.join(GOLD, "test2_families.txt"), max_size=g["max_size"])
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    rep, cd = O.report_with_oracle(t, counts, rng, g["search_result"]["lambda"], pvalue_cut=0.05)
+    gold = O.parse_cafe_report(os.path.join(GOLD, "test2.cafe"))
+    assert len(gold) == 4
+    # Newick print order of (((Chimp,Human),(Mouse,Rat)),Dog): ids 0,2,1,4,6,5,3,8,7
+    order = [0, 2, 1, 4, 6, 5, 3, 8, 7]
+    for fid, (maxp, sizes, bp) in zip(ids, rep):
+        gs, gp, gpairs = gold[fid]
+        assert [int(sizes[i]) for i in order] == gs
+        assert float("%g" % maxp) == gp
+        for j, pair in enumerate(gpairs):
+            if pair is None:
+                assert bp is None
+            else:
+                assert float("%g" % bp[2 * j]) == pair[0] and float("%g" % bp[2 * j + 1]) == pair[1]
