@@ -382,6 +382,158 @@ __global__ void k_fill_i32(int32_t* p, int32_t v) { *p = v; }
 
 #include "k2_mfma.hpp"
 
+// ------------------------------------------------------------------------------------
+// K4: Viterbi (cafe/viterbi.cpp:208-351).  Same walk as K2 with (max, argmax) in place of the
+// sum: thread r owns row r, factor[r] = max_k PT[k][row] * L_child[k] with strict '>' over
+// ascending k (first maximum wins), node vector = product of the two factors; the argmax
+// tables of the internal children stay in LDS (16-bit) and one thread per family backtracks
+// root -> leaves in prefix order.  No sums: every value is a chain of single multiplications,
+// so given the same matrices the sizes equal a host evaluation bit for bit.
+// ------------------------------------------------------------------------------------
+struct K4Args {
+    const double* PT;
+    const EvalParams* ep;
+    const cafehip::PruneOp* ops;
+    int n_ops;
+    const int32_t* counts;
+    int B, n_leaves, n_nodes;
+    int C, R, root_min;
+    int LD, KP, LDv;
+    int n_slots;
+    int root;
+    const int32_t* parent;     // [n_nodes]
+    const int32_t* prefix;     // [n_nodes] prefix order
+    const int32_t* vit_slot;   // [n_nodes] table index of internal non-root nodes, -1 otherwise
+    int n_tables;
+    const int32_t* root_lo;
+    const int32_t* root_hi;
+    const int32_t* col_max;
+    int32_t* node_sizes;       // [B][n_nodes]
+};
+
+template <int NF>
+__global__ __launch_bounds__(1024) void k4_viterbi(K4Args a)
+{
+    extern __shared__ double smem4[];
+    double* slots = smem4;                                                  // [n_slots][NF][LDv]
+    unsigned short* vit = reinterpret_cast<unsigned short*>(slots + (size_t)a.n_slots * NF * a.LDv);  // [n_tables][NF][LDv]
+    __shared__ int s_cnt[NF][kMaxLeaves];
+    __shared__ int s_colmax[NF];
+
+    const int tid = threadIdx.x;
+    const int r = tid;
+    const int fam0 = blockIdx.x * NF;
+    const size_t slot_stride = (size_t)NF * a.LDv;
+
+    for (int i = tid; i < NF * a.n_leaves; i += blockDim.x) {
+        const int f = i / a.n_leaves, j = i - f * a.n_leaves;
+        const int u = fam0 + f;
+        s_cnt[f][j] = (u < a.B) ? a.counts[(size_t)u * a.n_leaves + j] : 0;
+    }
+    if (tid < NF) s_colmax[tid] = (fam0 + tid < a.B) ? a.col_max[fam0 + tid] : (a.C - 1);
+    for (int i = tid; i < a.n_tables * NF * a.LDv; i += blockDim.x) vit[i] = 0;
+    __syncthreads();
+
+    int root_slot = 0;
+    for (int oi = 0; oi < a.n_ops; ++oi) {
+        const cafehip::PruneOp op = a.ops[oi];
+        const int rows = op.is_root ? a.R : a.C;
+        const int row_lo = op.is_root ? a.root_min : 0;
+        double y[2][NF];
+        int arg[2][NF];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const double* PTc = a.PT + (size_t)a.ep->node_key[op.child[ch]] * a.KP * a.LD + row_lo + r;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                y[ch][f] = 0.0;
+                arg[ch][f] = 0;
+            }
+            if (op.kind[ch] == 0) {
+                // one-hot leaf: the only non-zero product is at k = count
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const int cnt = s_cnt[f][op.src[ch]];
+                    if (r < rows && cnt <= s_colmax[f]) y[ch][f] = PTc[(size_t)cnt * a.LD];
+                }
+            } else if (r < rows) {
+                const double* src = slots + (size_t)op.src[ch] * slot_stride;
+                for (int k = 0; k < a.C; ++k) {
+                    const double pv = PTc[(size_t)k * a.LD];
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        const double tmp = pv * src[f * a.LDv + k];
+                        if (tmp > y[ch][f]) {   // cafe/viterbi.cpp:296-300
+                            y[ch][f] = tmp;
+                            arg[ch][f] = k;
+                        }
+                    }
+                }
+            }
+            if (op.kind[ch] == 1 && r < rows) {
+                const int tb = a.vit_slot[op.child[ch]];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) vit[((size_t)tb * NF + f) * a.LDv + r] = (unsigned short)arg[ch][f];
+            }
+        }
+        __syncthreads();
+        double* dst = slots + (size_t)op.dst * slot_stride;
+        for (int rr = tid; rr < a.LDv; rr += blockDim.x) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                double v = 0.0;
+                if (rr == r && r < rows) {
+                    v = y[0][f] * y[1][f];
+                    if (!op.is_root && r > s_colmax[f]) v = 0.0;
+                }
+                dst[f * a.LDv + rr] = v;
+            }
+        }
+        __syncthreads();
+        root_slot = op.dst;
+    }
+
+    // backtrack (cafe/viterbi.cpp:322-351): one thread per family, prefix order
+    if (tid < NF && fam0 + tid < a.B) {
+        const int f = tid;
+        const int u = fam0 + f;
+        int32_t* out = a.node_sizes + (size_t)u * a.n_nodes;
+        const double* L = slots + (size_t)root_slot * slot_stride + f * a.LDv;
+        const int lo = a.root_lo[u], hi = a.root_hi[u];
+        for (int j = 0; j < a.n_leaves; ++j) out[2 * j] = s_cnt[f][j];
+        int best = 0;
+        if (hi >= lo) {
+            double bv = L[lo - a.root_min];
+            for (int s = lo + 1; s <= hi; ++s) {
+                const double v = L[s - a.root_min];
+                if (bv < v) {   // __maxidx: first maximum
+                    bv = v;
+                    best = s - lo;
+                }
+            }
+        }
+        out[a.root] = lo + best;
+        for (int pi = 0; pi < a.n_nodes; ++pi) {
+            const int node = a.prefix[pi];
+            if (node == a.root || (node & 1) == 0) continue;   // leaves keep their counts
+            const int par = a.parent[node];
+            const int ps = out[par];
+            int idx = ps;                      // base = range.min = 0
+            int size;
+            if (par == a.root) {
+                // rows of a root child are indexed by root size; an empty root range computes none of
+                // them in the reference (stale zeros)
+                idx = ps - a.root_min;
+                size = (hi >= lo && idx >= 0 && idx < a.R) ? vit[((size_t)a.vit_slot[node] * NF + f) * a.LDv + idx] : 0;
+            } else {
+                size = (idx >= 0 && idx < a.C) ? vit[((size_t)a.vit_slot[node] * NF + f) * a.LDv + idx] : 0;
+            }
+            out[node] = size;
+        }
+    }
+}
+
+
 }  // namespace
 
 // ====================================================================================
@@ -404,6 +556,8 @@ struct cafehip_ctx {
     cafehip::MfmaOp* d_mops = nullptr;
     double* d_park = nullptr;
     size_t park_cap = 0;
+    int32_t *d_parent = nullptr, *d_prefix = nullptr, *d_vit_slot = nullptr;
+    int n_vit_tables = 0;
     int k2_cfg[4] = {0, 0, 0, 0};  // NFT_W, NRT_W, Wf, Wr of the last MFMA launch
     bool k2_used_mfma = false;
 
@@ -836,6 +990,22 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
 
 }  // namespace
 
+template <int NF>
+static int launch_k4_nf(cafehip_ctx* c, const K4Args& a, int block, size_t lds)
+{
+    static size_t attr_bytes = 0;
+    if (lds > 48 * 1024 && lds > attr_bytes) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_viterbi<NF>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    const int grid = (a.B + NF - 1) / NF;
+    hipLaunchKernelGGL(k4_viterbi<NF>, dim3(grid), dim3(block), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+
 // ====================================================================================
 // C ABI
 // ====================================================================================
@@ -893,6 +1063,9 @@ void cafehip_destroy(cafehip_ctx* c)
     hipFree(c->d_ops);
     hipFree(c->d_mops);
     hipFree(c->d_park);
+    hipFree(c->d_parent);
+    hipFree(c->d_prefix);
+    hipFree(c->d_vit_slot);
     hipFree(c->d_lncA);
     hipFree(c->d_lncB);
     hipFree(c->d_PT);
@@ -962,6 +1135,35 @@ int cafehip_set_tree(cafehip_ctx* c, int n_nodes, const int32_t* parent, const i
     HIP_TRY(hipMalloc(&c->d_mops, c->msched.ops.size() * sizeof(cafehip::MfmaOp)));
     HIP_TRY(hipMemcpy(c->d_mops, c->msched.ops.data(), c->msched.ops.size() * sizeof(cafehip::MfmaOp),
                       hipMemcpyHostToDevice));
+    {
+        // prefix order (tree_traveral_prefix, libtree/tree.c:101-124) and argmax-table slots for K4
+        std::vector<int32_t> prefix, vslot(n_nodes, -1);
+        std::vector<int> st;
+        st.push_back(root);
+        while (!st.empty()) {
+            const int v = st.back();
+            st.pop_back();
+            prefix.push_back(v);
+            if (c->left[v] >= 0) {
+                st.push_back(c->right[v]);
+                st.push_back(c->left[v]);
+            }
+        }
+        int nt = 0;
+        for (int i = 0; i < n_nodes; ++i)
+            if (c->left[i] >= 0 && i != root) vslot[i] = nt++;
+        c->n_vit_tables = nt;
+        hipFree(c->d_parent);
+        hipFree(c->d_prefix);
+        hipFree(c->d_vit_slot);
+        c->d_parent = c->d_prefix = c->d_vit_slot = nullptr;
+        HIP_TRY(hipMalloc(&c->d_parent, n_nodes * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&c->d_prefix, n_nodes * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&c->d_vit_slot, n_nodes * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(c->d_parent, c->parent.data(), n_nodes * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_prefix, prefix.data(), n_nodes * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_vit_slot, vslot.data(), n_nodes * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     c->have_matrices = false;
     if (c->M >= 0 && ensure_matrix_storage(c)) return -1;
     return 0;
@@ -1242,6 +1444,86 @@ int cafehip_eval_root_likelihoods(cafehip_ctx* c, int B, const int32_t* counts, 
     TRY2(hipMemcpyAsync(out, d_out, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TRY2(hipStreamSynchronize(c->stream));
 #undef TRY2
+    cleanup();
+    return 0;
+}
+
+int cafehip_viterbi(cafehip_ctx* c, int B, const int32_t* counts, const int32_t* root_lo,
+                    const int32_t* root_hi, const int32_t* col_max, int32_t* node_sizes)
+{
+    if (check_ready(c)) return -1;
+    if (!c->have_matrices) return fail("no matrices built yet (call cafehip_eval_posterior or cafehip_reset_birthdeath_cache)");
+    if (B <= 0) return 0;
+    if (!counts || !root_lo || !root_hi || !col_max || !node_sizes) return fail("null argument");
+    if (c->C > 65535) return fail("matrix side too large for 16-bit argmax tables");
+    HIP_TRY(hipSetDevice(c->device));
+    for (int b = 0; b < B; ++b) {
+        if (root_lo[b] < c->root_min || root_hi[b] > c->root_max)
+            return fail("row %d: root range [%d,%d] outside [%d,%d]", b, root_lo[b], root_hi[b], c->root_min, c->root_max);
+        if (col_max[b] < 0 || col_max[b] > c->range_max) return fail("row %d: col_max %d outside [0,%d]", b, col_max[b], c->range_max);
+        for (int j = 0; j < c->n_leaves; ++j)
+            if (counts[(size_t)b * c->n_leaves + j] < 0) return fail("row %d: negative count", b);
+    }
+    const int rows_max = std::max(c->C, c->R);
+    const int block = ((rows_max + 63) / 64) * 64;
+    if (block > 1024) return fail("matrix side %d exceeds the 1024 rows this kernel handles", rows_max);
+    int nf = 8;
+    size_t lds = 0;
+    const size_t stat = 8 * kMaxLeaves * 4 + 64;
+    for (; nf >= 1; nf >>= 1) {
+        lds = (size_t)c->sched.n_slots * nf * c->LDv * sizeof(double) + (size_t)c->n_vit_tables * nf * c->LDv * sizeof(unsigned short) + 16;
+        if (lds + stat <= (size_t)c->lds_limit) break;
+    }
+    if (nf < 1) return fail("Viterbi tables of this tree do not fit LDS");
+    int32_t *d_cnt = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_cm = nullptr, *d_out = nullptr;
+    auto cleanup = [&]() { hipFree(d_cnt); hipFree(d_lo); hipFree(d_hi); hipFree(d_cm); hipFree(d_out); };
+#define TRY3(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail("%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    TRY3(hipMalloc(&d_cnt, (size_t)B * c->n_leaves * sizeof(int32_t)));
+    TRY3(hipMalloc(&d_lo, B * sizeof(int32_t)));
+    TRY3(hipMalloc(&d_hi, B * sizeof(int32_t)));
+    TRY3(hipMalloc(&d_cm, B * sizeof(int32_t)));
+    TRY3(hipMalloc(&d_out, (size_t)B * c->n_nodes * sizeof(int32_t)));
+    TRY3(hipMemcpyAsync(d_cnt, counts, (size_t)B * c->n_leaves * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    TRY3(hipMemcpyAsync(d_lo, root_lo, B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    TRY3(hipMemcpyAsync(d_hi, root_hi, B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    TRY3(hipMemcpyAsync(d_cm, col_max, B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    K4Args a;
+    memset(&a, 0, sizeof a);
+    a.PT = c->d_PT;
+    a.ep = c->d_params;
+    a.ops = c->d_ops;
+    a.n_ops = (int)c->sched.ops.size();
+    a.counts = d_cnt;
+    a.B = B;
+    a.n_leaves = c->n_leaves;
+    a.n_nodes = c->n_nodes;
+    a.C = c->C;
+    a.R = c->R;
+    a.root_min = c->root_min;
+    a.LD = c->LD;
+    a.KP = c->KP;
+    a.LDv = c->LDv;
+    a.n_slots = c->sched.n_slots;
+    a.root = c->root;
+    a.parent = c->d_parent;
+    a.prefix = c->d_prefix;
+    a.vit_slot = c->d_vit_slot;
+    a.n_tables = c->n_vit_tables;
+    a.root_lo = d_lo;
+    a.root_hi = d_hi;
+    a.col_max = d_cm;
+    a.node_sizes = d_out;
+    int rc;
+    switch (nf) {
+        case 8: rc = launch_k4_nf<8>(c, a, block, lds); break;
+        case 4: rc = launch_k4_nf<4>(c, a, block, lds); break;
+        case 2: rc = launch_k4_nf<2>(c, a, block, lds); break;
+        default: rc = launch_k4_nf<1>(c, a, block, lds); break;
+    }
+    if (rc) { cleanup(); return -1; }
+    TRY3(hipMemcpyAsync(node_sizes, d_out, (size_t)B * c->n_nodes * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TRY3(hipStreamSynchronize(c->stream));
+#undef TRY3
     cleanup();
     return 0;
 }

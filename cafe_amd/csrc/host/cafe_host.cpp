@@ -395,6 +395,38 @@ std::string join_double(const double* v, int n)
     return out;
 }
 
+// pvalue(), libcommon/mathfunc.c:663-689: rank of v in the ascending null sample, ties split in half
+double pvalue_rank(double v, const double* conddist, int size)
+{
+    int from = 0;
+    int to = size - 1;
+    int mi;
+    while (from < to) {
+        mi = from + (to - from) / 2;
+        if (conddist[mi] > v) {
+            to = mi - 1;
+        } else if (conddist[mi] < v) {
+            from = mi + 1;
+        } else {
+            for (from = mi - 1; from >= 0 && conddist[from] == v; from--) {
+            }
+            for (to = mi + 1; to < size && conddist[to] == v; to++) {
+            }
+            from++, to--;
+            break;
+        }
+    }
+    if (from > to) to = from;
+    return (double)(from + (conddist[from] <= v ? 1 : 0) + (to - from) / 2.0) / (double)size;
+}
+
+std::string fmt_g(double v)
+{  // default ostream << double (6 significant digits)
+    char buf[64];
+    snprintf(buf, sizeof buf, "%g", v);
+    return buf;
+}
+
 struct Argument {
     std::string opt;
     std::vector<std::string> argv;
@@ -456,6 +488,28 @@ struct cafehost_session {
     int search_iters = 0, n_evals = 0;
     double search_seconds = 0;
     std::vector<double> trace;
+    std::vector<std::vector<double>> cond_dist;  // ConditionalDistribution::matrix, cafe/pvalue.cpp:13
+    // last report (exposed for tests)
+    std::vector<double> rep_max_p;
+    std::vector<int32_t> rep_sizes;      // F x n_nodes
+    std::vector<double> rep_branch_p;    // F x (n_nodes-1), -1 = not computed
+
+    // phylogeny_string (libtree/phylogeny.c:490-540): names + ":%g" branch lengths; `label` adds a suffix
+    std::string tree_string(const std::function<std::string(int)>& label, bool with_bl) const
+    {
+        std::function<std::string(int)> rec = [&](int v) -> std::string {
+            std::string out;
+            if (tree.left[v] >= 0) out = "(" + rec(tree.left[v]) + "," + rec(tree.right[v]) + ")";
+            out += label(v);
+            if (with_bl && tree.bl[v] >= 0) {
+                char buf[64];
+                snprintf(buf, sizeof buf, ":%g", tree.bl[v]);
+                out += buf;
+            }
+            return out;
+        };
+        return rec(tree.root);
+    }
 
     void log(const char* fmt, ...)
     {  // cafe_log, cafe/cafe_main.c:26-44
@@ -718,6 +772,7 @@ struct cafehost_session {
         if (file.empty()) throw std::runtime_error("Usage(load): load <family file>");
         fam.load(file, max_size);
         have_family = true;
+        cond_dist.clear();
         range = init_family_size(fam.max_size);  // set_range_from_family
         sync_species_index();
         device_families_current = false;
@@ -865,6 +920,212 @@ struct cafehost_session {
         return 0;
     }
 
+
+    // ---- Monte-Carlo null: cafe_conditional_distribution, cafe/conditional_distribution.cpp:10-120 ----
+    // Reference order for `-t 1`: root sizes ascending, trials sequential, one unifrnd() per non-root
+    // node in prefix order (cafe/cafe_tree.c:533-569); samples are drawn on the host from the device-built
+    // matrices, the likelihood of every simulated family is ONE batched GPU call.
+    void compute_conditional_distribution(const std::vector<std::vector<double>>& mats, int S)
+    {
+        const int R = range.root_max - range.root_min + 1;
+        const int nl = tree.n_leaves();
+        const int trials = num_random_samples;
+        std::vector<int> prefix;
+        {
+            std::vector<int> st{tree.root};
+            while (!st.empty()) {
+                const int v = st.back();
+                st.pop_back();
+                prefix.push_back(v);
+                if (tree.left[v] >= 0) {
+                    st.push_back(tree.right[v]);
+                    st.push_back(tree.left[v]);
+                }
+            }
+        }
+        std::vector<int32_t> counts((size_t)R * trials * nl), lo((size_t)R * trials), hi((size_t)R * trials), cm((size_t)R * trials);
+        std::vector<int> fs(tree.n);
+        size_t row = 0;
+        for (int s = range.root_min; s <= range.root_max; ++s) {
+            const int maxFamilySize = std::max(s, range.max);  // get_random_probabilities :20
+            int rmax = range.max;
+            for (int t = 0; t < trials; ++t, ++row) {
+                int mx = 0;
+                fs[tree.root] = s;
+                for (int v : prefix) {
+                    if (v == tree.root) continue;
+                    const double rnd = unifrnd();
+                    double cumul = 0;
+                    const double* m = mats[v].data();
+                    const int ps = fs[tree.parent[v]];
+                    int c = 0;
+                    for (; c < maxFamilySize - 1; ++c) {
+                        cumul += m[(size_t)ps * S + c];
+                        if (cumul >= rnd) break;
+                    }
+                    fs[v] = c;
+                    if (mx < c) mx = c;
+                }
+                rmax = std::min(mx + std::max(50, mx / 5), rmax);  // :29, running MIN over the trials of this root size
+                for (int j = 0; j < nl; ++j) counts[row * nl + j] = fs[2 * j];
+                lo[row] = hi[row] = s;
+                cm[row] = rmax;
+            }
+        }
+        std::vector<double> probs((size_t)R * trials);
+        hip_check(cafehip_eval_root_likelihoods(ctx, R * trials, counts.data(), lo.data(), hi.data(), cm.data(), probs.data()));
+        cond_dist.assign(R, std::vector<double>(trials));
+        for (int i = 0; i < R; ++i) {
+            std::copy(probs.begin() + (size_t)i * trials, probs.begin() + (size_t)(i + 1) * trials, cond_dist[i].begin());
+            std::sort(cond_dist[i].begin(), cond_dist[i].end());  // :41
+        }
+    }
+
+    int cmd_report(const std::vector<std::string>& tokens)
+    {  // cafe_cmd_report / cafe_do_report, cafe/cafe_commands.cpp:1010-1018, cafe/reports.cpp:650-708 (text format)
+        prereqs(true, true);
+        if ((int)params.size() != num_params || num_params == 0)
+            throw std::runtime_error("ERROR: Lambda values were not set. Please set lambda values with the 'lambda' or 'lambdamu' command.\n");
+        if (tokens.size() < 2) throw std::runtime_error("Usage(report): report <name>");
+        for (size_t i = 2; i < tokens.size(); ++i)
+            throw std::runtime_error("report " + tokens[i] + " is outside this build's scope (text report only)");
+        const std::string name = tokens[1];
+        upload();
+        // matrices for the fitted parameters, resident on the device + host copies for sampling and
+        // for the exact ==/< comparisons of viterbi_sum_probabilities
+        std::vector<double> nl_, nm_;
+        node_rates(params.data(), nl_, nm_);
+        hip_check(cafehip_reset_birthdeath_cache(ctx, nl_.data(), nm_.data()));
+        const int S = cafehip_matrix_size(ctx);
+        std::vector<std::vector<double>> mats(tree.n);
+        for (int v = 0; v < tree.n; ++v) {
+            if (v == tree.root) continue;
+            mats[v].resize((size_t)S * S);
+            int s_out = 0;
+            hip_check(cafehip_get_matrix(ctx, v, mats[v].data(), &s_out));
+        }
+        if (cond_dist.empty()) compute_conditional_distribution(mats, S);
+
+        log("Running Viterbi algorithm....\n");
+        const int F = fam.F(), nl = tree.n_leaves(), ns = (int)fam.species.size(), n = tree.n;
+        // per-family ranges: cafe_family_set_size_with_family_forced, cafe/cafe_family.c:236-255
+        std::vector<int32_t> counts((size_t)std::max(F, 1) * nl, 0), lo(F), hi(F), cm(F);
+        std::vector<int64_t> off(F + 1, 0);
+        for (int i = 0; i < F; ++i) {
+            int mx = 0;
+            for (int s = 0; s < ns; ++s) {
+                if (species_index[s] < 0) continue;
+                const int c = fam.counts[(size_t)i * ns + s];
+                counts[(size_t)i * nl + species_index[s] / 2] = c;
+                mx = std::max(mx, c);
+            }
+            lo[i] = 1;
+            hi[i] = (int)std::rint(mx * 1.25);
+            cm[i] = mx + std::max(50, mx / 5);
+            off[i + 1] = off[i] + std::max(hi[i] - lo[i] + 1, 0);
+        }
+        // the device call wants non-empty root ranges: families with rfsize == 0 are scored on [1,1] and ignored
+        std::vector<int32_t> hi_call(hi);
+        std::vector<int64_t> off_call(F + 1, 0);
+        for (int i = 0; i < F; ++i) {
+            if (hi_call[i] < lo[i]) hi_call[i] = lo[i];
+            off_call[i + 1] = off_call[i] + (hi_call[i] - lo[i] + 1);
+        }
+        std::vector<double> like((size_t)std::max<int64_t>(off_call[F], 1));
+        if (F) hip_check(cafehip_eval_root_likelihoods(ctx, F, counts.data(), lo.data(), hi_call.data(), cm.data(), like.data()));
+        rep_sizes.assign((size_t)F * n, 0);
+        if (F) hip_check(cafehip_viterbi(ctx, F, counts.data(), lo.data(), hi.data(), cm.data(), rep_sizes.data()));
+
+        rep_max_p.assign(F, 0.0);
+        rep_branch_p.assign((size_t)F * (n - 1), -1.0);
+        const int npairs = n - 1;
+        std::vector<double> avg_exp(npairs, 0.0);
+        std::vector<int> n_expand(npairs, 0), n_remain(npairs, 0), n_decrease(npairs, 0);
+        for (int i = 0; i < F; ++i) {
+            // cafe_tree_p_values (cafe/pvalue.cpp:143-154) + viterbi_set_max_pvalue (cafe/viterbi.cpp:32-39)
+            const int rf = hi[i] - lo[i] + 1;
+            double maxp = 0;
+            for (int s = 0; s < rf; ++s) {
+                const double pv = pvalue_rank(like[off_call[i] + s], cond_dist[s].data(), num_random_samples);
+                if (s == 0 || pv > maxp) maxp = pv;
+            }
+            rep_max_p[i] = maxp;
+            const int32_t* fs = &rep_sizes[(size_t)i * n];
+            // compute_size_deltas, cafe/viterbi.cpp:570-595
+            for (int j = 0; j < (n - 1) / 2; ++j) {
+                const int node = 2 * j + 1;
+                const int child[2] = {tree.left[node], tree.right[node]};
+                for (int k = 0; k < 2; ++k) {
+                    const int m = 2 * j + k;
+                    if (fs[child[k]] > fs[node]) n_expand[m]++;
+                    else if (fs[child[k]] == fs[node]) n_remain[m]++;
+                    else n_decrease[m]++;
+                    avg_exp[m] += fs[child[k]] - fs[node];
+                }
+            }
+            if (maxp > pvalue) continue;  // cafe/viterbi.cpp:105-114: branch p-values stay -1
+            // viterbi_sum_probabilities, cafe/viterbi.cpp:44-71
+            for (int j = 0; j < (n - 1) / 2; ++j) {
+                const int node = 2 * j + 1;
+                const int child[2] = {tree.left[node], tree.right[node]};
+                for (int k = 0; k < 2; ++k) {
+                    const double* m = mats[child[k]].data() + (size_t)fs[node] * S;
+                    const double p = m[fs[child[k]]];
+                    double acc = 0;
+                    for (int mm = 0; mm <= cm[i]; ++mm) {
+                        if (m[mm] == p) acc += m[mm] / 2.0;
+                        else if (m[mm] < p) acc += m[mm];
+                    }
+                    rep_branch_p[(size_t)i * (n - 1) + 2 * j + k] = acc;
+                }
+            }
+        }
+        for (double& v : avg_exp) v /= std::max(F, 1);
+
+        // ---- text report: operator<<(ostream&, const Report&), cafe/reports.cpp:453-501 ----
+        const std::string filename = name + ".cafe";
+        FILE* fp = fopen(filename.c_str(), "w");
+        if (!fp) throw std::runtime_error("ERROR(report) : Cannot open " + name + " in write mode.\n");
+        fprintf(fp, "Tree:%s\n", tree_string([&](int v) { return tree.name[v]; }, true).c_str());
+        fprintf(fp, "Lambda:");
+        for (int i = 0; i < num_lambdas; ++i) fprintf(fp, "\t%s", fmt_g(params[i]).c_str());
+        fprintf(fp, "\n");
+        if (have_lambda_tree)
+            fprintf(fp, "Lambda tree:\t%s\n", tree_string([&](int v) { return lambda_tree.name[v]; }, false).c_str());
+        fprintf(fp, "# IDs of nodes:%s\n",
+                tree_string([&](int v) { return tree.name[v] + "<" + std::to_string(v) + ">"; }, false).c_str());
+        fprintf(fp, "# Output format for: ' Average Expansion', 'Expansions', 'No Change', 'Contractions', and "
+                    "'Branch-specific P-values' = (node ID, node ID): ");
+        for (int b = 1; b < n; b += 2) fprintf(fp, "(%d,%d) ", tree.left[b], tree.right[b]);
+        fprintf(fp, "\n# Output format for 'Branch cutting P-values' and 'Likelihood Ratio Test': (0");
+        for (int i = 1; i < n; ++i) fprintf(fp, ", %d", i);
+        fprintf(fp, ")\n");
+        fprintf(fp, "Average Expansion:");
+        for (int b = 0; b < npairs / 2; ++b) fprintf(fp, "\t(%s,%s)", fmt_g(avg_exp[2 * b]).c_str(), fmt_g(avg_exp[2 * b + 1]).c_str());
+        fprintf(fp, "\nExpansion :");
+        for (int b = 0; b < npairs / 2; ++b) fprintf(fp, "\t(%d,%d)", n_expand[2 * b], n_expand[2 * b + 1]);
+        fprintf(fp, "\nnRemain :");
+        for (int b = 0; b < npairs / 2; ++b) fprintf(fp, "\t(%d,%d)", n_remain[2 * b], n_remain[2 * b + 1]);
+        fprintf(fp, "\nnDecrease :");
+        for (int b = 0; b < npairs / 2; ++b) fprintf(fp, "\t(%d,%d)", n_decrease[2 * b], n_decrease[2 * b + 1]);
+        fprintf(fp, "\n'ID'\t'Newick'\t'Family-wide P-value'\t'Viterbi P-values'\t'cut P-value'\t'Likelihood Ratio'\n");
+        for (int i = 0; i < F; ++i) {
+            const int32_t* fs = &rep_sizes[(size_t)i * n];
+            const std::string nw = tree_string([&](int v) { return tree.name[v] + "_" + std::to_string(fs[v]); }, true);
+            fprintf(fp, "%s\t%s\t%s\t(", fam.ids[i].c_str(), nw.c_str(), fmt_g(rep_max_p[i]).c_str());
+            for (int b = 0; b < npairs / 2; ++b) {
+                const double p1 = rep_branch_p[(size_t)i * (n - 1) + 2 * b], p2 = rep_branch_p[(size_t)i * (n - 1) + 2 * b + 1];
+                if (p1 < 0) fprintf(fp, "(-,-)");
+                else fprintf(fp, "(%s,%s)", fmt_g(p1).c_str(), fmt_g(p2).c_str());
+                if (b < npairs / 2 - 1) fprintf(fp, ",");
+            }
+            fprintf(fp, ")\t\n");
+        }
+        fclose(fp);
+        log("Report Done\n");
+        return 0;
+    }
+
     int dispatch(const std::string& line_in)
     {
         std::string line = line_in;
@@ -908,6 +1169,7 @@ struct cafehost_session {
         if (cmd == "tree") return cmd_tree(tokens);
         if (cmd == "lambda") return cmd_lambda(tokens);
         if (cmd == "lambdamu") return cmd_lambdamu(tokens);
+        if (cmd == "report") return cmd_report(tokens);
         throw std::runtime_error("command '" + cmd + "' is outside this build's scope (SURVEY.md section 8)");
     }
 

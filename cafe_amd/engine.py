@@ -154,6 +154,16 @@ class Engine:
         _lib.check(self._L.cafehip_eval_root_likelihoods(self._h, c.shape[0], _i(c), _i(lo), _i(hi), _i(cm), _d(out)))
         return out
 
+    def viterbi(self, counts, root_lo, root_hi, col_max):
+        """cafe_tree_viterbi for a batch of rows -> node sizes [B, n_nodes]."""
+        c = np.ascontiguousarray(counts, np.int32)
+        lo = np.ascontiguousarray(root_lo, np.int32)
+        hi = np.ascontiguousarray(root_hi, np.int32)
+        cm = np.ascontiguousarray(col_max, np.int32)
+        out = np.zeros((c.shape[0], self.n_nodes), np.int32)
+        _lib.check(self._L.cafehip_viterbi(self._h, c.shape[0], _i(c), _i(lo), _i(hi), _i(cm), _i(out)))
+        return out
+
     def enable_timing(self, on=True):
         _lib.check(self._L.cafehip_enable_timing(self._h, 1 if on else 0))
 

@@ -126,6 +126,16 @@ int cafehip_eval_root_likelihoods(cafehip_ctx *ctx, int B, const int32_t *counts
                                   const int32_t *root_lo, const int32_t *root_hi,
                                   const int32_t *col_max, double *out);
 
+/* Viterbi ancestral states (max-product pass + backtrack) for a batch of B count rows with per-row
+ * extents, using the matrices of the last evaluation / reset.  node_sizes: B x n_nodes int32 out
+ * (leaf entries repeat the counts, internal entries are the most likely sizes; strict '>' so the
+ * first maximum wins).  Rows whose products are all zero keep index 0 (the reference leaves stale
+ * memory there, cafe/viterbi.cpp:296-300).
+ * Replaces: cafe_tree_viterbi (cafe/viterbi.cpp:494-516, compute :208-320, backtrack :322-351)
+ * under the per-family ranges of cafe_family_set_size_with_family_forced (cafe/cafe_family.c:236-255). */
+int cafehip_viterbi(cafehip_ctx *ctx, int B, const int32_t *counts, const int32_t *root_lo,
+                    const int32_t *root_hi, const int32_t *col_max, int32_t *node_sizes);
+
 /* Timing of the kernels of the last cafehip_eval_posterior call, measured with HIP
  * events on the context's stream: ms[0] = matrix build, ms[1] = pruning+posterior,
  * ms[2] = score reduction.  Enabled by cafehip_enable_timing(ctx, 1). */
