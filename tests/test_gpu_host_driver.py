@@ -192,3 +192,39 @@ def test_viterbi_and_pvalue_inputs_match_oracle():
         assert list(got[i]) == list(fs), "family %d" % i
     L.orc_matrices_free(h)
     eng.close()
+
+
+def test_example_report_matches_oracle_and_survey_pin(shell, tmp_path):
+    # BASELINE north_star: identical ancestral-state / p-value output on the shipped example for `-t 1`.
+    # seed 10; load -t 1; tree; lambda -s; report  -- compared line by line with the oracle's report
+    # pipeline (same libc rand() stream) and with the row the reference printed in the build container
+    # (SURVEY.md section 8c): ENSF00000001658 ... _10  0.001  ((0.00547228,0.000329497),(0.193323,0.641219),
+    # (0.415701,0.263808),(0.79904,0.860897))
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+    path = os.path.join(GOLD, "example_data.tab")
+    shell.dispatch("seed 10")
+    shell.dispatch("load -i %s -t 1" % path)
+    shell.dispatch("tree " + newick)
+    shell.dispatch("lambda -s")
+    out = str(tmp_path / "example")
+    shell.dispatch("report " + out)
+    got = O.parse_cafe_report(out + ".cafe")
+    sp, ids, counts = O.load_family_table(path)
+    t = O.PyTree(newick)
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    rep, cd = O.report_with_oracle(t, counts, rng, float(shell.params[0]), pvalue_cut=0.01)
+    order = [0, 2, 1, 4, 6, 5, 3, 8, 7]  # Newick print order of the node ids
+    assert len(got) == len(ids) == 59
+    for fid, (maxp, sizes, bp) in zip(ids, rep):
+        gs, gp, gpairs = got[fid]
+        assert gs == [int(sizes[i]) for i in order], fid
+        assert gp == float("%g" % maxp), fid
+        for j, pair in enumerate(gpairs):
+            if bp is None:
+                assert pair is None, fid
+            else:
+                assert pair == (float("%g" % bp[2 * j]), float("%g" % bp[2 * j + 1])), fid
+    s, p, pairs = got["ENSF00000001658"]
+    assert s[-1] == 10 and p == 0.001
+    assert pairs == [(0.00547228, 0.000329497), (0.193323, 0.641219), (0.415701, 0.263808), (0.79904, 0.860897)]
