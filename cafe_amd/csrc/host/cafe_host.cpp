@@ -489,6 +489,11 @@ struct cafehost_session {
     double search_seconds = 0;
     std::vector<double> trace;
     std::vector<std::vector<double>> cond_dist;  // ConditionalDistribution::matrix, cafe/pvalue.cpp:13
+    // error model (one model file; ErrorStruct, libtree/family.h:31-38)
+    std::string err_file;
+    int err_mfs = -1, err_fromdiff = 0, err_todiff = 0;
+    std::vector<double> err_matrix;        // (mfs+1)^2, [observed][true]
+    std::vector<uint8_t> err_leaf;         // per node: leaf carries the model
     // last report (exposed for tests)
     std::vector<double> rep_max_p;
     std::vector<int32_t> rep_sizes;      // F x n_nodes
@@ -557,6 +562,10 @@ struct cafehost_session {
             for (int s = 0; s < ns; ++s)
                 if (species_index[s] >= 0) counts[(size_t)i * nl + species_index[s] / 2] = fam.counts[(size_t)i * ns + s];
         hip_check(cafehip_set_families(ctx, F, nl, counts.data(), nullptr, range.min, range.max, range.root_min, range.root_max));
+        if (err_mfs >= 0)
+            hip_check(cafehip_set_error_model(ctx, err_mfs, err_matrix.data(), err_leaf.data()));
+        else
+            hip_check(cafehip_set_error_model(ctx, 0, nullptr, nullptr));
         device_families_current = true;
     }
 
@@ -773,6 +782,8 @@ struct cafehost_session {
         fam.load(file, max_size);
         have_family = true;
         cond_dist.clear();
+        err_file.clear();
+        err_mfs = -1;
         range = init_family_size(fam.max_size);  // set_range_from_family
         sync_species_index();
         device_families_current = false;
@@ -1126,6 +1137,104 @@ struct cafehost_session {
         return 0;
     }
 
+
+    // ---- errormodel: cafe_cmd_errormodel (cafe/cafe_commands.cpp:1608-1639),
+    //      set_error_matrix_from_file (cafe/error_model.cpp:231-259), file reader (:145-204),
+    //      __check_error_model_columnsums (cafe/cafe_shell.c:585-622) ----
+    void read_error_model(const std::string& file)
+    {
+        std::ifstream in(file);
+        if (!in) throw std::runtime_error("ERROR(errormodel): Cannot open " + file + " in read mode.");
+        std::string line;
+        if (!std::getline(in, line)) throw std::runtime_error("Empty file");
+        auto data = HostFamilies::split(line, ' ');
+        auto mx = HostFamilies::split(data.at(0), ':');
+        if (mx.size() < 2) throw std::runtime_error("errormodel: first line must be maxcnt:<n>");
+        const int file_row_count = atoi(mx[1].c_str());
+        int mfs = std::max(range.max, file_row_count);  // :154-155, :241
+        int fromdiff = 0, todiff = 0;
+        if (std::getline(in, line)) {
+            data = HostFamilies::split(line, ' ');
+            fromdiff = atoi(data.at(1).c_str());
+            todiff = atoi(data.at(data.size() - 1).c_str());
+        }
+        const int ld = mfs + 1;
+        std::vector<double> E((size_t)ld * ld, 0.0);
+        int j = 0;
+        while (std::getline(in, line)) {
+            while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+            data = HostFamilies::split(line, ' ');
+            if ((int)data.size() != (todiff - fromdiff) + 2) continue;
+            const int col1 = atoi(data[0].c_str());
+            if (col1 != j)
+                throw std::runtime_error("errormodel: rows must be consecutive (row " + std::to_string(j) + " expected, found " +
+                                         std::to_string(col1) + "); the reference loops forever on such files (cafe/error_model.cpp:171-180)");
+            int k = 1;
+            for (int i = fromdiff; i <= todiff; ++i, ++k)
+                if (i + j >= 0 && i + j <= mfs) E[(size_t)(i + j) * ld + j] = atof(data[k].c_str());
+            ++j;
+        }
+        while (j && j <= mfs) {  // :193-201 copy the previous row's band down the diagonal
+            for (int i = fromdiff; i <= todiff; ++i)
+                if (i + j >= 0 && i + j <= mfs) E[(size_t)(i + j) * ld + j] = E[(size_t)(i + j - 1) * ld + (j - 1)];
+            ++j;
+        }
+        // __check_error_model_columnsums: NB the reference calls the INTEGER abs() on a double there, so the
+        // middle columns are renormalised only when |1 - sum| >= 1 (cafe/cafe_shell.c:603)
+        const int diff = todiff;
+        auto colsum = [&](int c) {
+            double sum = 0;
+            for (int i = 0; i <= mfs; ++i) sum += E[(size_t)i * ld + c];
+            return sum;
+        };
+        for (int c = 0; c < diff && c <= mfs; ++c) E[(size_t)0 * ld + c] += (1 - colsum(c));
+        for (int c = diff; c <= mfs - diff; ++c) {
+            const double sum = colsum(c);
+            if (std::abs((int)(1 - sum)) > 0.00000000000001)
+                for (int i = 0; i <= mfs; ++i) E[(size_t)i * ld + c] /= sum;
+        }
+        for (int c = std::max(mfs - diff + 1, 0); c <= mfs; ++c) E[(size_t)mfs * ld + c] += (1 - colsum(c));
+        err_matrix.swap(E);
+        err_mfs = mfs;
+        err_fromdiff = fromdiff;
+        err_todiff = todiff;
+        err_file = file;
+    }
+
+    int cmd_errormodel(const std::vector<std::string>& tokens)
+    {
+        prereqs(true, true);
+        auto args = build_argument_list(tokens);
+        std::string model;
+        std::vector<std::string> species;
+        bool all = false;
+        for (auto& a : args) {
+            if (a.opt == "-model" && !a.argv.empty()) model = a.argv[0];
+            else if (a.opt == "-sp") species.insert(species.end(), a.argv.begin(), a.argv.end());
+            else if (a.opt == "-all") all = true;
+            else throw std::runtime_error("errormodel " + a.opt + " is outside this build's scope (supported: -model -sp -all)");
+        }
+        if (model.empty()) throw std::runtime_error("ERROR(errormodel): we need an error model specified (-model) or two data files.\n");
+        if (!err_file.empty() && !iequals(err_file, model))
+            throw std::runtime_error("errormodel: one model file per session is supported (already using " + err_file + ")");
+        if (err_file.empty()) {
+            read_error_model(model);
+            err_leaf.assign(tree.n, 0);
+        }
+        // init_error_ptr, cafe/error_model.cpp:206-229
+        if (!species.empty()) {
+            for (auto& spname : species)
+                for (size_t s_ = 0; s_ < fam.species.size(); ++s_)
+                    if (iequals(fam.species[s_], spname) && species_index[s_] >= 0) err_leaf[species_index[s_]] = 1;
+        } else if (all) {
+            for (size_t s_ = 0; s_ < fam.species.size(); ++s_)
+                if (species_index[s_] >= 0) err_leaf[species_index[s_]] = 1;
+        }
+        device_families_current = false;
+        fprintf(stderr, "errormodel: %s set.\n", model.c_str());
+        return 0;
+    }
+
     int dispatch(const std::string& line_in)
     {
         std::string line = line_in;
@@ -1170,6 +1279,15 @@ struct cafehost_session {
         if (cmd == "lambda") return cmd_lambda(tokens);
         if (cmd == "lambdamu") return cmd_lambdamu(tokens);
         if (cmd == "report") return cmd_report(tokens);
+        if (cmd == "errormodel") return cmd_errormodel(tokens);
+        if (cmd == "noerrormodel") {  // cafe/cafe_commands.cpp: remove the model from every species
+            err_file.clear();
+            err_mfs = -1;
+            err_matrix.clear();
+            err_leaf.clear();
+            device_families_current = false;
+            return 0;
+        }
         throw std::runtime_error("command '" + cmd + "' is outside this build's scope (SURVEY.md section 8)");
     }
 

@@ -338,3 +338,47 @@ def report_with_oracle(tree, counts, rng, lam_value, trials=1000, pvalue_cut=0.0
         out.append((maxp, fs.copy(), bp))
     L.orc_matrices_free(h)
     return out, cd
+
+
+def load_error_model(path, range_max):
+    """Error-model file -> errormatrix[(mfs+1)^2] as the reference builds it: reader
+    cafe/error_model.cpp:145-204 (band on the diagonal, missing tail rows copy the previous band),
+    then __check_error_model_columnsums cafe/cafe_shell.c:585-622 -- including its use of the
+    INTEGER abs() on a double, which leaves middle columns untouched unless |1 - sum| >= 1."""
+    lines = [l.rstrip("\r\n") for l in open(path)]
+    mfs = max(range_max, int(lines[0].split(" ")[0].split(":")[1]))
+    head = lines[1].split(" ")
+    fromdiff, todiff = int(head[1]), int(head[-1])
+    E = np.zeros((mfs + 1, mfs + 1))
+    j = 0
+    for line in lines[2:]:
+        data = line.split(" ")
+        if len(data) != (todiff - fromdiff) + 2:
+            continue
+        assert int(data[0]) == j
+        for k, i in enumerate(range(fromdiff, todiff + 1), start=1):
+            if 0 <= i + j <= mfs:
+                E[i + j, j] = float(data[k])
+        j += 1
+    while j and j <= mfs:
+        for i in range(fromdiff, todiff + 1):
+            if 0 <= i + j <= mfs:
+                E[i + j, j] = E[i + j - 1, j - 1]
+        j += 1
+    diff = todiff
+
+    def colsum(c):
+        s = 0.0
+        for i in range(mfs + 1):
+            s += E[i, c]
+        return s
+
+    for c in range(0, min(diff, mfs + 1)):
+        E[0, c] += 1 - colsum(c)
+    for c in range(diff, mfs - diff + 1):
+        s = colsum(c)
+        if abs(int(1 - s)) > 1e-14:
+            E[:, c] /= s
+    for c in range(max(mfs - diff + 1, 0), mfs + 1):
+        E[mfs, c] += 1 - colsum(c)
+    return E, mfs

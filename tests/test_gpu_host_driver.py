@@ -228,3 +228,37 @@ def test_example_report_matches_oracle_and_survey_pin(shell, tmp_path):
     s, p, pairs = got["ENSF00000001658"]
     assert s[-1] == 10 and p == 0.001
     assert pairs == [(0.00547228, 0.000329497), (0.193323, 0.641219), (0.415701, 0.263808), (0.79904, 0.860897)]
+
+
+@pytest.mark.parametrize("model,sp", [("error1.txt", None), ("errormodel_test4.txt", ["mouse", "dog"])])
+def test_errormodel_command_matches_oracle(shell, model, sp):
+    # errormodel -model f (-all | -sp ...) then lambda -l x -score: leaves carry errormatrix[observed][.]
+    # (cafe/cafe_tree.c:196-203); compared with the oracle fed by an independent reading of the file
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+    path = os.path.join(GOLD, "example_data.tab")
+    shell.dispatch("seed 10")
+    shell.dispatch("load -i %s -t 1" % path)
+    shell.dispatch("tree " + newick)
+    if sp is None:
+        shell.dispatch("errormodel -model %s -all" % os.path.join(GOLD, model))
+    else:
+        shell.dispatch("errormodel -model %s -sp %s" % (os.path.join(GOLD, model), " ".join(sp)))
+    shell.dispatch("lambda -l 0.0017 -score")
+    spn, ids, counts = O.load_family_table(path)
+    t = O.PyTree(newick)
+    counts = O.reorder_to_tree(spn, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    E, mfs = O.load_error_model(os.path.join(GOLD, model), rng.max)
+    has = np.zeros(t.n_nodes, np.uint8)
+    for i in range(0, t.n_nodes, 2):
+        if sp is None or t.name[i] in sp:
+            has[i] = 1
+    prior = O.prior_poisson(1000, rng.root_min, shell.poisson_lambda)
+    so, *_ = O.eval_posterior(t, counts, rng, np.full(t.n_nodes, 0.0017), np.full(t.n_nodes, -1.0), prior,
+                              errormatrix=E, err_mfs=mfs, leaf_has_err=has)
+    assert math.isfinite(so)
+    assert shell.score == pytest.approx(-so, rel=1e-12)
+    # and it differs from the model-free score
+    shell.dispatch("noerrormodel")
+    shell.dispatch("lambda -l 0.0017 -score")
+    assert abs(shell.score + so) > 1e-3
