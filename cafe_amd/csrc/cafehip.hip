@@ -62,6 +62,9 @@ int fail(const char* fmt, ...)
 // ------------------------------------------------------------------------------------
 struct KeyParam {
     double log_alpha, log_beta, log_coeff, coeff;
+    double l2a, l2b, rho_m;   // product form (host_math.hpp KeyScalars)
+    int rho_e;
+    int fast_ok;
     int mode;  // host_math.hpp KeyScalars
     int bl;
 };
@@ -113,15 +116,17 @@ struct K2Args {
 // same sequence of IEEE operations as the reference's x86-64 build.
 // ------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
-template <bool USE_LDS>
+template <bool USE_LDS, bool PRODUCT_FORM>
 __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __restrict__ ep,
                                                          const double* __restrict__ lncA,
                                                          const double* __restrict__ lncB,
                                                          int ld_lnc, double* __restrict__ PT,
-                                                         int M, int LD, int KP)
+                                                         int M, int LD, int KP, int32_t* first_zero)
 {
     extern __shared__ double k1_smem[];
     const int key = blockIdx.z;
+    // first kernel of an evaluation: reset the first-zero-family slot K3 will atomicMin into
+    if (first_zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *first_zero = INT32_MAX;
     const int s0 = blockIdx.y * 16;
     const int c0 = blockIdx.x * 16;
     const int tx = threadIdx.x & 15;  // s within tile
@@ -175,7 +180,28 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
         p = 0.0;
         // terms are accumulated strictly in j order (the reference's order); the loads of the next
         // terms are independent of the running sum, so unrolling lets them overlap the exp chain
-        if (kp.mode == 2) {
+        if (PRODUCT_FORM && kp.fast_ok) {
+            // Same sum with the exponentials factored: a/b hold exp(ln C) (binomials through the
+            // reference's Lanczos lgamma), the power part alpha^(..) coeff^j is a geometric sequence kept
+            // as mantissa in [1,2) x 2^e so that nothing under/overflows before the final ldexp.  One exp2
+            // per ENTRY instead of one exp per TERM; deviation from the per-term form <~ 5e-13 relative,
+            // the size of the rounding the reference itself commits when it forms t.
+            const double y0 = (kp.mode == 2) ? (double)(s + c) * kp.l2a : (double)s * kp.l2a + (double)c * kp.l2b;
+            const double e0 = floor(y0);
+            double gm = exp2(y0 - e0);
+            int e = (int)e0;
+#pragma unroll 4
+            for (int j = 0; j <= m; ++j) {
+                const double term = a[j] * b[c - j] * gm;
+                p += ldexp(term, e);
+                gm *= kp.rho_m;
+                e += kp.rho_e;
+                if (gm >= 2.0) {
+                    gm *= 0.5;
+                    e += 1;
+                }
+            }
+        } else if (kp.mode == 2) {
             double lastterm = 1.0;
             const int s_add_c = s + c;
 #pragma unroll 4
@@ -354,13 +380,25 @@ __global__ __launch_bounds__(1024) void k2_prune_v1(K2Args a)
 // K3: score.  One workgroup per chunk of CAFEHIP_CHUNK families in FAMILY order
 // (duplicates expanded through fam2u), fixed-shape tree sum -> chunk_sums[chunk].
 // ------------------------------------------------------------------------------------
+// Results of the synchronous path go straight to pinned, device-visible host memory (no copy kernels,
+// no interrupt-driven wait): every block stores its chunk sum there, the last block to arrive (device
+// counter) publishes the first-zero index and a sequence number the host spins on.
+struct HostResult {
+    volatile int32_t done_seq;
+    int32_t first_zero;
+    double chunk_sums[1];  // n_chunks
+};
+
+template <bool HOST_OUT>
 __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(const double* __restrict__ max_post_u,
                                                           const double* __restrict__ max_lik_u,
                                                           const int32_t* __restrict__ fam2u, int F,
                                                           double* __restrict__ chunk_sums,
-                                                          int32_t* __restrict__ first_zero)
+                                                          int32_t* __restrict__ first_zero,
+                                                          HostResult* host, int32_t* arrive, int32_t seq)
 {
     __shared__ double red[CAFEHIP_CHUNK];
+    __shared__ int s_last;
     const int i = blockIdx.x * CAFEHIP_CHUNK + threadIdx.x;
     double v = 0.0;
     if (i < F) {
@@ -375,10 +413,25 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(const double* __restri
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = red[0];
+    if (!HOST_OUT) {
+        if (threadIdx.x == 0) chunk_sums[blockIdx.x] = red[0];
+        return;
+    }
+    if (threadIdx.x == 0) {
+        host->chunk_sums[blockIdx.x] = red[0];
+        __threadfence_system();
+        s_last = (atomicAdd(arrive, 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        __threadfence();
+        host->first_zero = atomicMin(first_zero, INT32_MAX);  // atomic read of the final value
+        *arrive = 0;
+        __threadfence_system();
+        host->done_seq = seq;
+    }
 }
 
-__global__ void k_fill_i32(int32_t* p, int32_t v) { *p = v; }
 
 #include "k2_mfma.hpp"
 
@@ -577,6 +630,8 @@ struct cafehip_ctx {
     // tables + matrices
     cafehip::LnCTables lnc;
     double *d_lncA = nullptr, *d_lncB = nullptr;
+    double *d_expA = nullptr, *d_expB = nullptr;
+    bool all_keys_fast = false, k1_product_form = false;
     double* d_PT = nullptr;
     size_t pt_keys_cap = 0;
 
@@ -594,10 +649,11 @@ struct cafehip_ctx {
     int err_mfs = -1;
     uint8_t* d_leaf_has_err = nullptr;
 
-    // pinned result staging
-    double* h_chunk = nullptr;
-    size_t h_chunk_cap = 0;
-    int32_t* h_fz = nullptr;
+    // pinned, device-visible result block of the synchronous path
+    HostResult* h_result = nullptr;
+    size_t h_result_chunks = 0;
+    int32_t* d_arrive = nullptr;
+    int32_t host_seq = 0;
 
     // timing
     bool timing = false;
@@ -671,6 +727,11 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
             h->keys[k].coeff = ks.coeff;
             h->keys[k].mode = ks.mode;
             h->keys[k].bl = bl;
+            h->keys[k].l2a = ks.l2a;
+            h->keys[k].l2b = ks.l2b;
+            h->keys[k].rho_m = ks.rho_m;
+            h->keys[k].rho_e = ks.rho_e;
+            h->keys[k].fast_ok = ks.fast_ok;
             ++nk;
         }
         c->node_key[i] = k;
@@ -678,6 +739,9 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
     }
     h->nkeys = nk;
     c->nkeys = nk;
+    c->all_keys_fast = true;
+    for (int k = 0; k < nk; ++k)
+        if (h->keys[k].mode >= 2 && !h->keys[k].fast_ok) c->all_keys_fast = false;
     if (prior) {
         // compute_posterior adds log(prior[j]) (cafe/lambda.cpp:681); the log is taken on the host
         for (int j = 0; j < c->R; ++j) h->logprior[j] = std::log(prior[j]);
@@ -689,19 +753,31 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
     return 0;
 }
 
-int launch_k1(cafehip_ctx* c)
+int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr)
 {
     if (c->nkeys == 0) return 0;
     dim3 grid((c->S + 15) / 16, (c->S + 15) / 16, c->nkeys);
     size_t lds = 2 * 16 * (size_t)c->lnc.ld * sizeof(double);
     const int use_lds = lds <= 60 * 1024;  // bigger tables are read through L1/L2 instead
     if (!use_lds) lds = 0;
-    if (use_lds)
-        hipLaunchKernelGGL(k1_build_matrices<true>, grid, dim3(256), lds, c->stream, c->d_params,
-                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP);
-    else
-        hipLaunchKernelGGL(k1_build_matrices<false>, grid, dim3(256), 0, c->stream, c->d_params,
-                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP);
+    const char* k1env = getenv("CAFEHIP_K1");
+    const bool product = c->lnc.product_form_ok && c->all_keys_fast && !(k1env && strcmp(k1env, "exact") == 0);
+    c->k1_product_form = product;
+    if (product) {
+        // every key of this evaluation qualifies: the staged tables are exp(ln C)
+        if (use_lds)
+            hipLaunchKernelGGL((k1_build_matrices<true, true>), grid, dim3(256), lds, c->stream, c->d_params,
+                               c->d_expA, c->d_expB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero);
+        else
+            hipLaunchKernelGGL((k1_build_matrices<false, true>), grid, dim3(256), 0, c->stream, c->d_params,
+                               c->d_expA, c->d_expB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero);
+    } else if (use_lds) {
+        hipLaunchKernelGGL((k1_build_matrices<true, false>), grid, dim3(256), lds, c->stream, c->d_params,
+                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero);
+    } else {
+        hipLaunchKernelGGL((k1_build_matrices<false, false>), grid, dim3(256), 0, c->stream, c->d_params,
+                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero);
+    }
     HIP_TRY(hipGetLastError());
     c->have_matrices = true;
     return 0;
@@ -954,14 +1030,14 @@ int check_ready(cafehip_ctx* c)
 }
 
 int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu,
-                const double* prior, double* d_chunk_sums, int32_t* d_first_zero)
+                const double* prior, double* d_chunk_sums, int32_t* d_first_zero, bool host_out = false)
 {
     if (check_ready(c)) return -1;
     HIP_TRY(hipSetDevice(c->device));
     EvalParams* h = nullptr;
     if (stage_params(c, node_lambda, node_mu, prior, &h)) return -1;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    if (launch_k1(c)) return -1;
+    if (launch_k1(c, d_first_zero)) return -1;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     K2Args a;
     fill_common_k2(c, a);
@@ -977,11 +1053,17 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
     }
     if (launch_k2(c, a, c->Fu)) return -1;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(1), 0, c->stream, d_first_zero, INT32_MAX);
     if (c->n_chunks > 0) {
-        hipLaunchKernelGGL(k3_score, dim3(c->n_chunks), dim3(CAFEHIP_CHUNK), 0, c->stream,
-                           c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, d_chunk_sums,
-                           d_first_zero);
+        if (host_out) {
+            ++c->host_seq;
+            hipLaunchKernelGGL(k3_score<true>, dim3(c->n_chunks), dim3(CAFEHIP_CHUNK), 0, c->stream,
+                               c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, d_chunk_sums, d_first_zero,
+                               c->h_result, c->d_arrive, c->host_seq);
+        } else {
+            hipLaunchKernelGGL(k3_score<false>, dim3(c->n_chunks), dim3(CAFEHIP_CHUNK), 0, c->stream,
+                               c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, d_chunk_sums, d_first_zero,
+                               (HostResult*)nullptr, (int32_t*)nullptr, 0);
+        }
     }
     HIP_TRY(hipGetLastError());
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
@@ -1049,7 +1131,8 @@ int cafehip_create(cafehip_ctx** out, int device_id)
     }
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
     HIP_TRY(hipMalloc(&c->d_first_zero, sizeof(int32_t)));
-    HIP_TRY(hipHostMalloc(&c->h_fz, sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&c->d_arrive, sizeof(int32_t)));
+    HIP_TRY(hipMemset(c->d_arrive, 0, sizeof(int32_t)));
     *out = c;
     return 0;
 }
@@ -1068,6 +1151,8 @@ void cafehip_destroy(cafehip_ctx* c)
     hipFree(c->d_vit_slot);
     hipFree(c->d_lncA);
     hipFree(c->d_lncB);
+    hipFree(c->d_expA);
+    hipFree(c->d_expB);
     hipFree(c->d_PT);
     hipFree(c->d_params);
     hipFree(c->d_err);
@@ -1078,8 +1163,8 @@ void cafehip_destroy(cafehip_ctx* c)
         hipEventDestroy(c->h_params_ev[i]);
     }
     for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
-    hipHostFree(c->h_chunk);
-    hipHostFree(c->h_fz);
+    hipHostFree(c->h_result);
+    hipFree(c->d_arrive);
     hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1256,11 +1341,13 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
     HIP_TRY(hipMalloc(&c->d_max_post, std::max(Fu, 1) * sizeof(double)));
     HIP_TRY(hipMalloc(&c->d_argmax, std::max(Fu, 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&c->d_chunk_sums, std::max(c->n_chunks, 1) * sizeof(double)));
-    if ((size_t)c->n_chunks > c->h_chunk_cap) {
-        hipHostFree(c->h_chunk);
-        c->h_chunk = nullptr;
-        HIP_TRY(hipHostMalloc(&c->h_chunk, std::max(c->n_chunks, 1) * sizeof(double), hipHostMallocDefault));
-        c->h_chunk_cap = c->n_chunks;
+    if (!c->h_result || (size_t)c->n_chunks > c->h_result_chunks) {
+        hipHostFree(c->h_result);
+        c->h_result = nullptr;
+        const size_t bytes = sizeof(HostResult) + (size_t)std::max(c->n_chunks, 1) * sizeof(double);
+        HIP_TRY(hipHostMalloc((void**)&c->h_result, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+        memset((void*)c->h_result, 0, bytes);
+        c->h_result_chunks = c->n_chunks;
     }
     if (new_M) {
         c->lnc.build(M);
@@ -1271,6 +1358,13 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
         HIP_TRY(hipMalloc(&c->d_lncB, c->lnc.B.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(c->d_lncA, c->lnc.A.data(), c->lnc.A.size() * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_lncB, c->lnc.B.data(), c->lnc.B.size() * sizeof(double), hipMemcpyHostToDevice));
+        hipFree(c->d_expA);
+        hipFree(c->d_expB);
+        c->d_expA = c->d_expB = nullptr;
+        HIP_TRY(hipMalloc(&c->d_expA, c->lnc.EA.size() * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_expB, c->lnc.EB.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(c->d_expA, c->lnc.EA.data(), c->lnc.EA.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_expB, c->lnc.EB.data(), c->lnc.EB.size() * sizeof(double), hipMemcpyHostToDevice));
         hipFree(c->d_PT);
         c->d_PT = nullptr;
         c->pt_keys_cap = 0;
@@ -1324,12 +1418,30 @@ int cafehip_eval_posterior(cafehip_ctx* c, const double* node_lambda, const doub
 {
     if (!c) return fail("null context");
     if (!node_lambda || !node_mu || !prior || !score) return fail("null argument");
-    if (cafehip_eval_posterior_async(c, node_lambda, node_mu, prior, c->d_chunk_sums, c->d_first_zero)) return -1;
-    if (c->n_chunks)
-        HIP_TRY(hipMemcpyAsync(c->h_chunk, c->d_chunk_sums, c->n_chunks * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_fz, c->d_first_zero, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_err && c->err_mfs < c->range_max)
+        return fail("error model covers sizes 0..%d but range_max is %d", c->err_mfs, c->range_max);
+    if (eval_device(c, node_lambda, node_mu, prior, c->d_chunk_sums, c->d_first_zero, true)) return -1;
+    if (c->n_chunks > 0) {
+        // spin on the sequence number the last K3 block publishes (a few microseconds after the kernel
+        // ends); fall back to a stream query now and then so that a faulted launch cannot hang us
+        const int32_t want = c->host_seq;
+        unsigned long spins = 0;
+        while (c->h_result->done_seq != want) {
+            if ((++spins & 0x3FFFF) == 0) {
+                hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess) {
+                    if (c->h_result->done_seq != want) HIP_TRY(hipStreamSynchronize(c->stream));
+                    if (c->h_result->done_seq != want) return fail("score kernel finished without publishing its result");
+                    break;
+                }
+                if (q != hipErrorNotReady) return fail("stream error while waiting: %s", hipGetErrorString(q));
+            }
+        }
+    } else {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     if (c->timing) {
+        HIP_TRY(hipEventSynchronize(c->ev[3]));
         for (int i = 0; i < 3; ++i) {
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
@@ -1338,8 +1450,9 @@ int cafehip_eval_posterior(cafehip_ctx* c, const double* node_lambda, const doub
     }
     // fixed-order final sum over chunks (independent of how chunks were produced)
     double s = 0.0;
-    for (int i = 0; i < c->n_chunks; ++i) s += c->h_chunk[i];
-    const int fz = (*c->h_fz >= 0 && *c->h_fz < c->F) ? *c->h_fz : -1;
+    for (int i = 0; i < c->n_chunks; ++i) s += c->h_result->chunk_sums[i];
+    const int32_t hfz = c->n_chunks > 0 ? c->h_result->first_zero : INT32_MAX;
+    const int fz = (hfz >= 0 && hfz < c->F) ? hfz : -1;
     *score = (fz >= 0) ? -INFINITY : s;  // cafe/lambda.cpp:753-760
     if (first_zero_family) *first_zero_family = fz;
     if (max_lik || argmax_root || max_post) {
@@ -1548,10 +1661,10 @@ const char* cafehip_describe(cafehip_ctx* c)
     char buf[512];
     snprintf(buf, sizeof buf,
              "device=%d cus=%d F=%d Fu=%d n_leaves=%d S=%d C=%d R=%d LD=%d KP=%d LDv=%d nkeys=%d "
-             "n_ops=%zu n_slots=%d n_parks=%d k2:%s NF=%d block=%d lds=%zu cfg(nftw,nrtw,wf,wr)=%d,%d,%d,%d",
+             "n_ops=%zu n_slots=%d n_parks=%d k1:%s k2:%s NF=%d block=%d lds=%zu cfg(nftw,nrtw,wf,wr)=%d,%d,%d,%d",
              c->device, c->n_cu, c->F, c->Fu, c->n_leaves, c->S, c->C, c->R, c->LD, c->KP, c->LDv,
              c->nkeys, c->sched.ops.size(), c->sched.n_slots, c->msched.n_parks,
-             c->k2_used_mfma ? "mfma" : "v1", c->k2_nf, c->k2_block, c->k2_lds, c->k2_cfg[0], c->k2_cfg[1],
+             c->k1_product_form ? "product" : "exact", c->k2_used_mfma ? "mfma" : "v1", c->k2_nf, c->k2_block, c->k2_lds, c->k2_cfg[0], c->k2_cfg[1],
              c->k2_cfg[2], c->k2_cfg[3]);
     c->desc = buf;
     return c->desc.c_str();

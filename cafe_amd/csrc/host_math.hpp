@@ -2,6 +2,7 @@
 // the ln C(n,k) tables and per-key birth-death scalars the device kernels consume.
 // Each function states the reference behaviour it must reproduce (file:line).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -39,17 +40,33 @@ struct LnCTables {
     int M = -1;
     int ld = 0;
     std::vector<double> A, B;
+    // exp() of the two tables for the product-form matrix kernel; usable only while every
+    // EA * EB * 2 stays finite (M up to ~300)
+    std::vector<double> EA, EB;
+    bool product_form_ok = false;
     void build(int M_)
     {
         M = M_;
         ld = (M + 1) | 1;
         A.assign((size_t)(M + 1) * ld, 0.0);
         B.assign((size_t)(M + 1) * ld, 0.0);
+        EA.assign(A.size(), 0.0);
+        EB.assign(B.size(), 0.0);
+        double maxA = 0, maxB = 0;
         for (int s = 0; s <= M; ++s) {
-            for (int j = 0; j <= s; ++j) A[(size_t)s * ld + j] = chooseln(s, j);
+            for (int j = 0; j <= s; ++j) {
+                A[(size_t)s * ld + j] = chooseln(s, j);
+                EA[(size_t)s * ld + j] = std::exp(A[(size_t)s * ld + j]);
+                maxA = std::max(maxA, EA[(size_t)s * ld + j]);
+            }
             if (s >= 1)
-                for (int i = 0; i <= M; ++i) B[(size_t)s * ld + i] = chooseln(s - 1 + i, s - 1);
+                for (int i = 0; i <= M; ++i) {
+                    B[(size_t)s * ld + i] = chooseln(s - 1 + i, s - 1);
+                    EB[(size_t)s * ld + i] = std::exp(B[(size_t)s * ld + i]);
+                    maxB = std::max(maxB, EB[(size_t)s * ld + i]);
+                }
         }
+        product_form_ok = std::isfinite(maxA) && std::isfinite(maxB) && (std::log10(maxA) + std::log10(maxB) < 300.0);
     }
 };
 
@@ -61,6 +78,11 @@ struct LnCTables {
 struct KeyScalars {
     double log_alpha, log_beta, log_coeff, coeff;
     int mode;
+    // product form: w_j = alpha^(s+c-2j) coeff^j (mode 2) or alpha^(s-j) beta^(c-j) coeff^j (mode 3)
+    //             = 2^(s*l2a + c*l2b) * rho^j,  rho = coeff / (alpha * beta) = rho_m * 2^rho_e, rho_m in [1,2)
+    double l2a, l2b, rho_m;
+    int rho_e;
+    int fast_ok;
 };
 
 inline KeyScalars key_scalars(int branchlength, double lambda, double mu)
@@ -86,17 +108,30 @@ inline KeyScalars key_scalars(int branchlength, double lambda, double mu)
         // `coeff > 0 && coeff != 1`, leaving the calloc'd zero rows: same as mode 0)
         k.mode = 0;
         k.log_alpha = k.log_beta = k.log_coeff = 0;
+        k.l2a = k.l2b = 0; k.rho_m = 1; k.rho_e = 0; k.fast_ok = 0;
         return k;
     }
     if (coeff == 1) {
         k.mode = 1;
         k.log_alpha = k.log_beta = k.log_coeff = 0;
+        k.l2a = k.l2b = 0; k.rho_m = 1; k.rho_e = 0; k.fast_ok = 0;
         return k;
     }
     k.log_alpha = std::log(alpha);
     k.log_beta = std::log(beta);
     k.log_coeff = std::log(coeff);
     k.mode = (mu < 0) ? 2 : 3;
+    k.l2a = std::log2(alpha);
+    k.l2b = std::log2(beta);
+    const double rho = coeff / (alpha * beta);
+    k.fast_ok = std::isfinite(rho) && rho > 0 && std::isfinite(k.l2a) && std::isfinite(k.l2b);
+    if (k.fast_ok) {
+        k.rho_e = std::ilogb(rho);
+        k.rho_m = std::scalbn(rho, -k.rho_e);
+    } else {
+        k.rho_e = 0;
+        k.rho_m = 1.0;
+    }
     return k;
 }
 

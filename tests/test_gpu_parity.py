@@ -79,18 +79,27 @@ def test_matrices_all_branches(eng):
         (np.full(t.n_nodes, 0.0123), np.full(t.n_nodes, -1.0)),  # 0.0123 * 93 > 1 -> zero matrix on E
         (np.linspace(0.001, 0.004, t.n_nodes), np.linspace(0.002, 0.0005, t.n_nodes)),
     ]
-    for lam, mu in cases:
-        eng.reset_birthdeath_cache(lam, mu)
-        for node in range(t.n_nodes):
-            if node == t.root:
-                continue
-            ref = O.birthdeath_matrix(int(t.branchlength[node]), lam[node], mu[node], M)
-            got = eng.get_matrix(node)
-            assert got.shape == ref.shape
-            ok, worst = rel_close(got, ref, MAT_RTOL, atol=1e-300)
-            assert ok, "node %d worst rel err %g" % (node, worst)
-            assert np.array_equal(got == 0, ref == 0)  # exact zeros in the same places
-            assert got[0, 0] == 1 and np.all(got[0, 1:] == 0)
+    try:
+        for mode, rtol in (("exact", MAT_RTOL), ("product", 5e-12)):
+            # exact: the reference's per-term exp sequence; product: factored exponentials (default)
+            os.environ["CAFEHIP_K1"] = mode
+            for lam, mu in cases:
+                eng.reset_birthdeath_cache(lam, mu)
+                for node in range(t.n_nodes):
+                    if node == t.root:
+                        continue
+                    ref = O.birthdeath_matrix(int(t.branchlength[node]), lam[node], mu[node], M)
+                    got = eng.get_matrix(node)
+                    assert got.shape == ref.shape
+                    ok, worst = rel_close(got, ref, rtol, atol=1e-300)
+                    assert ok, "%s: node %d worst rel err %g" % (mode, node, worst)
+                    if mode == "exact":
+                        assert np.array_equal(got == 0, ref == 0)  # exact zeros in the same places
+                    else:
+                        assert np.all(np.abs(got[ref == 0]) < 1e-290) and np.all(ref[got == 0] < 1e-290)
+                    assert got[0, 0] == 1 and np.all(got[0, 1:] == 0)
+    finally:
+        os.environ.pop("CAFEHIP_K1", None)
 
 
 def test_example_data_and_survey_pins(eng):
