@@ -914,6 +914,13 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out)
                 static const double wpen[9] = {0, 1.25, 1.09, 1.05, 1.0, 1.1, 1.2, 1.25, 1.3};
                 double cost = maxload * wpen[W];
                 cost *= 1.0 + 0.002 * (n_wg * wf) / (double)n_cu;  // matrix re-streaming
+                {
+                    // waves of one workgroup meet at barriers: an uneven deal of the row tiles stalls
+                    // the light waves (cfg4 shape: 3,3,2,2 tiles is 16 % slower than 5,5,5,5)
+                    const int hi_t = RTc / wr + (RTc % wr ? 1 : 0);
+                    const double mean_t = (double)RTc / wr;
+                    cost *= 1.0 + 0.8 * (hi_t / mean_t - 1.0);
+                }
                 if (cost < best) {
                     best = cost;
                     *out = K2Cfg{nft_w, nrt_w, wf, wr};
