@@ -1180,7 +1180,9 @@ int cafehip_set_stream(cafehip_ctx* c, void* hip_stream)
 {
     if (!c) return fail("null context");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    // NULL is a real stream in HIP (the legacy default stream, which is also what
+    // torch.cuda.current_stream().cuda_stream returns unless a side stream is current)
+    c->stream = (hipStream_t)hip_stream;
     return 0;
 }
 

@@ -378,7 +378,27 @@ struct FMinSearch {
     }
 };
 
-double unifrnd() { return rand() / (RAND_MAX + 1.0); }  // libcommon/mathfunc.c:91-94
+// The reference draws from glibc's process-global rand() (libcommon/mathfunc.c:91-94).  Other libraries
+// in the process (e.g. a collective backend) may call rand() too, so the session keeps a PRIVATE copy of
+// the same generator: rand() is random() on the default TYPE_3 state (128-byte table), which random_r
+// reproduces draw for draw for the same seed.
+struct GlibcRand {
+    struct random_data rd;
+    char state[128];
+    GlibcRand()
+    {
+        memset(&rd, 0, sizeof rd);
+        memset(state, 0, sizeof state);
+        initstate_r(1, state, sizeof state, &rd);  // glibc's state before any srand()
+    }
+    void seed(unsigned v) { srandom_r(v, &rd); }
+    double unifrnd()
+    {
+        int32_t r = 0;
+        random_r(&rd, &r);
+        return r / (RAND_MAX + 1.0);
+    }
+};
 
 // poisspdf, libcommon/mathfunc.c:352-355
 double poisspdf(int x, double lambda) { return std::exp(x * std::log(lambda) - cafehip::gammaln(x + 1) - lambda); }
@@ -461,6 +481,8 @@ std::vector<Argument> build_argument_list(const std::vector<std::string>& tokens
 // ====================================================================================
 struct cafehost_session {
     cafehip_ctx* ctx = nullptr;
+    GlibcRand rng;
+    double unifrnd() { return rng.unifrnd(); }
     FILE* flog = stdout;
     bool own_log = false;
     std::string log_name = "stdout";
@@ -478,6 +500,12 @@ struct cafehost_session {
     int num_threads = 1;
     int num_random_samples = 1000;
     bool device_families_current = false;
+    // multi-GPU: this rank's chunk-aligned block [shard_lo, shard_hi) of the table
+    int shard_rank = 0, shard_world = 1, shard_lo = 0, shard_hi = 0;
+    cafehost_exchange_fn exchange = nullptr;
+    void* exchange_user = nullptr;
+    double* d_exch_chunks = nullptr;
+    int32_t* d_exch_fz = nullptr;
 
     // model state
     int num_lambdas = 1, num_mus = 0, num_params = 0;
@@ -555,12 +583,24 @@ struct cafehost_session {
         if (device_families_current) return;
         hip_check(cafehip_set_tree(ctx, tree.n, tree.parent.data(), tree.left.data(), tree.right.data(), tree.bl.data()));
         const int nl = tree.n_leaves();
-        const int F = fam.F();
+        const int Fall = fam.F();
         const int ns = (int)fam.species.size();
+        {
+            // contiguous chunk-aligned blocks (same rule as cafe_amd/distributed.py shard_bounds)
+            const int n_chunks = (Fall + CAFEHIP_CHUNK - 1) / CAFEHIP_CHUNK;
+            const int base = n_chunks / shard_world, extra = n_chunks % shard_world;
+            int c0 = 0;
+            for (int r = 0; r < shard_rank; ++r) c0 += base + (r < extra ? 1 : 0);
+            const int nc = base + (shard_rank < extra ? 1 : 0);
+            shard_lo = std::min(c0 * CAFEHIP_CHUNK, Fall);
+            shard_hi = std::min((c0 + nc) * CAFEHIP_CHUNK, Fall);
+        }
+        const int F = shard_hi - shard_lo;
         std::vector<int32_t> counts((size_t)std::max(F, 1) * nl, 0);
         for (int i = 0; i < F; ++i)
             for (int s = 0; s < ns; ++s)
-                if (species_index[s] >= 0) counts[(size_t)i * nl + species_index[s] / 2] = fam.counts[(size_t)i * ns + s];
+                if (species_index[s] >= 0)
+                    counts[(size_t)i * nl + species_index[s] / 2] = fam.counts[(size_t)(shard_lo + i) * ns + s];
         hip_check(cafehip_set_families(ctx, F, nl, counts.data(), nullptr, range.min, range.max, range.root_min, range.root_max));
         if (err_mfs >= 0)
             hip_check(cafehip_set_error_model(ctx, err_mfs, err_matrix.data(), err_leaf.data()));
@@ -642,7 +682,16 @@ struct cafehost_session {
             std::vector<double> nl, nm;
             node_rates(x, nl, nm);
             int32_t zero = -1;
-            hip_check(cafehip_eval_posterior(ctx, nl.data(), nm.data(), prior.data(), &score, &zero, nullptr, nullptr, nullptr));
+            if (exchange) {
+                // multi-GPU: partial sums stay on the device, the caller's collective produces the score
+                hip_check(cafehip_eval_posterior_async(ctx, nl.data(), nm.data(), prior.data(), d_exch_chunks, d_exch_fz));
+                int z = -1;
+                score = exchange(exchange_user, &z);
+                zero = z;
+            } else {
+                hip_check(cafehip_eval_posterior(ctx, nl.data(), nm.data(), prior.data(), &score, &zero, nullptr, nullptr, nullptr));
+                if (zero >= 0) zero += shard_lo;
+            }
             if (zero >= 0) {  // cafe/lambda.cpp:715-720, 753-760
                 if (!quiet)
                     fprintf(stderr, "WARNING: Calculated posterior probability for family %s = 0\n", fam.ids[zero].c_str());
@@ -1252,7 +1301,7 @@ struct cafehost_session {
         if (cmd == "exit" || cmd == "quit") return 1;
         if (cmd == "seed") {  // cafe/cafe_commands.cpp:1950-1965
             if (tokens.size() < 2) throw std::runtime_error("Usage(seed): seed <value>");
-            srand((unsigned)atoi(tokens[1].c_str()));
+            rng.seed((unsigned)atoi(tokens[1].c_str()));
             return 0;
         }
         if (cmd == "date") {  // :262-270
@@ -1358,6 +1407,56 @@ int cafehost_run_script(cafehost_session* s, const char* path)
     if (!s || !path) return host_fail("null argument");
     try {
         return s->run_script(path);
+    } catch (const std::exception& e) {
+        return host_fail(e.what());
+    }
+}
+
+int cafehost_set_shard(cafehost_session* s, int rank, int world)
+{
+    if (!s) return host_fail("null session");
+    if (world < 1 || rank < 0 || rank >= world) return host_fail("bad shard " + std::to_string(rank) + "/" + std::to_string(world));
+    s->shard_rank = rank;
+    s->shard_world = world;
+    s->device_families_current = false;
+    return 0;
+}
+
+int cafehost_shard_bounds(cafehost_session* s, int* lo, int* hi, int* n_chunks_local)
+{
+    if (!s) return host_fail("null session");
+    if (lo) *lo = s->shard_lo;
+    if (hi) *hi = s->shard_hi;
+    if (n_chunks_local) *n_chunks_local = (s->shard_hi - s->shard_lo + CAFEHIP_CHUNK - 1) / CAFEHIP_CHUNK;
+    return 0;
+}
+
+int cafehost_set_exchange(cafehost_session* s, cafehost_exchange_fn exchange, void* user, void* d_chunk_sums,
+                          void* d_first_zero)
+{
+    if (!s) return host_fail("null session");
+    if (exchange && (!d_chunk_sums || !d_first_zero)) return host_fail("exchange needs device buffers");
+    s->exchange = exchange;
+    s->exchange_user = user;
+    s->d_exch_chunks = (double*)d_chunk_sums;
+    s->d_exch_fz = (int32_t*)d_first_zero;
+    return 0;
+}
+
+int cafehost_set_stream(cafehost_session* s, void* hip_stream)
+{
+    if (!s) return host_fail("null session");
+    if (cafehip_set_stream(s->ctx, hip_stream) != 0) return host_fail(std::string("cafehip: ") + cafehip_last_error());
+    return 0;
+}
+
+int cafehost_upload(cafehost_session* s)
+{
+    if (!s) return host_fail("null session");
+    try {
+        s->prereqs(true, true);
+        s->upload();
+        return 0;
     } catch (const std::exception& e) {
         return host_fail(e.what());
     }

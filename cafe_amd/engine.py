@@ -64,6 +64,7 @@ class Engine:
 
     # ---- setup -------------------------------------------------------------------------
     def set_stream(self, hip_stream_handle):
+        """Run on the caller's stream; 0 is the HIP default stream (torch's default stream handle)."""
         _lib.check(self._L.cafehip_set_stream(self._h, C.c_void_p(hip_stream_handle or 0)))
 
     def set_tree(self, parent, left, right, branchlength):

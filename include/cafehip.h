@@ -47,8 +47,9 @@ int cafehip_abi_version(void);
 int cafehip_create(cafehip_ctx **out, int device_id);
 void cafehip_destroy(cafehip_ctx *ctx);
 
-/* Run all subsequent work of this context on the caller's HIP stream
- * (a hipStream_t passed as void*; NULL = the context's own stream). */
+/* Run all subsequent work of this context on the caller's HIP stream (a hipStream_t passed as
+ * void*).  NULL is the HIP legacy default stream -- the handle torch reports for its default
+ * stream -- NOT "no stream": until this is called the context uses a private non-blocking stream. */
 int cafehip_set_stream(cafehip_ctx *ctx, void *hip_stream);
 
 /* Tree topology in the reference's nlist numbering (in-order: even ids are

@@ -36,6 +36,22 @@ int cafehost_dispatch(cafehost_session *s, const char *command_line);
 /* Run a script file (main.cpp:43 `source`): one command per line, '#' lines ignored. */
 int cafehost_run_script(cafehost_session *s, const char *path);
 
+/* ---- multi-GPU (one process per GPU) ------------------------------------------------------------
+ * Every rank runs the same script (same seed => same Nelder-Mead decisions); a rank scores only its
+ * chunk-aligned block of the family table and the ranks exchange the per-chunk partial sums once per
+ * objective call.  The collective itself stays outside this library (RCCL through torch.distributed
+ * in cafe_amd/multi_gpu.py): the driver fills the caller's device buffers asynchronously and then calls
+ * `exchange`, which must return the global score and set *first_zero_global (< 0 if none). */
+typedef double (*cafehost_exchange_fn)(void *user, int *first_zero_global);
+int cafehost_set_shard(cafehost_session *s, int rank, int world);
+int cafehost_shard_bounds(cafehost_session *s, int *lo, int *hi, int *n_chunks_local);
+int cafehost_set_exchange(cafehost_session *s, cafehost_exchange_fn exchange, void *user,
+                          void *d_chunk_sums, void *d_first_zero);
+int cafehost_set_stream(cafehost_session *s, void *hip_stream);
+/* Upload tree + (sharded) table now instead of at the first lambda command (so that the caller can size
+ * its exchange buffers from cafehost_shard_bounds). */
+int cafehost_upload(cafehost_session *s);
+
 /* Results of the last lambda / lambdamu command. */
 int cafehost_num_params(cafehost_session *s);
 int cafehost_get_params(cafehost_session *s, double *out, int n);   /* fitted lambda(s) [, mu(s)] */
