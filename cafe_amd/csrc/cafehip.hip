@@ -647,6 +647,7 @@ struct cafehip_ctx {
     // error model
     double* d_err = nullptr;
     int err_mfs = -1;
+    int err_banded = 0, err_dlo = 0, err_dhi = 0;
     uint8_t* d_leaf_has_err = nullptr;
 
     // pinned, device-visible result block of the synchronous path
@@ -979,6 +980,9 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     a.err = v1.err;
     a.err_ld = v1.err_ld;
     a.leaf_has_err = v1.leaf_has_err;
+    a.err_banded = (v1.err != nullptr) ? c->err_banded : 0;
+    a.err_dlo = c->err_dlo;
+    a.err_dhi = c->err_dhi;
     a.root_lo = v1.root_lo;
     a.root_hi = v1.root_hi;
     a.col_max = v1.col_max;
@@ -1398,6 +1402,21 @@ int cafehip_set_error_model(cafehip_ctx* c, int mfs, const double* errormatrix,
     if (c->n_nodes <= 0) return fail("set the tree before the error model");
     if (mfs < 0) return fail("bad error-model size %d", mfs);
     const size_t n = (size_t)(mfs + 1) * (mfs + 1);
+    {
+        // band of the model: non-zeros only where dlo <= true - observed <= dhi
+        int dlo = INT_MAX, dhi = INT_MIN;
+        for (int o = 0; o <= mfs; ++o)
+            for (int t = 0; t <= mfs; ++t)
+                if (errormatrix[(size_t)o * (mfs + 1) + t] != 0.0) {
+                    dlo = std::min(dlo, t - o);
+                    dhi = std::max(dhi, t - o);
+                }
+        if (dlo > dhi) dlo = dhi = 0;
+        c->err_dlo = dlo;
+        c->err_dhi = dhi;
+        const char* e = getenv("CAFEHIP_ERRBAND");
+        c->err_banded = (dhi - dlo + 1 <= 16) && !(e && strcmp(e, "0") == 0);
+    }
     HIP_TRY(hipMalloc(&c->d_err, n * sizeof(double)));
     HIP_TRY(hipMemcpy(c->d_err, errormatrix, n * sizeof(double), hipMemcpyHostToDevice));
     std::vector<uint8_t> by_col((c->n_nodes + 1) / 2, 0);

@@ -41,6 +41,8 @@ struct K2MfmaArgs {
     const double* err;
     int err_ld;
     const uint8_t* leaf_has_err;
+    int err_banded;        // 1: errormatrix[obs][true] is zero unless err_dlo <= true - obs <= err_dhi
+    int err_dlo, err_dhi;
     // batch mode (per-row extents)
     const int32_t* root_lo;
     const int32_t* root_hi;
@@ -149,7 +151,30 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
             const double* PTe = a.PT + (size_t)a.ep->node_key[op.child[ch]] * a.KP * a.LD + row_lo;
             const bool errleaf = (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.leafcol[ch]];
             cafe_d4 fac[NFT_W][NRT_W];
-            if (op.kind[ch] == 0 && !errleaf) {
+            if (errleaf && a.err_banded) {
+                // banded error model (as read from a model file, cafe/error_model.cpp:162-189): the leaf
+                // vector has a handful of non-zeros around the observed count, so the edge product is a
+                // short sum of column gathers, k ascending, instead of a GEMM
+#pragma unroll
+                for (int i = 0; i < NFT_W; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = (ft0 + i) * 16 + lk + 4 * r;
+                        const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
+                        const int klo = max(cnt + a.err_dlo, 0);
+                        const int khi = min(min(cnt + a.err_dhi, a.C - 1), s_colmax[f]);
+                        const double* erow = a.err + (size_t)cnt * a.err_ld;
+#pragma unroll
+                        for (int j = 0; j < NRT_W; ++j) {
+                            double v = 0.0;
+                            if (j < ntile)
+                                for (int k = klo; k <= khi; ++k)
+                                    v += erow[k] * PTe[(size_t)k * a.LD + (rt0 + j) * 16 + li];
+                            fac[i][j][r] = v;
+                        }
+                    }
+                }
+            } else if (op.kind[ch] == 0 && !errleaf) {
                 // one-hot leaf: factor = PT[count][row]  (cafe/cafe_tree.c:208-209)
 #pragma unroll
                 for (int i = 0; i < NFT_W; ++i) {

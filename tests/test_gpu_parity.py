@@ -252,9 +252,22 @@ def test_error_model_leaves(eng):
     lam = np.full(t.n_nodes, 0.002)
     mu = np.full(t.n_nodes, -1.0)
     try:
+        # banded model -> short gather sums; the same model forced through the dense GEMM path; a dense
+        # (epsilon-filled, as `esterror` builds, cafe/cafe_shell.c:671-689) model
         check_families(eng, t, counts, rng, lam, mu, prior, errormatrix=E, err_mfs=mfs, leaf_has_err=has,
                        nthreads=os.cpu_count() or 1)
+        os.environ["CAFEHIP_ERRBAND"] = "0"
+        eng.set_error_model(E, has)
+        check_families(eng, t, counts, rng, lam, mu, prior, errormatrix=E, err_mfs=mfs, leaf_has_err=has,
+                       nthreads=os.cpu_count() or 1)
+        os.environ.pop("CAFEHIP_ERRBAND")
+        Ed = E + 1e-6
+        Ed /= Ed.sum(axis=0, keepdims=True)
+        eng.set_error_model(Ed, has)
+        check_families(eng, t, counts, rng, lam, mu, prior, errormatrix=Ed, err_mfs=mfs, leaf_has_err=has,
+                       nthreads=os.cpu_count() or 1)
     finally:
+        os.environ.pop("CAFEHIP_ERRBAND", None)
         eng.set_error_model(None)
 
 
