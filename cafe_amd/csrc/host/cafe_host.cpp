@@ -802,11 +802,48 @@ struct cafehost_session {
     }
 
     // ---- commands ----------------------------------------------------------------------
+    // cafe_family_filter, cafe/gene_family.cpp:273-353: keep a family only when BOTH subtrees below the
+    // root hold at least one gene (parsimony: at least one copy at the root); ranges follow the new maximum
+    void family_filter()
+    {
+        const int ns = (int)fam.species.size();
+        const int F = fam.F();
+        std::vector<char> mark(tree.n);
+        std::vector<std::string> ids, desc;
+        std::vector<int32_t> counts;
+        int mx = 0;
+        for (int i = 0; i < F; ++i) {
+            std::fill(mark.begin(), mark.end(), 0);
+            for (int s_ = 0; s_ < ns; ++s_) {
+                if (species_index[s_] < 0 || fam.counts[(size_t)i * ns + s_] <= 0) continue;
+                for (int p = species_index[s_]; p >= 0 && !mark[p]; p = tree.parent[p]) mark[p] = 1;
+            }
+            if (mark[tree.left[tree.root]] && mark[tree.right[tree.root]]) {
+                ids.push_back(fam.ids[i]);
+                desc.push_back(fam.desc[i]);
+                counts.insert(counts.end(), fam.counts.begin() + (size_t)i * ns, fam.counts.begin() + (size_t)(i + 1) * ns);
+                for (int s_ = 0; s_ < ns; ++s_) mx = std::max(mx, (int)fam.counts[(size_t)i * ns + s_]);
+            }
+        }
+        if ((int)ids.size() != F) {
+            log("The Number of families : %d ==> %d\n", F, (int)ids.size());
+            fam.ids.swap(ids);
+            fam.desc.swap(desc);
+            fam.counts.swap(counts);
+        }
+        if (fam.max_size != mx) {
+            fam.max_size = mx;
+            range = init_family_size(mx);
+        }
+        device_families_current = false;
+    }
+
     int cmd_load(const std::vector<std::string>& tokens)
     {  // cafe_cmd_load, cafe/cafe_commands.cpp:868-970; args :817-866
         auto args = build_argument_list(tokens);
         std::string file;
         int max_size = -1;
+        bool filter = false;
         for (auto& a : args) {
             if (a.opt == "-t" && !a.argv.empty()) num_threads = atoi(a.argv[0].c_str());
             if (a.opt == "-r" && !a.argv.empty()) num_random_samples = atoi(a.argv[0].c_str());
@@ -822,7 +859,7 @@ struct cafehost_session {
                 own_log = true;
                 log_name = name;
             }
-            if (a.opt == "-filter") throw std::runtime_error("load -filter (parsimony root filter, cafe/gene_family.cpp:273-353) is outside this build's scope");
+            if (a.opt == "-filter") filter = true;
             if (a.opt == "-i") {
                 for (size_t i = 0; i < a.argv.size(); ++i) file += (i ? " " : "") + a.argv[i];
             }
@@ -835,6 +872,11 @@ struct cafehost_session {
         err_mfs = -1;
         range = init_family_size(fam.max_size);  // set_range_from_family
         sync_species_index();
+        if (filter && !have_tree) {
+            fprintf(stderr, "Error(load): You did not specify tree. Skip filtering\n");
+        } else if (filter) {
+            family_filter();
+        }
         device_families_current = false;
         // log_param_values, cafe/cafe_commands.cpp:1918-1943
         log("-----------------------------------------------------------\n");

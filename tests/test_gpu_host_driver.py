@@ -262,3 +262,22 @@ def test_errormodel_command_matches_oracle(shell, model, sp):
     shell.dispatch("noerrormodel")
     shell.dispatch("lambda -l 0.0017 -score")
     assert abs(shell.score + so) > 1e-3
+
+
+def test_load_filter_keeps_families_with_a_copy_at_the_root(shell, tmp_path):
+    # cafe_family_filter (cafe/gene_family.cpp:273-353): both subtrees below the root need >= 1 gene
+    path = tmp_path / "fam.tab"
+    path.write_text("Desc\tID\tA\tB\tC\n"
+                    "x\tF1\t1\t0\t3\n"     # kept: (A,B) has A, C has 3
+                    "x\tF2\t0\t0\t40\n"    # dropped: nothing under (A,B)
+                    "x\tF3\t2\t2\t0\n"     # dropped: C empty
+                    "x\tF4\t0\t5\t1\n")    # kept
+    shell.dispatch("tree ((A:10,B:10):5,C:15)")
+    shell.dispatch("load -i %s -filter" % path)
+    shell.dispatch("lambda -l 0.01 -score")
+    t = O.PyTree("((A:10,B:10):5,C:15)")
+    counts = np.array([[1, 0, 3], [0, 5, 1]], np.int32)
+    rng = O.range_from_max(5)   # the range follows the maximum of the KEPT rows (5, not 40)
+    prior = O.prior_poisson(1000, rng.root_min, shell.poisson_lambda)
+    so, *_ = O.eval_posterior(t, counts, rng, np.full(t.n_nodes, 0.01), np.full(t.n_nodes, -1.0), prior)
+    assert shell.score == pytest.approx(-so, rel=1e-12)
