@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the lambda-search wall-clock leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for debugging)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: take the multi-rank code path (process group + packed all_gather) even with 1 rank")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: all ranks share GPU 0 (functional check of the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
@@ -65,8 +67,12 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -113,7 +119,7 @@ def main():
 
     def one_step(step):
         nl, nm = node_rates(step)
-        if world == 1:
+        if not multi:
             score, fz = eng.get_posterior(nl, nm, prior)
             kernel_ms.append(eng.last_kernel_ms())
             return score
@@ -123,7 +129,7 @@ def main():
         return score
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -137,7 +143,7 @@ def main():
         last = one_step(args.warmup + s)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -222,7 +228,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
