@@ -1339,9 +1339,9 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
     c->KP = ((c->S + 3) / 4) * 4;
     c->LD = ((c->S + 15) / 16) * 16 + 16;  // room for the root row offset + a 16-row tile overrun
     {
-        // node-vector stride: >= max(C, R) rounded to even, congruent 2 mod 32 (conflict-free
-        // 16-family x 2-k LDS reads)
-        const int need = ((std::max(c->C, c->R) + 1) / 2) * 2;
+        // node-vector stride: the MFMA kernel stores whole 16-row tiles, so it must cover
+        // roundup16(max(C, R)); congruent 2 mod 32 (conflict-free 16-family x 2-k LDS reads)
+        const int need = ((std::max(c->C, c->R) + 15) / 16) * 16;
         c->LDv = 32 * ((std::max(need - 2, 0) + 31) / 32) + 2;
     }
     c->n_chunks = (F + CAFEHIP_CHUNK - 1) / CAFEHIP_CHUNK;

@@ -1,0 +1,101 @@
+"""Randomised shapes: tree topology (balanced / caterpillar / random joins, 3..64 taxa), range
+extents (tiny, ragged, R > C, root_min = 0), rate models (single lambda, per-node lambda, lambda/mu),
+both K2 kernels (MFMA and the row-per-thread fallback) -- every family against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _orc as O
+
+pytestmark = pytest.mark.gpu
+
+
+def random_newick(rs, n, shape):
+    names = ["s%d" % i for i in range(n)]
+    if shape == "caterpillar":
+        cur = names[0] + ":%d" % rs.randint(1, 30)
+        for i in range(1, n):
+            cur = "(%s,%s:%d)" % (cur, names[i], rs.randint(1, 30))
+            if i < n - 1:
+                cur += ":%d" % rs.randint(1, 30)
+        return cur
+    nodes = [nm + ":%d" % rs.randint(1, 40) for nm in names]
+    while len(nodes) > 1:
+        if shape == "balanced":
+            nxt = []
+            for i in range(0, len(nodes) - 1, 2):
+                nxt.append("(%s,%s):%d" % (nodes[i], nodes[i + 1], rs.randint(1, 40)))
+            if len(nodes) % 2:
+                nxt.append(nodes[-1])
+            nodes = nxt
+        else:
+            i, j = sorted(rs.choice(len(nodes), 2, replace=False))
+            a, b = nodes[i], nodes[j]
+            nodes = [x for k, x in enumerate(nodes) if k not in (i, j)] + ["(%s,%s):%d" % (a, b, rs.randint(1, 40))]
+    s = nodes[0]
+    return s[:s.rindex(":")]  # the root has no branch
+
+
+CASES = [
+    # n_taxa, shape, range(min,max,root_min,root_max), F, model
+    (3, "random", (0, 7, 0, 7), 5, "lambda"),
+    (4, "balanced", (0, 12, 1, 9), 33, "lambdamu"),
+    (8, "balanced", (0, 37, 1, 30), 70, "pernode"),
+    (13, "caterpillar", (0, 55, 1, 30), 40, "lambda"),
+    (16, "balanced", (0, 63, 1, 40), 50, "lambdamu"),
+    (21, "random", (0, 70, 1, 30), 64, "pernode"),
+    (32, "balanced", (0, 48, 1, 30), 24, "lambda"),
+    (40, "random", (0, 90, 2, 60), 40, "lambdamu"),
+    (64, "balanced", (0, 58, 1, 30), 20, "pernode"),
+    (64, "random", (0, 70, 1, 30), 36, "lambda"),
+    (6, "random", (0, 40, 1, 75), 30, "lambda"),       # R > C
+    (10, "caterpillar", (0, 129, 1, 100), 18, "lambdamu"),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("kernel", ["mfma", "v1"])
+def test_random_shapes(case, kernel):
+    import cafe_amd
+    n, shape, (mn, mx, rmin, rmax), F, model = CASES[case]
+    rs = np.random.RandomState(100 + case)
+    nw = random_newick(rs, n, shape)
+    t = O.PyTree(nw)
+    assert t.n_leaves == n
+    top = min(mx - 1, 25)
+    counts = rs.poisson(3, size=(F, n)).clip(0, top).astype(np.int32)
+    counts[0] = 0
+    counts[-1] = top
+    rng = O.make_range(mn, mx, rmin, rmax)
+    prior = O.prior_poisson(1000, max(rmin, 1), 3.0)
+    base = 0.4 / max(t.branchlength.max(), 1)
+    if model == "lambda":
+        lam = np.full(t.n_nodes, base)
+        mu = np.full(t.n_nodes, -1.0)
+    elif model == "lambdamu":
+        lam = np.full(t.n_nodes, base)
+        mu = np.full(t.n_nodes, base * 0.6)
+    else:
+        lam = base * (0.5 + rs.rand(t.n_nodes))
+        mu = np.where(rs.rand(t.n_nodes) < 0.5, -1.0, base * 0.7)
+        mu = np.full(t.n_nodes, -1.0) if rs.rand() < 0.5 else np.abs(mu)
+    os.environ["CAFEHIP_K2"] = kernel
+    eng = cafe_amd.Engine(0)
+    try:
+        eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+        eng.set_families(counts, cafe_amd.FamilySizeRange(mn, mx, rmin, rmax))
+        sg, fzg, mlg, amg, mpg = eng.get_posterior(lam, mu, prior, per_family=True)
+        desc = eng.describe()
+    finally:
+        os.environ.pop("CAFEHIP_K2", None)
+        eng.close()
+    assert ("k2:" + kernel) in desc
+    so, fzo, mlo, amo, mpo = O.eval_posterior(t, counts, rng, lam, mu, prior, nthreads=os.cpu_count() or 1)
+    assert fzg == fzo
+    nz = mlo > 0
+    assert np.array_equal(mlg == 0, mlo == 0)
+    assert np.max(np.abs(mlg[nz] - mlo[nz]) / mlo[nz], initial=0) < 1e-9, desc
+    assert np.max(np.abs(mpg[nz] - mpo[nz]) / mpo[nz], initial=0) < 1e-9, desc
+    ties_ok = amg == amo
+    assert np.all(ties_ok | ~nz), desc
