@@ -121,34 +121,21 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
                                                          const double* __restrict__ lncA,
                                                          const double* __restrict__ lncB,
                                                          int ld_lnc, double* __restrict__ PT,
-                                                         int M, int LD, int KP, int32_t* first_zero)
+                                                         int M, int LD, int KP, int32_t* first_zero,
+                                                         int keys_per_block)
 {
     extern __shared__ double k1_smem[];
-    const int key = blockIdx.z;
-    // first kernel of an evaluation: reset the first-zero-family slot K3 will atomicMin into
-    if (first_zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *first_zero = INT32_MAX;
     const int s0 = blockIdx.y * 16;
     const int c0 = blockIdx.x * 16;
     const int tx = threadIdx.x & 15;  // s within tile
     const int ty = threadIdx.x >> 4;  // c within tile
     const int s = s0 + tx;
     const int c = c0 + ty;
-    const KeyParam kp = ep->keys[key];
-    double* P = PT + (size_t)key * KP * LD;
+    // first kernel of an evaluation: reset the first-zero-family slot K3 will atomicMin into
+    if (first_zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *first_zero = INT32_MAX;
 
-    if (kp.mode < 2) {
-        // zero / identity matrices; row 0 is e_0 in every mode (libtree/birthdeath.c:244, :212-215)
-        if (s <= M && c <= M) {
-            double v = 0.0;
-            if (s == 0)
-                v = (c == 0) ? 1.0 : 0.0;
-            else if (kp.mode == 1)
-                v = (s == c) ? 1.0 : 0.0;
-            P[(size_t)c * LD + s] = v;
-        }
-        return;
-    }
-    // stage lnC runs: A needs j <= min(s, c) <= min(s0, c0) + 15; B needs i = c - j <= c0 + 15
+    // The table runs of this (s, c) tile do not depend on the key: stage them ONCE and build the tile
+    // for keys_per_block keys.  A needs j <= min(s, c) <= min(s0, c0) + 15; B needs i = c - j <= c0 + 15.
     const double* a;
     const double* b;
     if (USE_LDS) {
@@ -156,13 +143,31 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
         const int nB = min(c0 + 16, M + 1);
         double* sA = k1_smem;                        // [16][ld_lnc]
         double* sB = k1_smem + 16 * (size_t)ld_lnc;  // [16][ld_lnc]
-        for (int r = 0; r < 16; ++r) {
-            const int sr = s0 + r;
-            if (sr > M) break;
+        // thread (r = tid / 16, l = tid % 16) copies row s0 + r, columns l, l+16, ...: 128-byte runs,
+        // eight loads in flight per thread before the first LDS store (the copy is latency-bound)
+        {
+            const int r = threadIdx.x >> 4, l = threadIdx.x & 15;
+            const int sr = min(s0 + r, M);
             const double* ga = lncA + (size_t)sr * ld_lnc;
             const double* gb = lncB + (size_t)sr * ld_lnc;
-            for (int i = threadIdx.x; i < nA; i += 256) sA[r * ld_lnc + i] = ga[i];
-            for (int i = threadIdx.x; i < nB; i += 256) sB[r * ld_lnc + i] = gb[i];
+            double* da = sA + r * ld_lnc;
+            double* db = sB + r * ld_lnc;
+            for (int i0 = l; i0 < nA; i0 += 128) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (i0 + 16 * u < nA) ? ga[i0 + 16 * u] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + 16 * u < nA) da[i0 + 16 * u] = v[u];
+            }
+            for (int i0 = l; i0 < nB; i0 += 128) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (i0 + 16 * u < nB) ? gb[i0 + 16 * u] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + 16 * u < nB) db[i0 + 16 * u] = v[u];
+            }
         }
         __syncthreads();
         a = sA + tx * ld_lnc;
@@ -172,55 +177,60 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
         b = lncB + (size_t)min(s, M) * ld_lnc;
     }
     if (s > M || c > M) return;
-    double p;
-    if (s == 0) {
-        p = (c == 0) ? 1.0 : 0.0;
-    } else {
-        const int m = min(s, c);
-        p = 0.0;
-        // terms are accumulated strictly in j order (the reference's order); the loads of the next
-        // terms are independent of the running sum, so unrolling lets them overlap the exp chain
-        if (PRODUCT_FORM && kp.fast_ok) {
-            // Same sum with the exponentials factored: a/b hold exp(ln C) (binomials through the
-            // reference's Lanczos lgamma), the power part alpha^(..) coeff^j is a geometric sequence kept
-            // as mantissa in [1,2) x 2^e so that nothing under/overflows before the final ldexp.  One exp2
-            // per ENTRY instead of one exp per TERM; deviation from the per-term form <~ 5e-13 relative,
-            // the size of the rounding the reference itself commits when it forms t.
-            const double y0 = (kp.mode == 2) ? (double)(s + c) * kp.l2a : (double)s * kp.l2a + (double)c * kp.l2b;
-            const double e0 = floor(y0);
-            double gm = exp2(y0 - e0);
-            int e = (int)e0;
+    const int m = min(s, c);
+    const int key_end = min(ep->nkeys, (int)(blockIdx.z + 1) * keys_per_block);
+    for (int key = blockIdx.z * keys_per_block; key < key_end; ++key) {
+        const KeyParam kp = ep->keys[key];
+        double p;
+        if (s == 0) {
+            p = (c == 0) ? 1.0 : 0.0;  // row 0 is e_0 in every mode (libtree/birthdeath.c:244, :212-215)
+        } else if (kp.mode < 2) {
+            p = (kp.mode == 1 && s == c) ? 1.0 : 0.0;  // zero / identity matrices
+        } else {
+            p = 0.0;
+            // terms are accumulated strictly in j order (the reference's order)
+            if (PRODUCT_FORM && kp.fast_ok) {
+                // Same sum with the exponentials factored: a/b hold exp(ln C) (binomials through the
+                // reference's Lanczos lgamma), the power part alpha^(..) coeff^j is a geometric sequence
+                // kept as mantissa in [1,2) x 2^e so that nothing under/overflows before the final ldexp.
+                // One exp2 per ENTRY instead of one exp per TERM; deviation from the per-term form
+                // <~ 5e-13 relative, the size of the rounding the reference itself commits forming t.
+                const double y0 = (kp.mode == 2) ? (double)(s + c) * kp.l2a : (double)s * kp.l2a + (double)c * kp.l2b;
+                const double e0 = floor(y0);
+                double gm = exp2(y0 - e0);
+                int e = (int)e0;
 #pragma unroll 4
-            for (int j = 0; j <= m; ++j) {
-                const double term = a[j] * b[c - j] * gm;
-                p += ldexp(term, e);
-                gm *= kp.rho_m;
-                e += kp.rho_e;
-                if (gm >= 2.0) {
-                    gm *= 0.5;
-                    e += 1;
+                for (int j = 0; j <= m; ++j) {
+                    const double term = a[j] * b[c - j] * gm;
+                    p += ldexp(term, e);
+                    gm *= kp.rho_m;
+                    e += kp.rho_e;
+                    if (gm >= 2.0) {
+                        gm *= 0.5;
+                        e += 1;
+                    }
+                }
+            } else if (kp.mode == 2) {
+                double lastterm = 1.0;
+                const int s_add_c = s + c;
+#pragma unroll 4
+                for (int j = 0; j <= m; ++j) {
+                    const double t = a[j] + b[c - j] + (double)(s_add_c - 2 * j) * kp.log_alpha;
+                    p += exp(t) * lastterm;
+                    lastterm *= kp.coeff;
+                }
+            } else {
+#pragma unroll 4
+                for (int j = 0; j <= m; ++j) {
+                    const double t = a[j] + b[c - j] + (double)(s - j) * kp.log_alpha +
+                                     (double)(c - j) * kp.log_beta + (double)j * kp.log_coeff;
+                    p += exp(t);
                 }
             }
-        } else if (kp.mode == 2) {
-            double lastterm = 1.0;
-            const int s_add_c = s + c;
-#pragma unroll 4
-            for (int j = 0; j <= m; ++j) {
-                const double t = a[j] + b[c - j] + (double)(s_add_c - 2 * j) * kp.log_alpha;
-                p += exp(t) * lastterm;
-                lastterm *= kp.coeff;
-            }
-        } else {
-#pragma unroll 4
-            for (int j = 0; j <= m; ++j) {
-                const double t = a[j] + b[c - j] + (double)(s - j) * kp.log_alpha +
-                                 (double)(c - j) * kp.log_beta + (double)j * kp.log_coeff;
-                p += exp(t);
-            }
+            p = fmax(fmin(p, 1.0), 0.0);  // MAX(MIN(p,1),0)
         }
-        p = fmax(fmin(p, 1.0), 0.0);  // MAX(MIN(p,1),0)
+        PT[(size_t)key * KP * LD + (size_t)c * LD + s] = p;
     }
-    P[(size_t)c * LD + s] = p;
 }
 #pragma clang fp contract(fast)
 
@@ -632,6 +642,7 @@ struct cafehip_ctx {
     double *d_lncA = nullptr, *d_lncB = nullptr;
     double *d_expA = nullptr, *d_expB = nullptr;
     bool all_keys_fast = false, k1_product_form = false;
+    size_t k1_lds_attr = 0;
     double* d_PT = nullptr;
     size_t pt_keys_cap = 0;
 
@@ -757,10 +768,23 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
 int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr)
 {
     if (c->nkeys == 0) return 0;
-    dim3 grid((c->S + 15) / 16, (c->S + 15) / 16, c->nkeys);
+    // table rows are staged once per workgroup and reused for keys_per_block keys; keep >= ~3 workgroups
+    // per CU in flight
+    const int tiles = ((c->S + 15) / 16) * ((c->S + 15) / 16);
+    int kpb = 1;  // measured: more keys per block only lengthens the heavy tiles (tools/sweep_k1.py)
+    (void)tiles;
+    if (const char* e = getenv("CAFEHIP_K1KPB")) kpb = std::max(1, atoi(e));
+    dim3 grid((c->S + 15) / 16, (c->S + 15) / 16, (c->nkeys + kpb - 1) / kpb);
     size_t lds = 2 * 16 * (size_t)c->lnc.ld * sizeof(double);
-    const int use_lds = lds <= 60 * 1024;  // bigger tables are read through L1/L2 instead
+    const int use_lds = lds <= 150 * 1024;  // bigger tables are read through L1/L2 instead
     if (!use_lds) lds = 0;
+    if (lds > 48 * 1024 && lds > c->k1_lds_attr) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_build_matrices<true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_build_matrices<true, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->k1_lds_attr = lds;
+    }
     const char* k1env = getenv("CAFEHIP_K1");
     const bool product = c->lnc.product_form_ok && c->all_keys_fast && !(k1env && strcmp(k1env, "exact") == 0);
     c->k1_product_form = product;
@@ -768,16 +792,16 @@ int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr)
         // every key of this evaluation qualifies: the staged tables are exp(ln C)
         if (use_lds)
             hipLaunchKernelGGL((k1_build_matrices<true, true>), grid, dim3(256), lds, c->stream, c->d_params,
-                               c->d_expA, c->d_expB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero);
+                               c->d_expA, c->d_expB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb);
         else
             hipLaunchKernelGGL((k1_build_matrices<false, true>), grid, dim3(256), 0, c->stream, c->d_params,
-                               c->d_expA, c->d_expB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero);
+                               c->d_expA, c->d_expB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb);
     } else if (use_lds) {
         hipLaunchKernelGGL((k1_build_matrices<true, false>), grid, dim3(256), lds, c->stream, c->d_params,
-                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero);
+                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb);
     } else {
         hipLaunchKernelGGL((k1_build_matrices<false, false>), grid, dim3(256), 0, c->stream, c->d_params,
-                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero);
+                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb);
     }
     HIP_TRY(hipGetLastError());
     c->have_matrices = true;
