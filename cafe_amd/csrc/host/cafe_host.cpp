@@ -624,13 +624,19 @@ struct cafehost_session {
         pfm.init(1);
         pfm.tolx = 1e-6;
         pfm.tolf = 1e-6;
+        int max_x = 0;
+        for (int x : leaf_sizes) max_x = std::max(max_x, x);
+        std::vector<double> term(max_x + 1);
         pfm.eq = [&](const double* pl) {  // __lnLPoisson :771-787
-            double score = 0;
-            for (int x : leaf_sizes) {
+            // log(poisspdf(x, lambda)) is a pure function of x: evaluate it once per distinct size, then
+            // add the per-leaf terms in the reference's order -- the same doubles, summed the same way
+            for (int x = 0; x <= max_x; ++x) {
                 double ll = poisspdf(x, pl[0]);
                 if (std::isnan(ll)) ll = 0;
-                score += std::log(ll);
+                term[x] = std::log(ll);
             }
+            double score = 0;
+            for (int x : leaf_sizes) score += term[x];
             return -score;
         };
         double start = unifrnd();
