@@ -623,6 +623,7 @@ struct cafehip_ctx {
     int n_vit_tables = 0;
     int k2_cfg[4] = {0, 0, 0, 0};  // NFT_W, NRT_W, Wf, Wr of the last MFMA launch
     bool k2_used_mfma = false;
+    bool k2_shape4 = false;
 
     // families
     int F = 0, Fu = 0, n_leaves = 0;
@@ -894,10 +895,42 @@ size_t mfma_lds_bytes(const cafehip_ctx* c, int nf)
     return (size_t)nf * c->LDv * sizeof(double) + (size_t)nf * c->n_leaves * 4 + (size_t)nf * 4;
 }
 
-// Pick the wave grid: minimise (rounds of waves over the SIMDs) x (tiles per wave), then
-// prefer fewer, larger workgroups (less matrix re-streaming).  CAFEHIP_K2CFG="nftw,nrtw,wf,wr"
-// overrides (tuning sweeps).
-bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out)
+// Cost model fitted to sweeps on MI355X (tools/sweep_k2.py): every workgroup is resident at once,
+// block b lands on CU b % n_cu, its waves go to consecutive SIMDs from a rotating start; the kernel takes
+// as long as the busiest SIMD, times a per-wave-count factor (1-2 waves hide less latency, 8 waves pay
+// wider barriers), a matrix re-streaming term and an intra-workgroup imbalance term (waves meet at
+// barriers: 3,3,2,2 row tiles is 16 % slower than 5,5,5,5 on the cfg4 shape).  `groups` = 4-family groups
+// per wave (4 per 16-family tile), so both MFMA shapes are priced in the same unit.
+double k2_cost(const cafehip_ctx* c, int n_items, int nf, int groups, int wf, int wr, int RTc)
+{
+    const int n_cu = std::max(c->n_cu, 1);
+    const int W = wf * wr;
+    const long n_wg = (n_items + nf - 1) / nf;
+    const int wg_on_cu = (int)((n_wg + n_cu - 1) / n_cu);  // busiest CU
+    // accumulator-tile steps the busiest CU issues per k-step, spread over its 4 SIMDs (where the waves of
+    // several resident workgroups land is not under our control; the intra-workgroup term below prices the
+    // uneven deals)
+    double per_wg = 0;
+    int active_waves = 0;
+    for (int w = 0; w < W; ++w) {
+        const int wrow = w / wf;
+        const int act = RTc / wr + (wrow < RTc % wr ? 1 : 0);  // even deal of the row tiles
+        per_wg += act * groups;
+        active_waves += act > 0;
+    }
+    const double simds = std::min(4, std::max(1, wg_on_cu * active_waves));  // a lone 2-wave workgroup uses 2 SIMDs
+    const double maxload = wg_on_cu * per_wg / simds;
+    static const double wpen[9] = {0, 1.25, 1.09, 1.05, 1.0, 1.1, 1.2, 1.25, 1.3};
+    double cost = maxload * wpen[W];
+    cost *= 1.0 + 0.002 * (n_wg * wf) / (double)n_cu;
+    const int hi_t = RTc / wr + (RTc % wr ? 1 : 0);
+    const double mean_t = (double)RTc / wr;
+    cost *= 1.0 + 0.8 * (hi_t / mean_t - 1.0);
+    return cost;
+}
+
+// 16x16x4 shape: NF = 16 * nft_w * wf.  CAFEHIP_K2CFG="nftw,nrtw,wf,wr" overrides (tuning sweeps).
+bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_cost)
 {
     const int RT = (std::max(c->C, c->R) + 15) / 16;
     const int RTc = (c->C + 15) / 16;
@@ -907,14 +940,10 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out)
             k.nrt_w >= 1 && k.nrt_w <= 7 && k.nft_w * k.nrt_w <= 8 && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 && k.wr * k.nrt_w >= RT &&
             mfma_lds_bytes(c, 16 * k.nft_w * k.wf) <= (size_t)c->lds_limit) {
             *out = k;
+            *out_cost = 0;
             return true;
         }
     }
-    // Cost model fitted to sweeps on MI355X (tools/sweep_k2.py): every workgroup is resident at
-    // once, block b lands on CU b % n_cu, its waves go to consecutive SIMDs from a rotating start;
-    // the kernel takes as long as the busiest SIMD (in accumulator tiles per k-step), times a
-    // per-wave-count factor (1-2 waves hide less latency, 8 waves pay wider barriers).
-    const int n_cu = std::max(c->n_cu, 1);
     double best = 1e300;
     bool found = false;
     for (int wr = 1; wr <= 8; wr *= 2) {
@@ -925,27 +954,7 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out)
             for (int wf = 1; wf * wr <= 8; wf *= 2) {
                 const int nf = 16 * nft_w * wf;
                 if (mfma_lds_bytes(c, nf) > (size_t)c->lds_limit) continue;
-                const int W = wf * wr;
-                const long n_wg = (n_items + nf - 1) / nf;
-                const int wg_on_cu = (int)((n_wg + n_cu - 1) / n_cu);  // busiest CU
-                int load[4] = {0, 0, 0, 0};
-                for (int g = 0; g < wg_on_cu; ++g)
-                    for (int w = 0; w < W; ++w) {
-                        const int wrow = w / wf;
-                        const int act = RTc / wr + (wrow < RTc % wr ? 1 : 0);  // even deal of the row tiles
-                        load[(g + w) & 3] += act * nft_w;
-                    }
-                const int maxload = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));
-                static const double wpen[9] = {0, 1.25, 1.09, 1.05, 1.0, 1.1, 1.2, 1.25, 1.3};
-                double cost = maxload * wpen[W];
-                cost *= 1.0 + 0.002 * (n_wg * wf) / (double)n_cu;  // matrix re-streaming
-                {
-                    // waves of one workgroup meet at barriers: an uneven deal of the row tiles stalls
-                    // the light waves (cfg4 shape: 3,3,2,2 tiles is 16 % slower than 5,5,5,5)
-                    const int hi_t = RTc / wr + (RTc % wr ? 1 : 0);
-                    const double mean_t = (double)RTc / wr;
-                    cost *= 1.0 + 0.8 * (hi_t / mean_t - 1.0);
-                }
+                const double cost = k2_cost(c, n_items, nf, 4 * nft_w, wf, wr, RTc);
                 if (cost < best) {
                     best = cost;
                     *out = K2Cfg{nft_w, nrt_w, wf, wr};
@@ -954,20 +963,115 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out)
             }
         }
     }
+    *out_cost = best;
     return found;
+}
+
+// 4x4x4_4b shape: NF = 4 * G * wf (K2Cfg.nft_w carries G).  CAFEHIP_K2CFG4="G,nrtw,wf,wr" overrides.
+constexpr int kMaxGroupTiles = 24;  // G * NRT_W accumulators per wave (register budget)
+bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_cost)
+{
+    const int RT = (std::max(c->C, c->R) + 15) / 16;
+    const int RTc = (c->C + 15) / 16;
+    if (const char* e = getenv("CAFEHIP_K2CFG4")) {
+        K2Cfg k;
+        if (sscanf(e, "%d,%d,%d,%d", &k.nft_w, &k.nrt_w, &k.wf, &k.wr) == 4 && k.nft_w >= 1 && k.nft_w <= 8 &&
+            k.nrt_w >= 1 && k.nrt_w <= 7 && k.nft_w * k.nrt_w <= kMaxGroupTiles && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 &&
+            k.wr * k.nrt_w >= RT && mfma_lds_bytes(c, 4 * k.nft_w * k.wf) <= (size_t)c->lds_limit) {
+            *out = k;
+            *out_cost = 0;
+            return true;
+        }
+    }
+    double best = 1e300;
+    bool found = false;
+    for (int wr = 1; wr <= 8; wr *= 2) {
+        const int nrt_w = (RT + wr - 1) / wr;
+        if (nrt_w > 7) continue;
+        for (int G = 1; G <= 8; ++G) {
+            if (G * nrt_w > kMaxGroupTiles) continue;
+            for (int wf = 1; wf * wr <= 8 && wf <= 2; wf *= 2) {
+                const int nf = 4 * G * wf;
+                if (mfma_lds_bytes(c, nf) > (size_t)c->lds_limit) continue;
+                // measured: per flop this shape runs ~7 % behind the 16x16x4 one inside the kernel, and
+                // few groups per wave amortise the B-operand loads badly (G = 1: 2x, G = 2: 1.2x)
+                const double cost = 1.07 * (1.0 + 0.9 / (G * G)) * k2_cost(c, n_items, nf, G, wf, wr, RTc);
+                if (cost < best) {
+                    best = cost;
+                    *out = K2Cfg{G, nrt_w, wf, wr};
+                    found = true;
+                }
+            }
+        }
+    }
+    *out_cost = best;
+    return found;
+}
+
+template <int G, int NRT_W>
+int launch_mfma4_inst(cafehip_ctx* c, const K2MfmaArgs& a, int grid, int block, size_t lds)
+{
+    static size_t attr_bytes = 0;
+    if (lds > 64 * 1024 && lds > attr_bytes) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_prune_mfma4<G, NRT_W>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    hipLaunchKernelGGL((k2_prune_mfma4<G, NRT_W>), dim3(grid), dim3(block), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int G>
+int launch_mfma4_nrt(cafehip_ctx* c, const K2MfmaArgs& a, int nrt_w, int grid, int block, size_t lds)
+{
+    // only the (G, NRT_W) pairs within the register budget are instantiated
+#define CAFE_M4(N)                                                              \
+    case N:                                                                     \
+        if constexpr (G * N <= kMaxGroupTiles)                                  \
+            return launch_mfma4_inst<G, N>(c, a, grid, block, lds);             \
+        break;
+    switch (nrt_w) {
+        CAFE_M4(1) CAFE_M4(2) CAFE_M4(3) CAFE_M4(4) CAFE_M4(5) CAFE_M4(6) CAFE_M4(7)
+    }
+#undef CAFE_M4
+    return fail("unsupported 4x4 wave grid G=%d NRT_W=%d", G, nrt_w);
+}
+
+int launch_mfma4_g(cafehip_ctx* c, const K2MfmaArgs& a, int G, int nrt_w, int grid, int block, size_t lds)
+{
+    switch (G) {
+        case 1: return launch_mfma4_nrt<1>(c, a, nrt_w, grid, block, lds);
+        case 2: return launch_mfma4_nrt<2>(c, a, nrt_w, grid, block, lds);
+        case 3: return launch_mfma4_nrt<3>(c, a, nrt_w, grid, block, lds);
+        case 4: return launch_mfma4_nrt<4>(c, a, nrt_w, grid, block, lds);
+        case 5: return launch_mfma4_nrt<5>(c, a, nrt_w, grid, block, lds);
+        case 6: return launch_mfma4_nrt<6>(c, a, nrt_w, grid, block, lds);
+        case 7: return launch_mfma4_nrt<7>(c, a, nrt_w, grid, block, lds);
+        case 8: return launch_mfma4_nrt<8>(c, a, nrt_w, grid, block, lds);
+    }
+    return fail("unsupported G %d", G);
 }
 
 int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
 {
     if (n_items <= 0) return 0;
-    K2Cfg k;
-    if (!choose_mfma_cfg(c, n_items, &k)) {
+    K2Cfg k16{}, k4{};
+    double cost16 = 1e300, cost4 = 1e300;
+    const char* shape_env = getenv("CAFEHIP_MFMA");
+    const bool allow16 = !(shape_env && strcmp(shape_env, "4") == 0);
+    const bool allow4 = !(shape_env && strcmp(shape_env, "16") == 0);
+    const bool have16 = allow16 && choose_mfma_cfg(c, n_items, &k16, &cost16);
+    const bool have4 = allow4 && choose_mfma4_cfg(c, n_items, &k4, &cost4);
+    if (!have16 && !have4) {
         // matrices too large for the MFMA wave grids: the row-per-thread kernel handles them
         c->k2_used_mfma = false;
         K2Args a1 = v1;
         return launch_k2_v1(c, a1, n_items);
     }
-    const int nf = 16 * k.nft_w * k.wf;
+    const bool use4 = have4 && (!have16 || cost4 < cost16);
+    const K2Cfg k = use4 ? k4 : k16;
+    const int nf = use4 ? 4 * k.nft_w * k.wf : 16 * k.nft_w * k.wf;
     const int grid = (n_items + nf - 1) / nf;
     const int block = 64 * k.wf * k.wr;
     const size_t lds = mfma_lds_bytes(c, nf);
@@ -999,6 +1103,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     a.Wf = k.wf;
     a.Wr = k.wr;
     a.NF = nf;
+    a.shape4x4 = 0;
     a.park = c->d_park;
     a.n_parks = std::max(c->msched.n_parks, 1);
     a.err = v1.err;
@@ -1023,6 +1128,8 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     c->k2_block = block;
     c->k2_lds = lds;
     c->k2_used_mfma = true;
+    c->k2_shape4 = use4;
+    if (use4) return launch_mfma4_g(c, a, k.nft_w, k.nrt_w, grid, block, lds);
     if (k.nft_w == 1) return launch_mfma_nrt<1>(c, a, k.nrt_w, grid, block, lds);
     return launch_mfma_nrt<2>(c, a, k.nrt_w, grid, block, lds);
 }
@@ -1716,7 +1823,8 @@ const char* cafehip_describe(cafehip_ctx* c)
              "n_ops=%zu n_slots=%d n_parks=%d k1:%s k2:%s NF=%d block=%d lds=%zu cfg(nftw,nrtw,wf,wr)=%d,%d,%d,%d",
              c->device, c->n_cu, c->F, c->Fu, c->n_leaves, c->S, c->C, c->R, c->LD, c->KP, c->LDv,
              c->nkeys, c->sched.ops.size(), c->sched.n_slots, c->msched.n_parks,
-             c->k1_product_form ? "product" : "exact", c->k2_used_mfma ? "mfma" : "v1", c->k2_nf, c->k2_block, c->k2_lds, c->k2_cfg[0], c->k2_cfg[1],
+             c->k1_product_form ? "product" : "exact",
+             c->k2_used_mfma ? (c->k2_shape4 ? "mfma4x4(cfg=G,nrtw,wf,wr)" : "mfma") : "v1", c->k2_nf, c->k2_block, c->k2_lds, c->k2_cfg[0], c->k2_cfg[1],
              c->k2_cfg[2], c->k2_cfg[3]);
     c->desc = buf;
     return c->desc.c_str();

@@ -35,6 +35,7 @@ struct K2MfmaArgs {
     int ksteps;            // ceil(C / 4)
     int Wf, Wr;            // wave grid
     int NF;                // families per workgroup = 16 * Wf * NFT_W
+    int shape4x4;          // 1: v_mfma_f64_4x4x4_4b (default), 0: v_mfma_f64_16x16x4
     double* park;          // [grid][n_parks][NF][LDv]
     int n_parks;
     // error model
@@ -100,6 +101,70 @@ __device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const i
 #pragma unroll
             for (int j = 0; j < NRT_W; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// The same edge with v_mfma_f64_4x4x4_4b_f64 (4 independent 4x4x4 blocks per instruction).  Measured on
+// MI355X (tools/mfma_f64_4x4_probe.hip) it sustains 73.9 TFLOP/s against 47.7 for the 16x16x4 shape.
+// Mapping the 4 blocks to 4 groups of 4 rows makes its B operand IDENTICAL to the 16x16x4 one
+// (lane l: PT[k0 + (l>>4)][row0 + (l&15)]) and its result lane l = Y[fam0 + (l>>4)][row0 + (l&15)], i.e.
+// register r of the 16x16 accumulator when the A operand carries families fam0 + 4r + (l&3)
+// (lane l: L[fam0 + 4r + (l&3)][k0 + (l>>4)], broadcast over the blocks).  Four instructions with four
+// A registers and one shared B register therefore fill exactly the accumulator tile of one 16x16x4.
+template <int NFT_W, int NRT_W>
+__device__ __forceinline__ void mfma_edge_4x4(const double* __restrict__ bp, const int (&boff)[NRT_W],
+                                              size_t kstride, const double* ap4, int LDv, int ksteps,
+                                              cafe_d4 (&acc)[NFT_W][NRT_W])
+{
+    double a0[NFT_W][4], a1[NFT_W][4], b0[NRT_W], b1[NRT_W];
+#pragma unroll
+    for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a0[i][r] = ap4[(size_t)(i * 16 + 4 * r) * LDv];
+#pragma unroll
+    for (int j = 0; j < NRT_W; ++j) b0[j] = bp[boff[j]];
+    int ks = 0;
+    for (; ks + 2 <= ksteps; ks += 2) {
+        const double* bp1 = bp + (size_t)(ks + 1) * kstride;
+        const double* ap1 = ap4 + (ks + 1) * 4;
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1[i][r] = ap1[(size_t)(i * 16 + 4 * r) * LDv];
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j) b1[j] = bp1[boff[j]];
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+            for (int j = 0; j < NRT_W; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[i][r], b0[j], acc[i][j][r], 0, 0, 0);
+        const int kn = (ks + 2 < ksteps) ? ks + 2 : ksteps - 1;
+        const double* bp2 = bp + (size_t)kn * kstride;
+        const double* ap2 = ap4 + kn * 4;
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a0[i][r] = ap2[(size_t)(i * 16 + 4 * r) * LDv];
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j) b0[j] = bp2[boff[j]];
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+            for (int j = 0; j < NRT_W; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[i][r], b1[j], acc[i][j][r], 0, 0, 0);
+    }
+    if (ks < ksteps) {
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+            for (int j = 0; j < NRT_W; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[i][r], b0[j], acc[i][j][r], 0, 0, 0);
     }
 }
 
@@ -217,8 +282,13 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                     for (int j = 0; j < NRT_W; ++j)
                         boff[j] = ((j < ntile) ? (rt0 + j) : rt0) * 16;  // inactive tiles re-read tile rt0
                     const double* bp = PTe + (size_t)lk * a.LD + li;
-                    const double* ap = Lbuf + (size_t)(ft0 * 16 + li) * a.LDv + lk;
-                    mfma_edge<NFT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                    if (a.shape4x4) {
+                        const double* ap4 = Lbuf + (size_t)(ft0 * 16 + (lane & 3)) * a.LDv + lk;
+                        mfma_edge_4x4<NFT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
+                    } else {
+                        const double* ap = Lbuf + (size_t)(ft0 * 16 + li) * a.LDv + lk;
+                        mfma_edge<NFT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                    }
                 }
             }
             if (ch == 0) {
@@ -292,6 +362,233 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
             const int oi2 = __shfl_xor(bi, off);
             const double op2 = __shfl_xor(bestp, off);
             // first maximum wins (libcommon/mathfunc.c:9-24): larger value, then lower index
+            if (oi2 != INT_MAX && (bi == INT_MAX || ov > best || (ov == best && oi2 < bi))) {
+                best = ov;
+                bi = oi2;
+            }
+            bestp = fmax(bestp, op2);
+        }
+        if (lane == 0) {
+            a.max_lik[u] = best;
+            a.argmax[u] = bi;
+            a.max_post[u] = bestp;
+        }
+    }
+}
+
+
+// ====================================================================================
+// K2 with 4-family granularity: the 4x4x4_4b shape throughout.  A workgroup owns NF = 4*G*Wf
+// families (any multiple of 4, not only of 16), so the family tiles can be sized to fill the 256
+// CUs evenly when the table is small (10 k families = 625 tiles of 16 put 3 tiles on 113 CUs and 2 on
+// the rest; 250 tiles of 40 put one on each of 250 CUs).  Accumulator g of a wave holds, in lane l,
+// Y[fam_base + 4g + (l>>4)][row0 + (l&15)]: the same walk, gathers and stores as k2_prune_mfma with
+// (i, r) flattened to g = 4i + r.
+// ====================================================================================
+template <int G, int NRT_W>
+__device__ __forceinline__ void mfma4_edge(const double* __restrict__ bp, const int (&boff)[NRT_W],
+                                           size_t kstride, const double* ap4, int LDv, int ksteps,
+                                           double (&acc)[G][NRT_W])
+{
+    double a0[G], a1[G], b0[NRT_W], b1[NRT_W];
+#pragma unroll
+    for (int g = 0; g < G; ++g) a0[g] = ap4[(size_t)(4 * g) * LDv];
+#pragma unroll
+    for (int j = 0; j < NRT_W; ++j) b0[j] = bp[boff[j]];
+    int ks = 0;
+    for (; ks + 2 <= ksteps; ks += 2) {
+        const double* bp1 = bp + (size_t)(ks + 1) * kstride;
+        const double* ap1 = ap4 + (ks + 1) * 4;
+#pragma unroll
+        for (int g = 0; g < G; ++g) a1[g] = ap1[(size_t)(4 * g) * LDv];
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j) b1[j] = bp1[boff[j]];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < NRT_W; ++j)
+                acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[g], b0[j], acc[g][j], 0, 0, 0);
+        const int kn = (ks + 2 < ksteps) ? ks + 2 : ksteps - 1;
+        const double* bp2 = bp + (size_t)kn * kstride;
+        const double* ap2 = ap4 + kn * 4;
+#pragma unroll
+        for (int g = 0; g < G; ++g) a0[g] = ap2[(size_t)(4 * g) * LDv];
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j) b0[j] = bp2[boff[j]];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < NRT_W; ++j)
+                acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[g], b1[j], acc[g][j], 0, 0, 0);
+    }
+    if (ks < ksteps) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < NRT_W; ++j)
+                acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[g], b0[j], acc[g][j], 0, 0, 0);
+    }
+}
+
+template <int G, int NRT_W>
+__global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
+{
+    extern __shared__ double Lbuf[];                          // [NF][LDv]
+    int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv);  // [NF][n_leaves]
+    int* s_colmax = s_cnt + a.NF * a.n_leaves;                // [NF]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15;
+    const int lk = lane >> 4;
+    const int wf = wave % a.Wf;
+    const int wr = wave / a.Wf;
+    const int fbase = wf * 4 * G;               // first family of this wave inside the workgroup
+    const int fam0 = blockIdx.x * a.NF;
+    const bool batch = (a.col_max != nullptr);
+    const size_t park_stride = (size_t)a.NF * a.LDv;
+    double* my_park = a.park + (size_t)blockIdx.x * a.n_parks * park_stride;
+
+    for (int i = tid; i < a.NF * a.n_leaves; i += blockDim.x) {
+        const int f = i / a.n_leaves, j = i - f * a.n_leaves;
+        const int u = fam0 + f;
+        s_cnt[i] = (u < a.Fu) ? a.counts[(size_t)u * a.n_leaves + j] : 0;
+    }
+    for (int f = tid; f < a.NF; f += blockDim.x) {
+        const int u = fam0 + f;
+        s_colmax[f] = (batch && u < a.Fu) ? a.col_max[u] : (a.C - 1);
+    }
+    __syncthreads();
+
+    double hold[G][NRT_W];
+
+    for (int oi = 0; oi < a.n_ops; ++oi) {
+        const cafehip::MfmaOp op = a.ops[oi];
+        const int rows = op.is_root ? a.R : a.C;
+        const int row_lo = op.is_root ? a.root_min : 0;
+        const int RT = (rows + 15) >> 4;
+        const int rt_base = RT / a.Wr, rt_rem = RT - rt_base * a.Wr;
+        const int ntile = rt_base + (wr < rt_rem ? 1 : 0);
+        const int rt0 = wr * rt_base + min(wr, rt_rem);
+        const bool wave_active = ntile > 0;
+
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const double* PTe = a.PT + (size_t)a.ep->node_key[op.child[ch]] * a.KP * a.LD + row_lo;
+            const bool errleaf = (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.leafcol[ch]];
+            double fac[G][NRT_W];
+            if (errleaf && a.err_banded) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int f = fbase + 4 * g + lk;
+                    const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
+                    const int klo = max(cnt + a.err_dlo, 0);
+                    const int khi = min(min(cnt + a.err_dhi, a.C - 1), s_colmax[f]);
+                    const double* erow = a.err + (size_t)cnt * a.err_ld;
+#pragma unroll
+                    for (int j = 0; j < NRT_W; ++j) {
+                        double v = 0.0;
+                        if (j < ntile)
+                            for (int k = klo; k <= khi; ++k) v += erow[k] * PTe[(size_t)k * a.LD + (rt0 + j) * 16 + li];
+                        fac[g][j] = v;
+                    }
+                }
+            } else if (op.kind[ch] == 0 && !errleaf) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int f = fbase + 4 * g + lk;
+                    const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
+                    const bool ok = cnt <= s_colmax[f];
+#pragma unroll
+                    for (int j = 0; j < NRT_W; ++j)
+                        fac[g][j] = (ok && j < ntile) ? PTe[(size_t)cnt * a.LD + (rt0 + j) * 16 + li] : 0.0;
+                }
+            } else {
+                if (op.kind[ch] == 1 && op.src_park[ch] >= 0) {
+                    __syncthreads();
+                    const double* src = my_park + (size_t)op.src_park[ch] * park_stride;
+                    for (int i = tid; i < a.NF * a.LDv; i += blockDim.x) Lbuf[i] = src[i];
+                    __syncthreads();
+                } else if (errleaf) {
+                    __syncthreads();
+                    for (int i = tid; i < a.NF * a.LDv; i += blockDim.x) {
+                        const int f = i / a.LDv, k = i - f * a.LDv;
+                        const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
+                        Lbuf[i] = (k < a.C && k <= s_colmax[f]) ? a.err[(size_t)cnt * a.err_ld + k] : 0.0;
+                    }
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int j = 0; j < NRT_W; ++j) fac[g][j] = 0.0;
+                if (wave_active) {
+                    int boff[NRT_W];
+#pragma unroll
+                    for (int j = 0; j < NRT_W; ++j) boff[j] = ((j < ntile) ? (rt0 + j) : rt0) * 16;
+                    const double* bp = PTe + (size_t)lk * a.LD + li;
+                    const double* ap4 = Lbuf + (size_t)(fbase + (lane & 3)) * a.LDv + lk;
+                    mfma4_edge<G, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int j = 0; j < NRT_W; ++j) hold[g][j] = (ch == 0) ? fac[g][j] : hold[g][j] * fac[g][j];
+        }
+
+        double* dst;
+        if (op.dst_park >= 0) {
+            dst = my_park + (size_t)op.dst_park * park_stride;
+        } else {
+            __syncthreads();
+            dst = Lbuf;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = fbase + 4 * g + lk;
+            const int cm = s_colmax[f];
+#pragma unroll
+            for (int j = 0; j < NRT_W; ++j) {
+                if (j < ntile) {
+                    const int row = (rt0 + j) * 16 + li;
+                    double v = hold[g][j];
+                    if (!op.is_root && row > cm) v = 0.0;
+                    dst[(size_t)f * a.LDv + row] = v;
+                }
+            }
+        }
+        if (op.dst_park < 0) __syncthreads();
+    }
+
+    const int nwaves = blockDim.x >> 6;
+    for (int f = wave; f < a.NF; f += nwaves) {
+        const int u = fam0 + f;
+        if (u >= a.Fu) continue;
+        const double* L = Lbuf + (size_t)f * a.LDv;
+        if (batch) {
+            const int lo = a.root_lo[u] - a.root_min, hi = a.root_hi[u] - a.root_min;
+            double* o = a.out_root + a.out_off[u];
+            for (int i = lo + lane; i <= hi; i += 64) o[i - lo] = L[i];
+            continue;
+        }
+        double best = -INFINITY, bestp = -INFINITY;
+        int bi = INT_MAX;
+        for (int i = lane; i < a.R; i += 64) {
+            const double v = L[i];
+            if (bi == INT_MAX || v > best) {
+                best = v;
+                bi = i;
+            }
+            const double p = exp(log(v) + a.ep->logprior[i]);
+            bestp = fmax(bestp, p);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(best, off);
+            const int oi2 = __shfl_xor(bi, off);
+            const double op2 = __shfl_xor(bestp, off);
             if (oi2 != INT_MAX && (bi == INT_MAX || ov > best || (ov == best && oi2 < bi))) {
                 best = ov;
                 bi = oi2;
