@@ -187,7 +187,9 @@ def main():
         achieved = f_alg * F_local / (k2_ms * 1e-3) / 1e12
         out["roofline"] = {
             "bound": "mfma",
-            "kernel": "k2_prune_mfma (v_mfma_f64_16x16x4: pruning of all families + posterior in one launch)",
+            "kernel": "k2_prune_mfma4 (v_mfma_f64_4x4x4_4b)" if "mfma4x4" in eng.describe() else
+                      "k2_prune_mfma (v_mfma_f64_16x16x4)",
+            "kernel_does": "pruning of all families + posterior in one launch",
             "achieved": achieved,
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
@@ -200,11 +202,13 @@ def main():
             "avg_launch_ms": k2_ms,
             "executed": {"flops_per_family": f_exec, "TFLOP/s": f_exec * F_local / (k2_ms * 1e-3) / 1e12,
                          "frac_of_spec_peak": f_exec * F_local / (k2_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                         "frac_of_measured_mfma_f64_ceiling_47.7": f_exec * F_local / (k2_ms * 1e-3) / 1e12 / 47.7},
+                         "frac_of_measured_16x16x4_issue_ceiling_47.7": f_exec * F_local / (k2_ms * 1e-3) / 1e12 / 47.7,
+                         "frac_of_measured_4x4x4_issue_ceiling_73.9": f_exec * F_local / (k2_ms * 1e-3) / 1e12 / 73.9},
             "note": "achieved credits SURVEY.md 8(d) F_alg = the reference's dense product on EVERY child edge "
                     "(what the CPU path executes); 'executed' counts only the products the GEMM formulation issues "
-                    "(one-hot leaf edges are column gathers). Spec peak 78.6 TFLOP/s FP64; the f64 MFMA issue-rate "
-                    "ceiling measured on this chip is 47.7 TFLOP/s (profiles/r01_mfma_f64_probe.txt).",
+                    "(one-hot leaf edges are column gathers). Spec peak 78.6 TFLOP/s FP64; register-only issue-rate "
+                    "ceilings measured on this chip: 47.7 TFLOP/s for v_mfma_f64_16x16x4, 73.9 for "
+                    "v_mfma_f64_4x4x4_4b (profiles/r01_mfma_f64_probe.txt, r01_mfma_f64_4x4x4_probe.txt).",
         }
         out["roofline_hbm_effective"] = {
             "achieved": b_alg * F_local / (k2_ms * 1e-3) / 1e9,
