@@ -1103,7 +1103,6 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     a.Wf = k.wf;
     a.Wr = k.wr;
     a.NF = nf;
-    a.shape4x4 = 0;
     a.park = c->d_park;
     a.n_parks = std::max(c->msched.n_parks, 1);
     a.err = v1.err;

@@ -35,7 +35,6 @@ struct K2MfmaArgs {
     int ksteps;            // ceil(C / 4)
     int Wf, Wr;            // wave grid
     int NF;                // families per workgroup = 16 * Wf * NFT_W
-    int shape4x4;          // 1: v_mfma_f64_4x4x4_4b (default), 0: v_mfma_f64_16x16x4
     double* park;          // [grid][n_parks][NF][LDv]
     int n_parks;
     // error model
@@ -101,70 +100,6 @@ __device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const i
 #pragma unroll
             for (int j = 0; j < NRT_W; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
-    }
-}
-
-// The same edge with v_mfma_f64_4x4x4_4b_f64 (4 independent 4x4x4 blocks per instruction).  Measured on
-// MI355X (tools/mfma_f64_4x4_probe.hip) it sustains 73.9 TFLOP/s against 47.7 for the 16x16x4 shape.
-// Mapping the 4 blocks to 4 groups of 4 rows makes its B operand IDENTICAL to the 16x16x4 one
-// (lane l: PT[k0 + (l>>4)][row0 + (l&15)]) and its result lane l = Y[fam0 + (l>>4)][row0 + (l&15)], i.e.
-// register r of the 16x16 accumulator when the A operand carries families fam0 + 4r + (l&3)
-// (lane l: L[fam0 + 4r + (l&3)][k0 + (l>>4)], broadcast over the blocks).  Four instructions with four
-// A registers and one shared B register therefore fill exactly the accumulator tile of one 16x16x4.
-template <int NFT_W, int NRT_W>
-__device__ __forceinline__ void mfma_edge_4x4(const double* __restrict__ bp, const int (&boff)[NRT_W],
-                                              size_t kstride, const double* ap4, int LDv, int ksteps,
-                                              cafe_d4 (&acc)[NFT_W][NRT_W])
-{
-    double a0[NFT_W][4], a1[NFT_W][4], b0[NRT_W], b1[NRT_W];
-#pragma unroll
-    for (int i = 0; i < NFT_W; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a0[i][r] = ap4[(size_t)(i * 16 + 4 * r) * LDv];
-#pragma unroll
-    for (int j = 0; j < NRT_W; ++j) b0[j] = bp[boff[j]];
-    int ks = 0;
-    for (; ks + 2 <= ksteps; ks += 2) {
-        const double* bp1 = bp + (size_t)(ks + 1) * kstride;
-        const double* ap1 = ap4 + (ks + 1) * 4;
-#pragma unroll
-        for (int i = 0; i < NFT_W; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a1[i][r] = ap1[(size_t)(i * 16 + 4 * r) * LDv];
-#pragma unroll
-        for (int j = 0; j < NRT_W; ++j) b1[j] = bp1[boff[j]];
-#pragma unroll
-        for (int i = 0; i < NFT_W; ++i)
-#pragma unroll
-            for (int j = 0; j < NRT_W; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[i][r], b0[j], acc[i][j][r], 0, 0, 0);
-        const int kn = (ks + 2 < ksteps) ? ks + 2 : ksteps - 1;
-        const double* bp2 = bp + (size_t)kn * kstride;
-        const double* ap2 = ap4 + kn * 4;
-#pragma unroll
-        for (int i = 0; i < NFT_W; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a0[i][r] = ap2[(size_t)(i * 16 + 4 * r) * LDv];
-#pragma unroll
-        for (int j = 0; j < NRT_W; ++j) b0[j] = bp2[boff[j]];
-#pragma unroll
-        for (int i = 0; i < NFT_W; ++i)
-#pragma unroll
-            for (int j = 0; j < NRT_W; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[i][r], b1[j], acc[i][j][r], 0, 0, 0);
-    }
-    if (ks < ksteps) {
-#pragma unroll
-        for (int i = 0; i < NFT_W; ++i)
-#pragma unroll
-            for (int j = 0; j < NRT_W; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[i][r], b0[j], acc[i][j][r], 0, 0, 0);
     }
 }
 
@@ -282,13 +217,8 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                     for (int j = 0; j < NRT_W; ++j)
                         boff[j] = ((j < ntile) ? (rt0 + j) : rt0) * 16;  // inactive tiles re-read tile rt0
                     const double* bp = PTe + (size_t)lk * a.LD + li;
-                    if (a.shape4x4) {
-                        const double* ap4 = Lbuf + (size_t)(ft0 * 16 + (lane & 3)) * a.LDv + lk;
-                        mfma_edge_4x4<NFT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
-                    } else {
-                        const double* ap = Lbuf + (size_t)(ft0 * 16 + li) * a.LDv + lk;
-                        mfma_edge<NFT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
-                    }
+                    const double* ap = Lbuf + (size_t)(ft0 * 16 + li) * a.LDv + lk;
+                    mfma_edge<NFT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
                 }
             }
             if (ch == 0) {
@@ -378,7 +308,13 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 
 
 // ====================================================================================
-// K2 with 4-family granularity: the 4x4x4_4b shape throughout.  A workgroup owns NF = 4*G*Wf
+// K2 with 4-family granularity: v_mfma_f64_4x4x4_4b_f64 (4 independent 4x4x4 blocks per instruction,
+// 16 cycles, the same 32 flop/cycle/SIMD as the 64-cycle 16x16x4; measured SQ_VALU_MFMA_BUSY_CYCLES per
+// instruction: 16.0 and 64.0).  Mapping the 4 blocks to 4 groups of 4 rows makes the B operand IDENTICAL to
+// the 16x16x4 one (lane l: PT[k0 + (l>>4)][row0 + (l&15)]); with the A operand carrying families
+// fam + (l&3) (lane l: L[fam + (l&3)][k0 + (l>>4)], broadcast over the blocks) the result lane l is
+// Y[fam + (l>>4)][row0 + (l&15)] -- one register of the 16x16 accumulator tile (layout decoded by
+// tools/mfma_f64_4x4_probe.hip).  A workgroup owns NF = 4*G*Wf
 // families (any multiple of 4, not only of 16), so the family tiles can be sized to fill the 256
 // CUs evenly when the table is small (10 k families = 625 tiles of 16 put 3 tiles on 113 CUs and 2 on
 // the rest; 250 tiles of 40 put one on each of 250 CUs).  Accumulator g of a wave holds, in lane l,
