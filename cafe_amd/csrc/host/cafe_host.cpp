@@ -517,6 +517,7 @@ struct cafehost_session {
     double search_seconds = 0;
     std::vector<double> trace;
     std::vector<std::vector<double>> cond_dist;  // ConditionalDistribution::matrix, cafe/pvalue.cpp:13
+    std::vector<int> root_dist;  // param->root_dist: families per root size (index = size), cafe_commands.cpp:742
     // error model (one model file; ErrorStruct, libtree/family.h:31-38)
     std::string err_file;
     int err_mfs = -1, err_fromdiff = 0, err_todiff = 0;
@@ -954,6 +955,7 @@ struct cafehost_session {
         have_lambda_tree = false;
         num_lambdas = 1;
         bool search_flag = false, score_flag = false;
+        double vlambda = -1;
         std::vector<double> lambdas;
         for (auto& a : args) {
             if (a.opt == "-s") search_flag = true;
@@ -963,8 +965,12 @@ struct cafehost_session {
                 if (a.argv.empty()) throw std::runtime_error("lambda -t needs a lambda tree");
                 set_lambda_tree(a.argv.back());
             } else if (a.opt == "-l") lambdas = doubles_of(a);
-            else
-                throw std::runtime_error("lambda " + a.opt + " is outside this build's scope (supported: -s -l -t -score -checkconv)");
+            else if (a.opt == "-v") {
+                // SINGLE_LAMBDA: set_all_lambdas before the command (cafe/lambda.cpp:386-389); a search starts from
+                // random values anyway, so it only matters for the set form
+                if (!a.argv.empty()) vlambda = atof(a.argv[0].c_str());
+            } else
+                throw std::runtime_error("lambda " + a.opt + " is outside this build's scope (supported: -s -l -v -t -score -checkconv)");
         }
         upload();
         n_evals = 0;
@@ -974,6 +980,7 @@ struct cafehost_session {
         if (search_flag) {
             search();
         } else {
+            if (lambdas.empty() && vlambda > 0) lambdas.assign(num_lambdas, vlambda);
             if ((int)lambdas.size() != num_lambdas)
                 throw std::runtime_error("ERROR(lambda): Number of parameters not correct. The number of -l lambdas are " +
                                          std::to_string(lambdas.size()) + " they need to be " + std::to_string(num_lambdas));
@@ -1332,6 +1339,318 @@ struct cafehost_session {
         return 0;
     }
 
+
+    // ---- helpers shared by genfamily / rootdist / pvalue / lhtest ----
+    std::vector<int> prefix_order() const
+    {
+        std::vector<int> prefix, st{tree.root};
+        while (!st.empty()) {
+            const int v = st.back();
+            st.pop_back();
+            prefix.push_back(v);
+            if (tree.left[v] >= 0) {
+                st.push_back(tree.right[v]);
+                st.push_back(tree.left[v]);
+            }
+        }
+        return prefix;
+    }
+
+    // matrices for the current parameters on the device + host copies (node -> S x S)
+    int fetch_matrices(std::vector<std::vector<double>>& mats)
+    {
+        if ((int)params.size() != num_params || num_params == 0)
+            throw std::runtime_error("ERROR: Lambda values were not set. Please set lambda values with the 'lambda' or 'lambdamu' command.\n");
+        upload();
+        std::vector<double> nl_, nm_;
+        node_rates(params.data(), nl_, nm_);
+        hip_check(cafehip_reset_birthdeath_cache(ctx, nl_.data(), nm_.data()));
+        const int S = cafehip_matrix_size(ctx);
+        mats.assign(tree.n, {});
+        for (int v = 0; v < tree.n; ++v) {
+            if (v == tree.root) continue;
+            mats[v].resize((size_t)S * S);
+            int s_out = 0;
+            hip_check(cafehip_get_matrix(ctx, v, mats[v].data(), &s_out));
+        }
+        return S;
+    }
+
+    // cafe_tree_random_familysize, cafe/cafe_tree.c:533-569
+    int random_familysize(const std::vector<std::vector<double>>& mats, int S, const std::vector<int>& prefix,
+                          int root_size, int max_family_size, std::vector<int>& fs)
+    {
+        int mx = 0;
+        fs[tree.root] = root_size;
+        for (int v : prefix) {
+            if (v == tree.root) continue;
+            const double rnd = unifrnd();
+            double cumul = 0;
+            const double* m = mats[v].data() + (size_t)fs[tree.parent[v]] * S;
+            int c = 0;
+            for (; c < max_family_size - 1; ++c) {
+                cumul += m[c];
+                if (cumul >= rnd) break;
+            }
+            fs[v] = c;
+            if (mx < c) mx = c;
+        }
+        return mx;
+    }
+
+    // get_root_dist, cafe/cafe_commands.cpp:619-646: Viterbi root size of every family under the GLOBAL ranges
+    void compute_root_dist()
+    {
+        std::vector<std::vector<double>> mats;
+        fetch_matrices(mats);
+        const int F = fam.F(), nl = tree.n_leaves(), ns = (int)fam.species.size(), n = tree.n;
+        std::vector<int32_t> counts((size_t)std::max(F, 1) * nl, 0), lo(F, range.root_min), hi(F, range.root_max), cm(F, range.max);
+        for (int i = 0; i < F; ++i)
+            for (int s_ = 0; s_ < ns; ++s_)
+                if (species_index[s_] >= 0) counts[(size_t)i * nl + species_index[s_] / 2] = fam.counts[(size_t)i * ns + s_];
+        std::vector<int32_t> sizes((size_t)std::max(F, 1) * n);
+        printf("Viterbi\n");
+        if (F) hip_check(cafehip_viterbi(ctx, F, counts.data(), lo.data(), hi.data(), cm.data(), sizes.data()));
+        root_dist.assign(range.root_max - range.root_min + 2, 0);
+        for (int i = 0; i < F; ++i) {
+            const int rs = sizes[(size_t)i * n + tree.root];
+            if (rs >= 0 && rs < (int)root_dist.size()) root_dist[rs]++;
+        }
+    }
+
+    int cmd_rootdist(const std::vector<std::string>& tokens)
+    {  // cafe_cmd_rootdist, cafe/cafe_commands.cpp:1831-1916
+        prereqs(false, true);
+        auto args = build_argument_list(tokens);
+        std::string file;
+        for (auto& a : args)
+            if (a.opt == "-i" && !a.argv.empty()) file = a.argv[0];
+        if (tokens.size() < 2) {
+            prereqs(true, false);
+            compute_root_dist();
+            log("-----------------------------------------------------------\n");
+            log("Family information: %s\n", fam.path.c_str());
+            log("Log: %s\n", log_name.c_str());
+            log("Tree: %s\n", tree_string([&](int v) { return tree.name[v]; }, true).c_str());
+            log("The number of families is %d\n", fam.F());
+            return 0;
+        }
+        if (file.empty()) throw std::runtime_error("Usage(rootdist): rootdist [-i file]");
+        std::ifstream in(file);
+        if (!in) throw std::runtime_error("ERROR(rootdist): Cannot open " + file + " in read mode.");
+        std::string line;
+        if (!std::getline(in, line)) throw std::runtime_error("Empty file: " + file);
+        auto data = HostFamilies::split(line, ' ');
+        auto mx = HostFamilies::split(data.back(), ':');
+        if (mx.size() < 2) throw std::runtime_error("Invalid format in rootdist file");
+        const int max_rootsize = atoi(mx[1].c_str());
+        root_dist.assign(max_rootsize + 1, 0);
+        range.root_min = 1;  // :1889-1893
+        range.root_max = max_rootsize;
+        range.min = 0;
+        range.max = max_rootsize * 2;
+        device_families_current = false;
+        while (std::getline(in, line)) {
+            data = HostFamilies::split(line, ' ');
+            if (data.size() < 2) continue;
+            const int idx = atoi(data[0].c_str());
+            if (idx >= 0 && idx <= max_rootsize) root_dist[idx] = atoi(data[1].c_str());
+        }
+        return 0;
+    }
+
+    int cmd_genfamily(const std::vector<std::string>& tokens)
+    {  // cafe_cmd_generate_random_family, cafe/cafe_commands.cpp:718-815
+        if (tokens.size() == 1) throw std::runtime_error("Usage: genfamily directory/fileprefix -t integer");
+        prereqs(false, true);
+        int num_trials = 1;
+        for (auto& a : build_argument_list(tokens))
+            if (a.opt == "-t" && !a.argv.empty()) num_trials = atoi(a.argv[0].c_str());
+        const std::string prefix_path = tokens[1];
+        if (root_dist.empty()) {
+            prereqs(true, false);
+            compute_root_dist();
+        } else {
+            log("Using user defined root size distribution for simulation... \n");
+            if (!have_family) {
+                // no table loaded: the device only needs the ranges, give it an empty table
+                fam = HostFamilies();
+                for (int i = 0; i < tree.n; i += 2) fam.species.push_back(tree.name[i]);
+                have_family = true;
+                sync_species_index();
+            }
+        }
+        std::vector<std::vector<double>> mats;
+        const int S = fetch_matrices(mats);
+        const std::vector<int> prefix = prefix_order();
+        const int rfsize = range.root_max - range.root_min + 1;
+        const int maxFamilysize = S - 1;  // probability_cache->maxFamilysize
+        std::vector<int> fs(tree.n, 0);
+        for (int t = 0; t < num_trials; ++t) {
+            const std::string base = prefix_path + "_" + std::to_string(t + 1);
+            FILE* ft = fopen((base + ".tab").c_str(), "w");
+            if (!ft) throw std::runtime_error(base + ".tab failed to open");
+            FILE* fr = fopen((base + ".truth").c_str(), "w");
+            if (!fr) {
+                fclose(ft);
+                throw std::runtime_error(base + ".truth failed to open");
+            }
+            // write_node_headers :672-694
+            fprintf(ft, "DESC\tFID");
+            fprintf(fr, "DESC\tFID");
+            for (int i = 0; i < tree.n; i += 2) fprintf(ft, "\t%s", tree.name[i].c_str());
+            fprintf(ft, "\n");
+            for (int i = 0; i < tree.n; ++i) {
+                if (!tree.name[i].empty()) fprintf(fr, "\t%s", tree.name[i].c_str());
+                else fprintf(fr, "\t-%d", i);
+            }
+            fprintf(fr, "\n");
+            int id = 1;
+            for (int i = 1; i <= rfsize && i < (int)root_dist.size(); ++i) {
+                for (int j = 0; j < root_dist[i]; ++j) {
+                    random_familysize(mats, S, prefix, i, maxFamilysize, fs);
+                    fprintf(ft, "root%d\t%d", i, id);  // write_leaves :696-711
+                    fprintf(fr, "root%d\t%d", i, id);
+                    for (int n_ = 0; n_ < tree.n; n_ += 2) fprintf(ft, "\t%d", fs[n_]);
+                    for (int n_ = 0; n_ < tree.n; ++n_) fprintf(fr, "\t%d", fs[n_]);
+                    fprintf(ft, "\n");
+                    fprintf(fr, "\n");
+                    ++id;
+                }
+            }
+            fclose(ft);
+            fclose(fr);
+        }
+        return 0;
+    }
+
+    // get_posterior for the current parameters and a given prior (cafe/lambda.cpp:691-724), -inf on a zero family
+    double posterior_with_prior(const std::vector<double>& pr)
+    {
+        upload();
+        std::vector<double> nl_, nm_;
+        node_rates(params.data(), nl_, nm_);
+        double score = 0;
+        int32_t zero = -1;
+        hip_check(cafehip_eval_posterior(ctx, nl_.data(), nm_.data(), pr.data(), &score, &zero, nullptr, nullptr, nullptr));
+        if (zero >= 0) {
+            fprintf(stderr, "WARNING: Calculated posterior probability for family %s = 0\n", fam.ids[zero].c_str());
+            score = std::log(0.0);
+        }
+        return score;
+    }
+
+    int cmd_lhtest(const std::vector<std::string>& tokens)
+    {  // cafe_cmd_lhtest, cafe/cafe_commands.cpp:1473-1536
+        prereqs(false, true);
+        std::string dir, ltree, outfile;
+        double lam = 0.0;
+        for (auto& a : build_argument_list(tokens)) {
+            if (a.argv.empty()) continue;
+            if (a.opt == "-d") dir = a.argv[0];
+            if (a.opt == "-l") lam = atof(a.argv[0].c_str());
+            if (a.opt == "-t") ltree = a.argv[0];
+            if (a.opt == "-o") outfile = a.argv[0];
+        }
+        if (dir.empty() || ltree.empty()) throw std::runtime_error("Usage(lhtest): lhtest -d directory -l lambda -t lambdatree [-o outfile]");
+        FILE* fout = stdout;
+        if (!outfile.empty() && !(fout = fopen(outfile.c_str(), "w"))) throw std::runtime_error("Failed to open output file");
+        std::vector<std::string> files;
+        {
+            std::string cmd = "ls -1 '" + dir + "' 2>/dev/null";
+            FILE* pp = popen(cmd.c_str(), "r");
+            if (!pp) throw std::runtime_error("Failed to read directory");
+            char buf[4096];
+            while (fgets(buf, sizeof buf, pp)) {
+                std::string f = buf;
+                while (!f.empty() && (f.back() == '\n' || f.back() == '\r')) f.pop_back();
+                if (f.size() > 4 && f.substr(f.size() - 4) == ".tab" && f[0] != '.') files.push_back(f);
+            }
+            pclose(pp);
+        }
+        std::sort(files.begin(), files.end());  // the reference uses readdir order; sorted here for reproducibility
+        const std::string tree_str = tree_string([&](int v) { return tree.name[v]; }, true);
+        std::vector<double> pr = prior;  // the prior in force when lhtest starts is used for every file (:1492-1493)
+        if (pr.size() < 1000) pr.assign(1000, 0.0);
+        char lbuf[64];
+        snprintf(lbuf, sizeof lbuf, "%lf", lam);
+        for (auto& f : files) {
+            dispatch("load -i " + dir + "/" + f + " -p 0.01 -t 10 -l " + log_name);
+            dispatch("tree " + tree_str);
+            dispatch(std::string("lambda -s -l ") + lbuf);
+            fprintf(fout, "\t%lf\t%lf", posterior_with_prior(pr), params[0]);
+            dispatch(std::string("lambda -s -v ") + lbuf + " -t " + ltree);
+            fprintf(fout, "\t%lf", posterior_with_prior(pr));
+            for (int j = 0; j < num_lambdas; ++j) fprintf(fout, "\t%lf", params[j]);
+            fprintf(fout, "\n");
+            fflush(fout);
+        }
+        if (fout != stdout) fclose(fout);
+        return 0;
+    }
+
+    int cmd_pvalue(const std::vector<std::string>& tokens)
+    {  // cafe_cmd_pvalue, cafe/cafe_commands.cpp:1373-1412 (-o / -i / -idx)
+        prereqs(false, true);
+        std::string outfile, infile;
+        int index = -1;
+        for (auto& a : build_argument_list(tokens)) {
+            if (a.argv.empty()) continue;
+            if (a.opt == "-o") outfile = a.argv[0];
+            if (a.opt == "-i") infile = a.argv[0];
+            if (a.opt == "-idx") index = atoi(a.argv[0].c_str());
+        }
+        if (!outfile.empty()) {
+            std::vector<std::vector<double>> mats;
+            const int S = fetch_matrices(mats);
+            compute_conditional_distribution(mats, S);
+            FILE* fp = fopen(outfile.c_str(), "w");
+            if (!fp) throw std::runtime_error("ERROR(pvalue): Cannot open " + outfile + " in write mode.");
+            // write_pvalues, cafe/pvalue.cpp:63-77 (the reference passes a zeroed copy here, cafe_commands.cpp:1351-1361;
+            // the distribution itself is written instead)
+            for (auto& row : cond_dist) {
+                for (size_t j = 0; j < row.size(); ++j) fprintf(fp, j ? "\t%.9g" : "%.9g", row[j]);
+                fprintf(fp, "\n");
+            }
+            fclose(fp);
+            return 0;
+        }
+        if (!infile.empty()) {
+            log("Loading p-values ... \n");
+            std::ifstream in(infile);
+            if (!in) throw std::runtime_error("ERROR(pvalue): Cannot open " + infile + " in read mode.");
+            cond_dist.clear();  // read_pvalues, cafe/pvalue.cpp:80-93
+            std::string line;
+            while (std::getline(in, line)) {
+                std::vector<double> row(num_random_samples, 0.0);
+                std::istringstream iss(line);
+                for (int i = 0; i < num_random_samples; ++i) iss >> row[i];
+                cond_dist.push_back(row);
+            }
+            log("Done Loading p-values ... \n");
+            return 0;
+        }
+        if (index >= 0) {  // pvalues_for_family, cafe/pvalue.cpp:95-121
+            prereqs(true, false);
+            if (index >= fam.F()) throw std::runtime_error("ERROR(pvalue): family index out of range");
+            std::vector<std::vector<double>> mats;
+            const int S = fetch_matrices(mats);
+            if (cond_dist.empty()) compute_conditional_distribution(mats, S);
+            const int nl = tree.n_leaves(), ns = (int)fam.species.size();
+            std::vector<int32_t> counts(nl, 0);
+            for (int s_ = 0; s_ < ns; ++s_)
+                if (species_index[s_] >= 0) counts[species_index[s_] / 2] = fam.counts[(size_t)index * ns + s_];
+            const int32_t lo = range.root_min, hi = range.root_max, cm = range.max;
+            std::vector<double> lh(hi - lo + 1);
+            hip_check(cafehip_eval_root_likelihoods(ctx, 1, counts.data(), &lo, &hi, &cm, lh.data()));
+            for (int i = 0; i <= hi - lo; ++i)
+                printf("%d\t%lg\t%lg\n", i + range.root_min, lh[i], pvalue_rank(lh[i], cond_dist[i].data(), num_random_samples));
+            fflush(stdout);
+            return 0;
+        }
+        throw std::runtime_error("pvalue: supported forms are -o file, -i file, -idx n");
+    }
+
     int dispatch(const std::string& line_in)
     {
         std::string line = line_in;
@@ -1377,6 +1696,10 @@ struct cafehost_session {
         if (cmd == "lambdamu") return cmd_lambdamu(tokens);
         if (cmd == "report") return cmd_report(tokens);
         if (cmd == "errormodel") return cmd_errormodel(tokens);
+        if (cmd == "rootdist") return cmd_rootdist(tokens);
+        if (cmd == "genfamily") return cmd_genfamily(tokens);
+        if (cmd == "lhtest") return cmd_lhtest(tokens);
+        if (cmd == "pvalue") return cmd_pvalue(tokens);
         if (cmd == "noerrormodel") {  // cafe/cafe_commands.cpp: remove the model from every species
             err_file.clear();
             err_mfs = -1;

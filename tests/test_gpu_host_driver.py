@@ -281,3 +281,105 @@ def test_load_filter_keeps_families_with_a_copy_at_the_root(shell, tmp_path):
     prior = O.prior_poisson(1000, rng.root_min, shell.poisson_lambda)
     so, *_ = O.eval_posterior(t, counts, rng, np.full(t.n_nodes, 0.01), np.full(t.n_nodes, -1.0), prior)
     assert shell.score == pytest.approx(-so, rel=1e-12)
+
+
+def test_genfamily_matches_oracle_simulation(shell, tmp_path):
+    # genfamily (cafe/cafe_commands.cpp:718-815): root-size distribution from the Viterbi root sizes of the
+    # loaded table (get_root_dist :619-646), then per family one unifrnd() per non-root node in prefix order
+    # (cafe/cafe_tree.c:533-569).  Same rand() stream => the simulated tables must be identical.
+    import ctypes as C
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+    path = os.path.join(GOLD, "example_data.tab")
+    shell.dispatch("seed 10")
+    shell.dispatch("load -i %s -t 1" % path)
+    shell.dispatch("tree " + newick)
+    shell.dispatch("lambda -l 0.0017")
+    prefix = str(tmp_path / "rnd")
+    shell.dispatch("genfamily %s -t 2" % prefix)
+
+    sp, ids, counts = O.load_family_table(path)
+    t = O.PyTree(newick)
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    L = O.lib()
+    libc = C.CDLL(None)
+    lam = np.full(t.n_nodes, 0.0017)
+    mu = np.full(t.n_nodes, -1.0)
+    ct = t.ctree()
+    M = max(rng.max, rng.root_max)
+    h = L.orc_matrices_build(C.byref(ct), O.dptr(lam), O.dptr(mu), M, 1)
+    sof = M + 2
+    vit = np.zeros(t.n_nodes * sof, np.int32)
+    Lb = np.zeros(t.n_nodes * sof)
+    root_dist = np.zeros(rng.root_max + 2, int)
+    for i in range(counts.shape[0]):
+        fs = np.full(t.n_nodes, -1, np.int32)
+        fs[0::2] = counts[i]
+        vit[:] = 0
+        L.orc_tree_viterbi(C.byref(ct), C.byref(rng), h, O.iptr(fs), O.iptr(vit), O.dptr(Lb), sof)
+        root_dist[fs[t.root]] += 1
+    libc.srand(10)
+    libc.rand()  # the Poisson-fit start of `lambda -l`
+    for trial in (1, 2):
+        exp_rows = []
+        fid = 1
+        for rs in range(1, rng.root_max + 1):
+            for _ in range(root_dist[rs]):
+                fs = np.zeros(t.n_nodes, np.int32)
+                L.orc_tree_random_familysize(C.byref(ct), h, rs, M, O.iptr(fs))
+                exp_rows.append(["root%d" % rs, str(fid)] + [str(int(x)) for x in fs[0::2]])
+                fid += 1
+        got = [l.rstrip("\n").split("\t") for l in open("%s_%d.tab" % (prefix, trial))]
+        assert got[0] == ["DESC", "FID", "chimp", "human", "mouse", "rat", "dog"]
+        assert got[1:] == exp_rows
+        truth = [l.rstrip("\n").split("\t") for l in open("%s_%d.truth" % (prefix, trial))]
+        assert truth[0] == ["DESC", "FID", "chimp", "-1", "human", "-3", "mouse", "-5", "rat", "-7", "dog"]
+        assert len(truth) == len(got)
+    L.orc_matrices_free(h)
+
+
+def test_example_script_runs_end_to_end(shell, tmp_path):
+    # example/cafe_script.sh: load; tree; lambda -s -t <2 classes>; lambda -l; genfamily; lhtest
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+    path = os.path.join(GOLD, "example_data.tab")
+    os.makedirs(tmp_path / "rndtree")
+    shell.dispatch("date")
+    shell.dispatch("seed 3")
+    shell.dispatch("load -i %s -p 0.01 -t 10 -l %s" % (path, tmp_path / "log.txt"))
+    shell.dispatch("tree " + newick)
+    shell.dispatch("lambda -s -t (((2,2)1,(1,1)1)1,1)")
+    # class 1 carries dog's branch of 93 (finite likelihood needs lambda * 93 < 1), class 2 the chimp/human cherry
+    assert len(shell.params) == 2 and 0 < shell.params[0] * 93 < 1 and 0 < shell.params[1] * 6 < 1
+    two_class_score = shell.score
+    shell.dispatch("lambda -l 0.0017")
+    shell.dispatch("genfamily %s -t 3" % (tmp_path / "rndtree" / "rnd"))
+    out = tmp_path / "lh2.out"
+    shell.dispatch("lhtest -d %s -l 0.0017 -t (((2,2)1,(1,1)1)1,1) -o %s" % (tmp_path / "rndtree", out))
+    rows = [l.rstrip("\n").split("\t") for l in open(out)]
+    assert len(rows) == 3
+    for r in rows:
+        assert r[0] == "" and len(r) == 6          # "\t<lnL global>\t<lambda>\t<lnL 2 classes>\t<l1>\t<l2>"
+        l_global, lam_g, l_two = float(r[1]), float(r[2]), float(r[3])
+        assert np.isfinite(l_global) and np.isfinite(l_two)
+        assert l_two >= l_global - 1e-3             # the nested 2-class model cannot fit worse
+        assert 0 < lam_g * 93 < 1
+    assert np.isfinite(two_class_score)
+    shell.dispatch("date")
+
+
+def test_pvalue_save_load_roundtrip_and_idx(shell, tmp_path, capfd):
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+    path = os.path.join(GOLD, "example_data.tab")
+    shell.dispatch("seed 10")
+    shell.dispatch("load -i %s -t 1 -r 200" % path)
+    shell.dispatch("tree " + newick)
+    shell.dispatch("lambda -l 0.0017")
+    f = tmp_path / "cd.txt"
+    shell.dispatch("pvalue -o %s" % f)
+    cd = np.loadtxt(f)
+    assert cd.shape == (42, 200) and np.all(np.diff(cd, axis=1) >= 0)   # R root sizes x trials, sorted
+    shell.dispatch("pvalue -i %s" % f)
+    shell.dispatch("pvalue -idx 3")
+    out = capfd.readouterr().out
+    lines = [l.split("\t") for l in out.strip().splitlines() if l and l[0].isdigit()]
+    assert len(lines) == 42 and lines[0][0] == "1" and all(0 <= float(l[2]) <= 1 for l in lines)
