@@ -122,9 +122,21 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
                                                          const double* __restrict__ lncB,
                                                          int ld_lnc, double* __restrict__ PT,
                                                          int M, int LD, int KP, int32_t* first_zero,
-                                                         int keys_per_block)
+                                                         int keys_per_block, EvalParams* __restrict__ ep_dev,
+                                                         int n_nodes, int n_prior, int nkeys)
 {
+    // `ep` is this evaluation's parameter block in PINNED HOST memory (read over the fabric: one 56-byte
+    // KeyParam per workgroup); block (0,0,0) mirrors the parts the later kernels need (node -> key map,
+    // log prior) into device memory, so an evaluation needs no separate host-to-device copy.
     extern __shared__ double k1_smem[];
+    // issue the (slow, host-memory) read of this block's first key before the table staging so that the
+    // two latencies overlap
+    const KeyParam kp_first = ep->keys[min((int)blockIdx.z * keys_per_block, nkeys - 1)];
+    if (ep_dev && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        if (threadIdx.x == 0) ep_dev->nkeys = nkeys;
+        for (int i = threadIdx.x; i < n_nodes; i += 256) ep_dev->node_key[i] = ep->node_key[i];
+        for (int i = threadIdx.x; i < n_prior; i += 256) ep_dev->logprior[i] = ep->logprior[i];
+    }
     const int s0 = blockIdx.y * 16;
     const int c0 = blockIdx.x * 16;
     const int tx = threadIdx.x & 15;  // s within tile
@@ -178,9 +190,9 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
     }
     if (s > M || c > M) return;
     const int m = min(s, c);
-    const int key_end = min(ep->nkeys, (int)(blockIdx.z + 1) * keys_per_block);
+    const int key_end = min(nkeys, (int)(blockIdx.z + 1) * keys_per_block);
     for (int key = blockIdx.z * keys_per_block; key < key_end; ++key) {
-        const KeyParam kp = ep->keys[key];
+        const KeyParam kp = (key == (int)blockIdx.z * keys_per_block) ? kp_first : ep->keys[key];
         double p;
         if (s == 0) {
             p = (c == 0) ? 1.0 : 0.0;  // row 0 is e_0 in every mode (libtree/birthdeath.c:244, :212-215)
@@ -651,6 +663,8 @@ struct cafehip_ctx {
     EvalParams* h_params[kParamRing] = {};
     hipEvent_t h_params_ev[kParamRing] = {};
     int ring_pos = 0;
+    const EvalParams* cur_params = nullptr;  // staged block the next K1 launch reads
+    int cur_prior_n = 0, cur_slot = 0;
     EvalParams* d_params = nullptr;
     std::vector<int> node_key;
     int nkeys = 0;
@@ -760,14 +774,16 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
         for (int j = 0; j < c->R; ++j) h->logprior[j] = std::log(prior[j]);
     }
     *out_h = h;
-    const size_t bytes = prior ? sizeof(EvalParams) : offsetof(EvalParams, logprior);
-    HIP_TRY(hipMemcpyAsync(c->d_params, h, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->h_params_ev[slot], c->stream));
+    c->cur_params = h;
+    c->cur_prior_n = prior ? c->R : 0;
+    c->cur_slot = slot;
     return 0;
 }
 
 int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr)
 {
+    const EvalParams* hp = c->cur_params;  // pinned host block staged by stage_params
+    const int n_prior = c->cur_prior_n;
     if (c->nkeys == 0) return 0;
     // table rows are staged once per workgroup and reused for keys_per_block keys; keep >= ~3 workgroups
     // per CU in flight
@@ -792,19 +808,25 @@ int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr)
     if (product) {
         // every key of this evaluation qualifies: the staged tables are exp(ln C)
         if (use_lds)
-            hipLaunchKernelGGL((k1_build_matrices<true, true>), grid, dim3(256), lds, c->stream, c->d_params,
-                               c->d_expA, c->d_expB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb);
+            hipLaunchKernelGGL((k1_build_matrices<true, true>), grid, dim3(256), lds, c->stream, hp,
+                               c->d_expA, c->d_expB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb,
+                               c->d_params, c->n_nodes, n_prior, c->nkeys);
         else
-            hipLaunchKernelGGL((k1_build_matrices<false, true>), grid, dim3(256), 0, c->stream, c->d_params,
-                               c->d_expA, c->d_expB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb);
+            hipLaunchKernelGGL((k1_build_matrices<false, true>), grid, dim3(256), 0, c->stream, hp,
+                               c->d_expA, c->d_expB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb,
+                               c->d_params, c->n_nodes, n_prior, c->nkeys);
     } else if (use_lds) {
-        hipLaunchKernelGGL((k1_build_matrices<true, false>), grid, dim3(256), lds, c->stream, c->d_params,
-                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb);
+        hipLaunchKernelGGL((k1_build_matrices<true, false>), grid, dim3(256), lds, c->stream, hp,
+                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb,
+                           c->d_params, c->n_nodes, n_prior, c->nkeys);
     } else {
-        hipLaunchKernelGGL((k1_build_matrices<false, false>), grid, dim3(256), 0, c->stream, c->d_params,
-                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb);
+        hipLaunchKernelGGL((k1_build_matrices<false, false>), grid, dim3(256), 0, c->stream, hp,
+                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb,
+                           c->d_params, c->n_nodes, n_prior, c->nkeys);
     }
     HIP_TRY(hipGetLastError());
+    // the pinned block may be rewritten once this launch has consumed it
+    HIP_TRY(hipEventRecord(c->h_params_ev[c->cur_slot], c->stream));
     c->have_matrices = true;
     return 0;
 }
@@ -1266,7 +1288,7 @@ int cafehip_create(cafehip_ctx** out, int device_id)
     c->stream = c->own_stream;
     HIP_TRY(hipMalloc(&c->d_params, sizeof(EvalParams)));
     for (int i = 0; i < kParamRing; ++i) {
-        HIP_TRY(hipHostMalloc(&c->h_params[i], sizeof(EvalParams), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&c->h_params[i], sizeof(EvalParams), hipHostMallocMapped | hipHostMallocCoherent));
         memset(c->h_params[i], 0, sizeof(EvalParams));
         HIP_TRY(hipEventCreateWithFlags(&c->h_params_ev[i], hipEventDisableTiming));
     }
