@@ -914,7 +914,8 @@ int launch_mfma_nrt(cafehip_ctx* c, const K2MfmaArgs& a, int nrt_w, int grid, in
 
 size_t mfma_lds_bytes(const cafehip_ctx* c, int nf)
 {
-    return (size_t)nf * c->LDv * sizeof(double) + (size_t)nf * c->n_leaves * 4 + (size_t)nf * 4;
+    return (size_t)nf * c->LDv * sizeof(double) + (size_t)nf * c->n_leaves * 4 + (size_t)nf * 4 +
+           c->msched.ops.size() * (sizeof(cafehip::MfmaOp) + 2 * sizeof(int));
 }
 
 // Cost model fitted to sweeps on MI355X (tools/sweep_k2.py): every workgroup is resident at once,

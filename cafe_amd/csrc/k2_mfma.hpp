@@ -109,6 +109,10 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     extern __shared__ double Lbuf[];                          // [NF][LDv]
     int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv);  // [NF][n_leaves]
     int* s_colmax = s_cnt + a.NF * a.n_leaves;                // [NF]
+    // the walk's step list and each step's matrix index, copied to LDS once: the step loop then never
+    // waits on a chain of dependent global loads (step record -> node_key -> matrix base)
+    int* s_ops = s_colmax + a.NF;                             // [n_ops][12]  (cafehip::MfmaOp)
+    int* s_key = s_ops + a.n_ops * 12;                        // [n_ops][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -132,12 +136,14 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
         const int u = fam0 + f;
         s_colmax[f] = (batch && u < a.Fu) ? a.col_max[u] : (a.C - 1);
     }
+    for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
+    for (int i = tid; i < a.n_ops * 2; i += blockDim.x) s_key[i] = a.ep->node_key[a.ops[i >> 1].child[i & 1]];
     __syncthreads();
 
     cafe_d4 hold[NFT_W][NRT_W];
 
     for (int oi = 0; oi < a.n_ops; ++oi) {
-        const cafehip::MfmaOp op = a.ops[oi];
+        const cafehip::MfmaOp op = *reinterpret_cast<const cafehip::MfmaOp*>(s_ops + oi * 12);
         const int rows = op.is_root ? a.R : a.C;
         const int row_lo = op.is_root ? a.root_min : 0;
         const int RT = (rows + 15) >> 4;           // row tiles of this step, dealt evenly to the Wr wave rows
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            const double* PTe = a.PT + (size_t)a.ep->node_key[op.child[ch]] * a.KP * a.LD + row_lo;
+            const double* PTe = a.PT + (size_t)s_key[oi * 2 + ch] * a.KP * a.LD + row_lo;
             const bool errleaf = (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.leafcol[ch]];
             cafe_d4 fac[NFT_W][NRT_W];
             if (errleaf && a.err_banded) {
@@ -372,6 +378,10 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     extern __shared__ double Lbuf[];                          // [NF][LDv]
     int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv);  // [NF][n_leaves]
     int* s_colmax = s_cnt + a.NF * a.n_leaves;                // [NF]
+    // the walk's step list and each step's matrix index, copied to LDS once: the step loop then never
+    // waits on a chain of dependent global loads (step record -> node_key -> matrix base)
+    int* s_ops = s_colmax + a.NF;                             // [n_ops][12]  (cafehip::MfmaOp)
+    int* s_key = s_ops + a.n_ops * 12;                        // [n_ops][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -395,12 +405,14 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         const int u = fam0 + f;
         s_colmax[f] = (batch && u < a.Fu) ? a.col_max[u] : (a.C - 1);
     }
+    for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
+    for (int i = tid; i < a.n_ops * 2; i += blockDim.x) s_key[i] = a.ep->node_key[a.ops[i >> 1].child[i & 1]];
     __syncthreads();
 
     double hold[G][NRT_W];
 
     for (int oi = 0; oi < a.n_ops; ++oi) {
-        const cafehip::MfmaOp op = a.ops[oi];
+        const cafehip::MfmaOp op = *reinterpret_cast<const cafehip::MfmaOp*>(s_ops + oi * 12);
         const int rows = op.is_root ? a.R : a.C;
         const int row_lo = op.is_root ? a.root_min : 0;
         const int RT = (rows + 15) >> 4;
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            const double* PTe = a.PT + (size_t)a.ep->node_key[op.child[ch]] * a.KP * a.LD + row_lo;
+            const double* PTe = a.PT + (size_t)s_key[oi * 2 + ch] * a.KP * a.LD + row_lo;
             const bool errleaf = (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.leafcol[ch]];
             double fac[G][NRT_W];
             if (errleaf && a.err_banded) {
