@@ -912,9 +912,20 @@ int launch_mfma_nrt(cafehip_ctx* c, const K2MfmaArgs& a, int nrt_w, int grid, in
     return fail("unsupported NRT_W %d", nrt_w);
 }
 
+// The park buffers (node vectors waiting for their sibling) stay in LDS when the whole set still lets two
+// workgroups share a CU; otherwise they live in global scratch and are fetched back when consumed.
+bool mfma_lds_parks(const cafehip_ctx* c, int nf)
+{
+    const char* e = getenv("CAFEHIP_LDSPARK");
+    if (e && atoi(e) == 0) return false;
+    if (c->msched.n_parks <= 0) return false;
+    return (size_t)nf * c->LDv * sizeof(double) * (1 + c->msched.n_parks) <= (size_t)72 * 1024;
+}
+
 size_t mfma_lds_bytes(const cafehip_ctx* c, int nf)
 {
-    return (size_t)nf * c->LDv * sizeof(double) + (size_t)nf * c->n_leaves * 4 + (size_t)nf * 4 +
+    return (size_t)nf * c->LDv * sizeof(double) * (mfma_lds_parks(c, nf) ? 1 + c->msched.n_parks : 1) +
+           (size_t)nf * c->n_leaves * 4 + (size_t)nf * 4 +
            c->msched.ops.size() * (sizeof(cafehip::MfmaOp) + 2 * sizeof(int));
 }
 
@@ -1128,6 +1139,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     a.NF = nf;
     a.park = c->d_park;
     a.n_parks = std::max(c->msched.n_parks, 1);
+    a.lds_parks = mfma_lds_parks(c, nf) ? 1 : 0;
     a.err = v1.err;
     a.err_ld = v1.err_ld;
     a.leaf_has_err = v1.leaf_has_err;

@@ -27,6 +27,7 @@ struct K2MfmaArgs {
     const EvalParams* ep;
     const cafehip::MfmaOp* ops;
     int n_ops;
+    int lds_parks;         // 1: the park buffers live in LDS behind the node buffer (no global round trip)
     const int32_t* counts;
     int Fu;
     int n_leaves;
@@ -107,7 +108,7 @@ template <int NFT_W, int NRT_W>
 __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 {
     extern __shared__ double Lbuf[];                          // [NF][LDv]
-    int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv);  // [NF][n_leaves]
+    int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv * (a.lds_parks ? 1 + a.n_parks : 1));  // [NF][n_leaves]
     int* s_colmax = s_cnt + a.NF * a.n_leaves;                // [NF]
     // the walk's step list and each step's matrix index, copied to LDS once: the step loop then never
     // waits on a chain of dependent global loads (step record -> node_key -> matrix base)
@@ -120,7 +121,9 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     const int li = lane & 15;   // row within a tile (B/D) or family within a tile (A)
     const int lk = lane >> 4;   // k within a step (A/B) or family group within a tile (D)
     const int wf = wave % a.Wf;
-    const int wr = wave / a.Wf;
+    // workgroups of the second dispatch round share a CU with one of the first: rotate their row-tile deal by
+    // half so that the waves carrying the odd extra tile do not pile up on the same SIMDs
+    const int wr = (wave / a.Wf + ((blockIdx.x >> 8) & 1) * (a.Wr >> 1)) % a.Wr;
     const int ft0 = wf * NFT_W;
     const int fam0 = blockIdx.x * a.NF;
     const bool batch = (a.col_max != nullptr);
@@ -197,7 +200,10 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                     }
                 }
             } else {
-                if (op.kind[ch] == 1 && op.src_park[ch] >= 0) {
+                const double* Lsrc = Lbuf;
+                if (op.kind[ch] == 1 && op.src_park[ch] >= 0 && a.lds_parks) {
+                    Lsrc = Lbuf + (size_t)(1 + op.src_park[ch]) * park_stride;  // read the parked vector in place
+                } else if (op.kind[ch] == 1 && op.src_park[ch] >= 0) {
                     // fetch the parked vector into the LDS buffer
                     __syncthreads();
                     const double* src = my_park + (size_t)op.src_park[ch] * park_stride;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                     for (int j = 0; j < NRT_W; ++j)
                         boff[j] = ((j < ntile) ? (rt0 + j) : rt0) * 16;  // inactive tiles re-read tile rt0
                     const double* bp = PTe + (size_t)lk * a.LD + li;
-                    const double* ap = Lbuf + (size_t)(ft0 * 16 + li) * a.LDv + lk;
+                    const double* ap = Lsrc + (size_t)(ft0 * 16 + li) * a.LDv + lk;
                     mfma_edge<NFT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
                 }
             }
@@ -241,32 +247,45 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
         }
 
         // ---- result: Hadamard product in `hold` (D layout) -> LDS buffer or park ----
-        double* dst;
-        if (op.dst_park >= 0) {
-            dst = my_park + (size_t)op.dst_park * park_stride;
-        } else {
-            __syncthreads();  // every wave is done reading the buffer: overwrite in place
-            dst = Lbuf;
-        }
+        // (two explicit address spaces: a pointer that may be either makes every store a flat_store)
+        if (op.dst_park >= 0 && !a.lds_parks) {
+            double* dst = my_park + (size_t)op.dst_park * park_stride;
 #pragma unroll
-        for (int i = 0; i < NFT_W; ++i) {
+            for (int i = 0; i < NFT_W; ++i) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = (ft0 + i) * 16 + lk + 4 * r;
-                const int cm = s_colmax[f];
+                for (int r = 0; r < 4; ++r) {
+                    const int f = (ft0 + i) * 16 + lk + 4 * r;
+                    const int cm = s_colmax[f];
 #pragma unroll
-                for (int j = 0; j < NRT_W; ++j) {
-                    if (j < ntile) {
-                        const int row = (rt0 + j) * 16 + li;
-                        double v = hold[i][j][r];
-                        // rows beyond this family's column range do not exist in the reference
-                        if (!op.is_root && row > cm) v = 0.0;
-                        dst[(size_t)f * a.LDv + row] = v;
+                    for (int j = 0; j < NRT_W; ++j) {
+                        if (j < ntile) {
+                            const int row = (rt0 + j) * 16 + li;
+                            // rows beyond this family's column range do not exist in the reference
+                            dst[(size_t)f * a.LDv + row] = (!op.is_root && row > cm) ? 0.0 : hold[i][j][r];
+                        }
                     }
                 }
             }
+        } else {
+            __syncthreads();  // every wave is done reading the buffers: overwrite in place
+            double* dst = Lbuf + ((op.dst_park >= 0) ? (size_t)(1 + op.dst_park) * park_stride : 0);
+#pragma unroll
+            for (int i = 0; i < NFT_W; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = (ft0 + i) * 16 + lk + 4 * r;
+                    const int cm = s_colmax[f];
+#pragma unroll
+                    for (int j = 0; j < NRT_W; ++j) {
+                        if (j < ntile) {
+                            const int row = (rt0 + j) * 16 + li;
+                            dst[f * a.LDv + row] = (!op.is_root && row > cm) ? 0.0 : hold[i][j][r];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
         }
-        if (op.dst_park < 0) __syncthreads();
     }
 
     // ---- root vector (in Lbuf) -> posterior (cafe/lambda.cpp:657-689) or packed root rows ----
@@ -376,7 +395,7 @@ template <int G, int NRT_W>
 __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 {
     extern __shared__ double Lbuf[];                          // [NF][LDv]
-    int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv);  // [NF][n_leaves]
+    int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv * (a.lds_parks ? 1 + a.n_parks : 1));  // [NF][n_leaves]
     int* s_colmax = s_cnt + a.NF * a.n_leaves;                // [NF]
     // the walk's step list and each step's matrix index, copied to LDS once: the step loop then never
     // waits on a chain of dependent global loads (step record -> node_key -> matrix base)
@@ -389,7 +408,9 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     const int li = lane & 15;
     const int lk = lane >> 4;
     const int wf = wave % a.Wf;
-    const int wr = wave / a.Wf;
+    // workgroups of the second dispatch round share a CU with one of the first: rotate their row-tile deal by
+    // half so that the waves carrying the odd extra tile do not pile up on the same SIMDs
+    const int wr = (wave / a.Wf + ((blockIdx.x >> 8) & 1) * (a.Wr >> 1)) % a.Wr;
     const int fbase = wf * 4 * G;               // first family of this wave inside the workgroup
     const int fam0 = blockIdx.x * a.NF;
     const bool batch = (a.col_max != nullptr);
@@ -421,8 +442,32 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         const int rt0 = wr * rt_base + min(wr, rt_rem);
         const bool wave_active = ntile > 0;
 
+        // one-hot leaf child next to a child that needs the matrix cores: issue its column gathers first so
+        // that their latency hides under the sibling's product (the Hadamard product commutes exactly)
+        bool simple[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+            simple[ch] = (op.kind[ch] == 0) && !(a.err != nullptr && a.leaf_has_err[op.leafcol[ch]]);
+        const int pre_ch = (simple[1] && !simple[0]) ? 1 : ((simple[0] && !simple[1]) ? 0 : -1);
+        double pre[G][NRT_W];
+        if (pre_ch >= 0) {
+            const double* PTe = a.PT + (size_t)s_key[oi * 2 + pre_ch] * a.KP * a.LD + row_lo;
+            const int leafcol = pre_ch ? op.leafcol[1] : op.leafcol[0];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int f = fbase + 4 * g + lk;
+                const int cnt = s_cnt[f * a.n_leaves + leafcol];
+                const bool ok = cnt <= s_colmax[f];
+#pragma unroll
+                for (int j = 0; j < NRT_W; ++j)
+                    pre[g][j] = (ok && j < ntile) ? PTe[(size_t)cnt * a.LD + (rt0 + j) * 16 + li] : 0.0;
+            }
+        }
+
+        bool first = true;
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
+            if (ch == pre_ch) continue;
             const double* PTe = a.PT + (size_t)s_key[oi * 2 + ch] * a.KP * a.LD + row_lo;
             const bool errleaf = (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.leafcol[ch]];
             double fac[G][NRT_W];
@@ -453,7 +498,10 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                         fac[g][j] = (ok && j < ntile) ? PTe[(size_t)cnt * a.LD + (rt0 + j) * 16 + li] : 0.0;
                 }
             } else {
-                if (op.kind[ch] == 1 && op.src_park[ch] >= 0) {
+                const double* Lsrc = Lbuf;
+                if (op.kind[ch] == 1 && op.src_park[ch] >= 0 && a.lds_parks) {
+                    Lsrc = Lbuf + (size_t)(1 + op.src_park[ch]) * park_stride;
+                } else if (op.kind[ch] == 1 && op.src_park[ch] >= 0) {
                     __syncthreads();
                     const double* src = my_park + (size_t)op.src_park[ch] * park_stride;
                     for (int i = tid; i < a.NF * a.LDv; i += blockDim.x) Lbuf[i] = src[i];
@@ -476,38 +524,54 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 #pragma unroll
                     for (int j = 0; j < NRT_W; ++j) boff[j] = ((j < ntile) ? (rt0 + j) : rt0) * 16;
                     const double* bp = PTe + (size_t)lk * a.LD + li;
-                    const double* ap4 = Lbuf + (size_t)(fbase + (lane & 3)) * a.LDv + lk;
+                    const double* ap4 = Lsrc + (size_t)(fbase + (lane & 3)) * a.LDv + lk;
                     mfma4_edge<G, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
                 }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int j = 0; j < NRT_W; ++j) hold[g][j] = (ch == 0) ? fac[g][j] : hold[g][j] * fac[g][j];
+                for (int j = 0; j < NRT_W; ++j) hold[g][j] = first ? fac[g][j] : hold[g][j] * fac[g][j];
+            first = false;
+        }
+        if (pre_ch >= 0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int j = 0; j < NRT_W; ++j) hold[g][j] *= pre[g][j];
         }
 
-        double* dst;
-        if (op.dst_park >= 0) {
-            dst = my_park + (size_t)op.dst_park * park_stride;
-        } else {
-            __syncthreads();
-            dst = Lbuf;
-        }
+        if (op.dst_park >= 0 && !a.lds_parks) {
+            double* dst = my_park + (size_t)op.dst_park * park_stride;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int f = fbase + 4 * g + lk;
-            const int cm = s_colmax[f];
+            for (int g = 0; g < G; ++g) {
+                const int f = fbase + 4 * g + lk;
+                const int cm = s_colmax[f];
 #pragma unroll
-            for (int j = 0; j < NRT_W; ++j) {
-                if (j < ntile) {
-                    const int row = (rt0 + j) * 16 + li;
-                    double v = hold[g][j];
-                    if (!op.is_root && row > cm) v = 0.0;
-                    dst[(size_t)f * a.LDv + row] = v;
+                for (int j = 0; j < NRT_W; ++j) {
+                    if (j < ntile) {
+                        const int row = (rt0 + j) * 16 + li;
+                        dst[(size_t)f * a.LDv + row] = (!op.is_root && row > cm) ? 0.0 : hold[g][j];
+                    }
                 }
             }
+        } else {
+            __syncthreads();
+            double* dst = Lbuf + ((op.dst_park >= 0) ? (size_t)(1 + op.dst_park) * park_stride : 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int f = fbase + 4 * g + lk;
+                const int cm = s_colmax[f];
+#pragma unroll
+                for (int j = 0; j < NRT_W; ++j) {
+                    if (j < ntile) {
+                        const int row = (rt0 + j) * 16 + li;
+                        dst[f * a.LDv + row] = (!op.is_root && row > cm) ? 0.0 : hold[g][j];
+                    }
+                }
+            }
+            __syncthreads();
         }
-        if (op.dst_park < 0) __syncthreads();
     }
 
     const int nwaves = blockDim.x >> 6;
