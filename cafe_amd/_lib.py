@@ -45,6 +45,7 @@ HOST_SIGNATURES = {
     "cafehost_shard_bounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cafehost_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cafehost_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cafehost_set_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cafehost_upload": (C.c_int, [C.c_void_p]),
     "cafehost_num_params": (C.c_int, [C.c_void_p]),
     "cafehost_get_params": (C.c_int, [C.c_void_p, _dp, C.c_int]),

@@ -506,6 +506,37 @@ struct cafehost_session {
     void* exchange_user = nullptr;
     double* d_exch_chunks = nullptr;
     int32_t* d_exch_fz = nullptr;
+    cafehost_allgather_fn allgather = nullptr;  // report / Monte-Carlo null sharding
+    void* allgather_user = nullptr;
+
+    bool report_sharded() const { return shard_world > 1 && allgather != nullptr; }
+    // contiguous block of [0, n) owned by rank r
+    void block_of(int n, int r, int& lo, int& hi) const
+    {
+        const int base = n / shard_world, extra = n % shard_world;
+        lo = r * base + std::min(r, extra);
+        hi = lo + base + (r < extra ? 1 : 0);
+    }
+    // Every rank contributes `bytes_of(rank)` bytes (sizes are a function of the shared table, so every rank
+    // knows them all); returns the blocks concatenated in rank order.  One collective.
+    template <class SizeFn>
+    std::vector<char> gather_blocks(const void* mine, SizeFn bytes_of)
+    {
+        long long slot = 0, total = 0;
+        for (int r = 0; r < shard_world; ++r) {
+            slot = std::max<long long>(slot, bytes_of(r));
+            total += bytes_of(r);
+        }
+        std::vector<char> all((size_t)std::max<long long>(slot, 1) * shard_world), out((size_t)total);
+        if (allgather(allgather_user, mine, bytes_of(shard_rank), all.data(), std::max<long long>(slot, 1)) != 0)
+            throw std::runtime_error("allgather callback failed");
+        size_t o = 0;
+        for (int r = 0; r < shard_world; ++r) {
+            memcpy(out.data() + o, all.data() + (size_t)r * std::max<long long>(slot, 1), (size_t)bytes_of(r));
+            o += (size_t)bytes_of(r);
+        }
+        return out;
+    }
 
     // model state
     int num_lambdas = 1, num_mus = 0, num_params = 0;
@@ -1088,7 +1119,24 @@ struct cafehost_session {
             }
         }
         std::vector<double> probs((size_t)R * trials);
-        hip_check(cafehip_eval_root_likelihoods(ctx, R * trials, counts.data(), lo.data(), hi.data(), cm.data(), probs.data()));
+        if (report_sharded()) {
+            // the draws above follow the reference's global order on every rank; the likelihoods of the simulated
+            // families are sharded by root size (as the reference's threads are, cafe/conditional_distribution.cpp:88-108)
+            int r0, r1;
+            block_of(R, shard_rank, r0, r1);
+            const size_t b0 = (size_t)r0 * trials, nb = (size_t)(r1 - r0) * trials;
+            if (nb)
+                hip_check(cafehip_eval_root_likelihoods(ctx, (int)nb, counts.data() + b0 * nl, lo.data() + b0, hi.data() + b0,
+                                                        cm.data() + b0, probs.data() + b0));
+            auto all = gather_blocks(probs.data() + b0, [&](int r) {
+                int a, b;
+                block_of(R, r, a, b);
+                return (long long)(b - a) * trials * (long long)sizeof(double);
+            });
+            memcpy(probs.data(), all.data(), all.size());
+        } else {
+            hip_check(cafehip_eval_root_likelihoods(ctx, R * trials, counts.data(), lo.data(), hi.data(), cm.data(), probs.data()));
+        }
         cond_dist.assign(R, std::vector<double>(trials));
         for (int i = 0; i < R; ++i) {
             std::copy(probs.begin() + (size_t)i * trials, probs.begin() + (size_t)(i + 1) * trials, cond_dist[i].begin());
@@ -1147,9 +1195,33 @@ struct cafehost_session {
             off_call[i + 1] = off_call[i] + (hi_call[i] - lo[i] + 1);
         }
         std::vector<double> like((size_t)std::max<int64_t>(off_call[F], 1));
-        if (F) hip_check(cafehip_eval_root_likelihoods(ctx, F, counts.data(), lo.data(), hi_call.data(), cm.data(), like.data()));
         rep_sizes.assign((size_t)F * n, 0);
-        if (F) hip_check(cafehip_viterbi(ctx, F, counts.data(), lo.data(), hi.data(), cm.data(), rep_sizes.data()));
+        if (F && report_sharded()) {
+            // each rank scores and back-tracks a contiguous block of the families; two gathers rebuild the full arrays
+            int f0, f1;
+            block_of(F, shard_rank, f0, f1);
+            if (f1 > f0) {
+                hip_check(cafehip_eval_root_likelihoods(ctx, f1 - f0, counts.data() + (size_t)f0 * nl, lo.data() + f0,
+                                                        hi_call.data() + f0, cm.data() + f0, like.data() + off_call[f0]));
+                hip_check(cafehip_viterbi(ctx, f1 - f0, counts.data() + (size_t)f0 * nl, lo.data() + f0, hi.data() + f0,
+                                          cm.data() + f0, rep_sizes.data() + (size_t)f0 * n));
+            }
+            auto all_like = gather_blocks(like.data() + off_call[f0], [&](int r) {
+                int a, b;
+                block_of(F, r, a, b);
+                return (long long)(off_call[b] - off_call[a]) * (long long)sizeof(double);
+            });
+            memcpy(like.data(), all_like.data(), all_like.size());
+            auto all_sizes = gather_blocks(rep_sizes.data() + (size_t)f0 * n, [&](int r) {
+                int a, b;
+                block_of(F, r, a, b);
+                return (long long)(b - a) * n * (long long)sizeof(int32_t);
+            });
+            memcpy(rep_sizes.data(), all_sizes.data(), all_sizes.size());
+        } else if (F) {
+            hip_check(cafehip_eval_root_likelihoods(ctx, F, counts.data(), lo.data(), hi_call.data(), cm.data(), like.data()));
+            hip_check(cafehip_viterbi(ctx, F, counts.data(), lo.data(), hi.data(), cm.data(), rep_sizes.data()));
+        }
 
         rep_max_p.assign(F, 0.0);
         rep_branch_p.assign((size_t)F * (n - 1), -1.0);
@@ -1198,6 +1270,10 @@ struct cafehost_session {
         for (double& v : avg_exp) v /= std::max(F, 1);
 
         // ---- text report: operator<<(ostream&, const Report&), cafe/reports.cpp:453-501 ----
+        if (shard_world > 1 && shard_rank != 0) {  // one writer
+            log("Report Done\n");
+            return 0;
+        }
         const std::string filename = name + ".cafe";
         FILE* fp = fopen(filename.c_str(), "w");
         if (!fp) throw std::runtime_error("ERROR(report) : Cannot open " + name + " in write mode.\n");
@@ -1604,6 +1680,7 @@ struct cafehost_session {
             std::vector<std::vector<double>> mats;
             const int S = fetch_matrices(mats);
             compute_conditional_distribution(mats, S);
+            if (shard_world > 1 && shard_rank != 0) return 0;  // one writer
             FILE* fp = fopen(outfile.c_str(), "w");
             if (!fp) throw std::runtime_error("ERROR(pvalue): Cannot open " + outfile + " in write mode.");
             // write_pvalues, cafe/pvalue.cpp:63-77 (the reference passes a zeroed copy here, cafe_commands.cpp:1351-1361;
@@ -1811,6 +1888,14 @@ int cafehost_set_exchange(cafehost_session* s, cafehost_exchange_fn exchange, vo
     s->exchange_user = user;
     s->d_exch_chunks = (double*)d_chunk_sums;
     s->d_exch_fz = (int32_t*)d_first_zero;
+    return 0;
+}
+
+int cafehost_set_allgather(cafehost_session* s, cafehost_allgather_fn fn, void* user)
+{
+    if (!s) return host_fail("null session");
+    s->allgather = fn;
+    s->allgather_user = user;
     return 0;
 }
 

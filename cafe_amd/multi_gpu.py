@@ -18,6 +18,7 @@ from . import distributed as D
 from .shell import CafeShell
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_int))
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong)
 
 
 class MultiGpuShell(CafeShell):
@@ -33,6 +34,25 @@ class MultiGpuShell(CafeShell):
             self._check(self._L.cafehost_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         self._cb = None
         self._wired = False
+
+        def allgather(_user, mine, nbytes_mine, out, slot):
+            # report / Monte-Carlo null: one fixed-slot all_gather of this rank's block of results
+            try:
+                buf = torch.zeros(slot, dtype=torch.uint8, device=self.device)
+                if nbytes_mine:
+                    src = np.ctypeslib.as_array(C.cast(mine, C.POINTER(C.c_uint8)), shape=(nbytes_mine,))
+                    buf[:nbytes_mine] = torch.from_numpy(src.copy()).to(self.device)
+                gathered = torch.empty(slot * self.world, dtype=torch.uint8, device=self.device)
+                dist.all_gather_into_tensor(gathered, buf)
+                dst = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(slot * self.world,))
+                dst[:] = gathered.cpu().numpy()
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("allgather failed:", e, file=sys.stderr, flush=True)
+                return -1
+
+        self._ag = ALLGATHER_FN(allgather)
+        self._check(self._L.cafehost_set_allgather(self._h, C.cast(self._ag, C.c_void_p), None))
 
     def _wire(self):
         """Size and register the exchange buffers (needs tree + table)."""

@@ -47,6 +47,16 @@ int cafehost_set_shard(cafehost_session *s, int rank, int world);
 int cafehost_shard_bounds(cafehost_session *s, int *lo, int *hi, int *n_chunks_local);
 int cafehost_set_exchange(cafehost_session *s, cafehost_exchange_fn exchange, void *user,
                           void *d_chunk_sums, void *d_first_zero);
+/* `report` and `pvalue` (Monte-Carlo null, per-family root likelihoods, Viterbi): with an allgather callback
+ * registered the simulated families are sharded by root size (as the reference's threads are,
+ * cafe/conditional_distribution.cpp:88-108) and the observed families by contiguous block; the callback
+ * receives this rank's `nbytes_mine` bytes and must fill `all` with world slots of `nbytes_slot` bytes each
+ * (rank order, own data first in its slot).  Random draws stay on the host in the reference's global
+ * order, so the output does not depend on the number of ranks.  Only rank 0 writes files.  Without a
+ * callback every rank computes everything. */
+typedef int (*cafehost_allgather_fn)(void *user, const void *mine, long long nbytes_mine, void *all,
+                                     long long nbytes_slot);
+int cafehost_set_allgather(cafehost_session *s, cafehost_allgather_fn fn, void *user);
 int cafehost_set_stream(cafehost_session *s, void *hip_stream);
 /* Upload tree + (sharded) table now instead of at the first lambda command (so that the caller can size
  * its exchange buffers from cafehost_shard_bounds). */

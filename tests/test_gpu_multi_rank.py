@@ -54,3 +54,23 @@ def test_sharded_search_equals_single_gpu(tmp_path, nproc):
     pm, sm, itm, evm = _run_multi(str(script), nproc, 29620 + nproc)
     assert pm == p1 and sm == s1 and itm == it1 and evm == ev1
     assert p1[0] == pytest.approx(g["search_result"]["lambda"], abs=2e-7)
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_sharded_report_equals_golden_test2_cafe(tmp_path, nproc):
+    # `report` on several ranks: the Monte-Carlo null is sharded by root size, the observed families by block,
+    # rank 0 writes the file -- which must still be the reference's golden text (seed 10, -t 1 draw order)
+    g = TR["test2"]
+    out = str(tmp_path / "test2")
+    lines = ["seed 10", "load -i %s -p 0.05 -max_size 20" % os.path.join(GOLD, "test2_families.txt"),
+             "tree " + g["newick"], "lambda -s", "report " + out, "pvalue -o " + out + ".pv"]
+    script = tmp_path / "run.sh"
+    script.write_text("\n".join(lines) + "\n")
+    _run_multi(str(script), nproc, 29640 + nproc)
+    got = open(out + ".cafe").read().splitlines()
+    exp = open(os.path.join(GOLD, "test2.cafe")).read().splitlines()
+    assert exp[1].endswith(got[1]) and got[1] == "Lambda:\t0.00133949"
+    assert got[:1] + got[2:] == exp[:1] + exp[2:]
+    # the conditional distribution written by `pvalue -o`: root sizes x 1000 sorted likelihoods
+    rows = open(out + ".pv").read().splitlines()
+    assert len(rows) == 30 and all(len(r.split("\t")) == 1000 for r in rows)
