@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <map>
 #include <vector>
 
 #include "../../../include/cafehip.h"
@@ -481,6 +482,8 @@ std::vector<Argument> build_argument_list(const std::vector<std::string>& tokens
 // ====================================================================================
 struct cafehost_session {
     cafehip_ctx* ctx = nullptr;
+    cafehip_ctx* ctx_one = nullptr;  // one-family evaluations (lambda -e), created on first use
+    int device_id = 0;
     GlibcRand rng;
     double unifrnd() { return rng.unifrnd(); }
     FILE* flog = stdout;
@@ -975,6 +978,153 @@ struct cafehost_session {
         log("%s\n", cmd.c_str());
     }
 
+    // ---- lambda -s -e: one Nelder-Mead search per family (cafe_each_best_lambda_by_fminsearch,
+    //      cafe/lambda.cpp:911-1010; objective __cafe_each_best_lambda_search :872-908) ----
+    // Every family is scored under ITS OWN ranges (cafe_family_set_size_with_family_forced,
+    // cafe/cafe_family.c:236-255), so the matrices are rebuilt per family at that size: a one-family table on
+    // a second device context (the "tree-level" seam of SURVEY.md section 8b routed to the batch API with F = 1).
+    // Objective = log(max_i L_root[i]) -- no prior.  Quirks kept: the optimiser object is reused across
+    // families, and because cafe_shell_set_lambda aliases param->lambda to the last parameters set
+    // (cafe/cafe_shell.c:245-251), family i+1 starts from family i's optimum (the first from 0.5 / max branch).
+    std::vector<std::vector<double>> each_lambda;  // per family fitted parameters
+    void each_family_search(const std::string& outfile)
+    {
+        if (shard_world > 1) throw std::runtime_error("lambda -e runs on one rank (it is a loop of one-family searches)");
+        if (!ctx_one && cafehip_create(&ctx_one, device_id) != 0)
+            throw std::runtime_error(std::string("cafehip: ") + cafehip_last_error());
+        hip_check(cafehip_set_tree(ctx_one, tree.n, tree.parent.data(), tree.left.data(), tree.right.data(), tree.bl.data()));
+        const int F = fam.F(), nl = tree.n_leaves(), ns = (int)fam.species.size();
+        // ref: first identical row (cafe/cafe_family.c:9-34)
+        std::vector<int> ref(F, -1);
+        {
+            std::map<std::vector<int32_t>, int> first;
+            for (int i = 0; i < F; ++i) {
+                std::vector<int32_t> row(fam.counts.begin() + (size_t)i * ns, fam.counts.begin() + (size_t)(i + 1) * ns);
+                auto it = first.find(row);
+                if (it == first.end()) first.emplace(std::move(row), i);
+                else ref[i] = it->second;
+            }
+        }
+        const double mbl = tree.max_branch_length();
+        std::vector<double> start(num_lambdas, 0.5 / mbl);
+        FMinSearch pfm;
+        pfm.init(num_lambdas);
+        pfm.tolx = 1e-6;
+        pfm.tolf = 1e-6;
+        std::vector<double> one_prior(1000, 1.0);  // unused by the max-likelihood output, must be positive
+        pfm.eq = [&](const double* x) {
+            double score = 0;
+            bool skip = false;
+            for (int i = 0; i < num_lambdas; ++i)
+                if (x[i] < 0) {
+                    skip = true;
+                    score = std::log(0.0);
+                    break;
+                }
+            if (!skip) {
+                std::vector<double> nlam, nmu;
+                node_rates(x, nlam, nmu);
+                double sc = 0, ml = 0;
+                int32_t zero = -1;
+                hip_check(cafehip_eval_posterior(ctx_one, nlam.data(), nmu.data(), one_prior.data(), &sc, &zero, &ml, nullptr, nullptr));
+                score = std::log(ml);
+            }
+            ++n_evals;
+            log("\tLambda : %s & Score: %f\n", join_double(x, num_lambdas).c_str(), score);
+            log("\n");
+            return -score;
+        };
+        auto family_tree_string = [&](int i, const std::vector<double>& x) {
+            std::vector<double> nlam, nmu;
+            node_rates(x.data(), nlam, nmu);
+            std::vector<int> size(tree.n, -1);
+            for (int s_ = 0; s_ < ns; ++s_)
+                if (species_index[s_] >= 0) size[species_index[s_]] = fam.counts[(size_t)i * ns + s_];
+            return tree_string(
+                [&](int v) {  // cafe_tree_string_familysize_lambda, cafe/cafe_tree.c:121-129
+                    if (tree.bl[v] <= 0) return std::string();
+                    char buf[96];
+                    std::string out = tree.name[v];
+                    if (size[v] >= 0) {
+                        snprintf(buf, sizeof buf, "<%d>", size[v]);
+                        out += buf;
+                    }
+                    snprintf(buf, sizeof buf, "_%lf", nlam[v]);
+                    return out + buf;
+                },
+                true);
+        };
+        each_lambda.assign(F, {});
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < F; ++i) {
+            if (ref[i] >= 0) {
+                each_lambda[i] = each_lambda[ref[i]];
+                start = each_lambda[i];  // cafe_shell_set_lambdas(param, pitem->lambda) re-aliases param->lambda
+                log("%s: Lambda Search Result of %d/%d in %d iteration \n", fam.ids[i].c_str(), i + 1, F, pfm.iters);
+                log("%s: %s\n", fam.ids[i].c_str(), family_tree_string(i, each_lambda[i]).c_str());
+                continue;
+            }
+            std::vector<int32_t> counts(nl, 0);
+            int mx = 0;
+            for (int s_ = 0; s_ < ns; ++s_) {
+                if (species_index[s_] < 0) continue;
+                const int c = fam.counts[(size_t)i * ns + s_];
+                counts[species_index[s_] / 2] = c;
+                mx = std::max(mx, c);
+            }
+            const int root_max = (int)std::rint(mx * 1.25), range_max = mx + std::max(50, mx / 5);
+            log("%s:\n", fam.ids[i].c_str());
+            if (root_max < 1) {
+                // all counts zero: root range [1, 0] is empty.  The reference then maximises over an empty root
+                // vector and reads the stale element 0 left by the previous evaluation (libcommon/mathfunc.c:26-38
+                // with size 0), so its "search" fits leftover memory.  Not reproducible and not meaningful:
+                // the family keeps the lambda the search would have started from.
+                each_lambda[i] = start;
+                log("Lambda Search Result of %d/%d in 0 iteration (empty root range: not searched)\n", i + 1, F);
+                log("%s\n", family_tree_string(i, each_lambda[i]).c_str());
+                continue;
+            }
+            hip_check(cafehip_set_families(ctx_one, 1, nl, counts.data(), nullptr, 0, range_max, 1, root_max));
+            if (err_mfs >= 0)
+                hip_check(cafehip_set_error_model(ctx_one, err_mfs, err_matrix.data(), err_leaf.data()));
+            pfm.minimize(start.data());
+            each_lambda[i] = pfm.v[0];
+            start = each_lambda[i];
+            bool near_boundary = false;
+            for (int j = 0; j < num_lambdas; ++j) {
+                const double a = each_lambda[i][j] * mbl;
+                if (a >= 0.5 || std::fabs(a - 0.5) < 1e-3) near_boundary = true;
+            }
+            log("Lambda Search Result of %d/%d in %d iteration \n", i + 1, F, pfm.iters);
+            if (near_boundary) log("Caution : at least one lambda near boundary\n");
+            if (near_boundary) log("@@ ");
+            log("%s\n", family_tree_string(i, each_lambda[i]).c_str());
+        }
+        search_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        search_iters = pfm.iters;
+        params = F ? each_lambda[F - 1] : std::vector<double>(num_lambdas, 0.5 / mbl);
+        last_score = F ? pfm.fv[0] : 0.0;
+        // per-family result table: cafe/lambda.cpp:465-497 (`-e` implies write_files; <outfile>.lambda, the
+        // .html twin is presentation and not written)
+        FILE* fp = stdout;
+        if (!outfile.empty()) {
+            fp = fopen((outfile + ".lambda").c_str(), "w");
+            if (!fp) throw std::runtime_error("Cannot open file: " + outfile + ".lambda");
+        }
+        for (int i = 0; i < F; ++i) {
+            for (int j = 0; j < num_lambdas; ++j) {
+                const double a = each_lambda[i][j] * mbl;
+                if (a >= 0.5 || std::fabs(a - 0.5) < 1e-3) {
+                    fprintf(fp, "@@ ");
+                    break;
+                }
+            }
+            fprintf(fp, "%s\t%s\n", fam.ids[i].c_str(), family_tree_string(i, each_lambda[i]).c_str());
+        }
+        if (fp != stdout) fclose(fp);
+        else fflush(stdout);
+    }
+
     int cmd_lambda(const std::vector<std::string>& tokens)
     {  // cafe_cmd_lambda, cafe/lambda.cpp:369-515
         prereqs(true, true);
@@ -985,9 +1135,12 @@ struct cafehost_session {
         checkconv = false;
         have_lambda_tree = false;
         num_lambdas = 1;
-        bool search_flag = false, score_flag = false;
+        bool search_flag = false, score_flag = false, each = false;
         double vlambda = -1;
         std::vector<double> lambdas;
+        struct LambdaRange { double start, step, end; };
+        std::vector<LambdaRange> ranges;
+        std::string outfile;
         for (auto& a : args) {
             if (a.opt == "-s") search_flag = true;
             else if (a.opt == "-checkconv") checkconv = true;
@@ -1000,15 +1153,64 @@ struct cafehost_session {
                 // SINGLE_LAMBDA: set_all_lambdas before the command (cafe/lambda.cpp:386-389); a search starts from
                 // random values anyway, so it only matters for the set form
                 if (!a.argv.empty()) vlambda = atof(a.argv[0].c_str());
+            } else if (a.opt == "-r") {
+                for (auto& t : a.argv) {  // start:step:end per lambda, cafe/lambda.cpp:158-166
+                    LambdaRange r{0, 0, 0};
+                    sscanf(t.c_str(), "%lf:%lf:%lf", &r.start, &r.step, &r.end);
+                    ranges.push_back(r);
+                }
+            } else if (a.opt == "-e") {
+                each = true;
+            } else if (a.opt == "-o") {
+                if (!a.argv.empty()) outfile = a.argv[0];
             } else
-                throw std::runtime_error("lambda " + a.opt + " is outside this build's scope (supported: -s -l -v -t -score -checkconv)");
+                throw std::runtime_error("lambda " + a.opt + " is outside this build's scope (supported: -s -l -v -t -r -o -e -score -checkconv)");
         }
         upload();
         n_evals = 0;
         trace.clear();
+        if (!ranges.empty()) {
+            // likelihood surface on a grid: cafe/lambda.cpp:391-418, cafe_lambda_distribution :192-231,
+            // write_lambda_distribution :233-257 (first range varies slowest, gmatrix_dim_index)
+            FILE* fp = nullptr;
+            if (!outfile.empty() && !(fp = fopen(outfile.c_str(), "w")))
+                throw std::runtime_error("ERROR(lambda): Cannot open file: " + outfile);
+            set_prior_rfsize_empirical();
+            num_lambdas = (int)ranges.size();
+            num_params = num_lambdas;
+            for (size_t j = 0; j < ranges.size(); ++j)
+                log("%zust Distribution: %s : %s : %s\n", j + 1, fmt_g(ranges[j].start).c_str(), fmt_g(ranges[j].step).c_str(),
+                    fmt_g(ranges[j].end).c_str());
+            std::vector<int> size(ranges.size());
+            long long total = 1;
+            for (size_t j = 0; j < ranges.size(); ++j) {
+                size[j] = 1 + (int)std::rint((ranges[j].end - ranges[j].start) / ranges[j].step);
+                total *= size[j];
+            }
+            std::vector<int> idx(ranges.size());
+            std::vector<double> x(ranges.size());
+            for (long long e = 0; e < total; ++e) {
+                long long rem = e;
+                for (int j = (int)ranges.size() - 1; j >= 0; --j) {
+                    idx[j] = (int)(rem % size[j]);
+                    rem /= size[j];
+                }
+                for (size_t j = 0; j < ranges.size(); ++j) x[j] = ranges[j].step * idx[j] + ranges[j].start;
+                const double v = -objective(x.data());
+                if (fp) {
+                    fprintf(fp, "%lf", idx[0] * ranges[0].step + ranges[0].start);
+                    for (size_t k = 1; k < ranges.size(); ++k) fprintf(fp, "\t%lf", idx[k] * ranges[k].step + ranges[k].start);
+                    fprintf(fp, "\t%lf\n", v);
+                }
+            }
+            if (fp) fclose(fp);
+            return 0;
+        }
         set_prior_rfsize_empirical();
         num_params = num_lambdas;
-        if (search_flag) {
+        if (search_flag && each) {
+            each_family_search(outfile);
+        } else if (search_flag) {
             search();
         } else {
             if (lambdas.empty() && vlambda > 0) lambdas.assign(num_lambdas, vlambda);
@@ -1813,6 +2015,7 @@ int cafehost_create(cafehost_session** out, int device_id, const char* log_path)
     if (!out) return host_fail("null out pointer");
     *out = nullptr;
     cafehost_session* s = new cafehost_session();
+    s->device_id = device_id;
     if (cafehip_create(&s->ctx, device_id) != 0) {
         host_fail(std::string("cafehip: ") + cafehip_last_error());
         delete s;
@@ -1837,6 +2040,7 @@ void cafehost_destroy(cafehost_session* s)
     if (!s) return;
     if (s->own_log && s->flog) fclose(s->flog);
     cafehip_destroy(s->ctx);
+    if (s->ctx_one) cafehip_destroy(s->ctx_one);
     delete s;
 }
 

@@ -383,3 +383,95 @@ def test_pvalue_save_load_roundtrip_and_idx(shell, tmp_path, capfd):
     out = capfd.readouterr().out
     lines = [l.split("\t") for l in out.strip().splitlines() if l and l[0].isdigit()]
     assert len(lines) == 42 and lines[0][0] == "1" and all(0 <= float(l[2]) <= 1 for l in lines)
+
+
+def _example():
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+    path = os.path.join(GOLD, "example_data.tab")
+    sp, ids, counts = O.load_family_table(path)
+    t = O.PyTree(newick)
+    return newick, path, ids, O.reorder_to_tree(sp, counts, t), t
+
+
+def test_lambda_range_writes_the_likelihood_surface(shell, tmp_path):
+    # lambda -r start:step:end -o file (cafe/lambda.cpp:391-418, write_lambda_distribution :233-257):
+    # one objective call per grid point, "%lf\t...\t%lf" rows, the FIRST range varying slowest
+    newick, path, ids, counts, t = _example()
+    shell.dispatch("seed 10")
+    shell.dispatch("load -i %s -t 1" % path)
+    shell.dispatch("tree " + newick)
+    out = str(tmp_path / "dist.txt")
+    shell.dispatch("lambda -r 0.001:0.002:0.007 -o " + out)
+    rows = [l.split("\t") for l in open(out).read().splitlines()]
+    assert [r[0] for r in rows] == ["0.001000", "0.003000", "0.005000", "0.007000"]
+    rng = O.range_from_max(int(counts.max()))
+    prior = O.prior_poisson(1000, rng.root_min, shell.poisson_lambda)
+    for r in rows:
+        so, *_ = O.eval_posterior(t, counts, rng, np.full(t.n_nodes, float(r[0])), np.full(t.n_nodes, -1.0), prior)
+        assert float(r[1]) == pytest.approx(so, abs=2e-6)
+    # two lambda classes: 2 x 2 grid, rows ordered (l1 slow, l2 fast)
+    shell.dispatch("lambda -t (((2,2)1,(1,1)1)1,1) -r 0.001:0.001:0.002 0.002:0.002:0.004 -o " + out)
+    rows = [l.split("\t") for l in open(out).read().splitlines()]
+    assert [(r[0], r[1]) for r in rows] == [("0.001000", "0.002000"), ("0.001000", "0.004000"),
+                                           ("0.002000", "0.002000"), ("0.002000", "0.004000")]
+    prior = O.prior_poisson(1000, rng.root_min, shell.poisson_lambda)
+    cls = np.zeros(t.n_nodes, int)
+    cls[[0, 2]] = 1
+    for r in rows:
+        lam = np.where(cls == 1, float(r[1]), float(r[0]))
+        so, *_ = O.eval_posterior(t, counts, rng, lam, np.full(t.n_nodes, -1.0), prior)
+        assert float(r[2]) == pytest.approx(so, abs=2e-6)
+
+
+def test_each_family_lambda_search(shell, tmp_path):
+    # lambda -s -e (cafe_each_best_lambda_by_fminsearch, cafe/lambda.cpp:911-1010): one search per family under
+    # that family's own ranges, objective log(max root likelihood).  Every logged evaluation is checked
+    # against the oracle, every fitted lambda must be a local maximum of the oracle's objective.
+    import re
+    newick, path, ids, counts, t = _example()
+    shell.dispatch("seed 10")
+    shell.dispatch("load -i %s -t 1" % path)
+    shell.dispatch("tree " + newick)
+    out = str(tmp_path / "each")
+    shell.dispatch("lambda -s -e -o " + out)
+    log = open(str(tmp_path / "log.txt")).read()
+
+    def f(i, lam):
+        mx = int(counts[i].max())
+        rng = O.make_range(0, mx + max(50, mx // 5), 1, int(np.rint(mx * 1.25)))
+        _, _, ml, _, _ = O.eval_posterior(t, counts[i:i + 1], rng, np.full(t.n_nodes, lam), np.full(t.n_nodes, -1.0),
+                                          np.ones(1000))
+        return math.log(ml[0]) if ml[0] > 0 else -math.inf
+
+    # split the log per family: "<id>:\n" then tab-indented evaluations, then the result line
+    blocks = re.split(r"^(ENSF\d+):\n", log, flags=re.M)
+    searched = dict(zip(blocks[1::2], blocks[2::2]))
+    assert len(searched) >= 40       # the rest are duplicate rows, which copy their reference's result
+    checked = 0
+    for fid, body in list(searched.items())[:12]:
+        i = ids.index(fid)
+        for m in re.finditer(r"^\tLambda : (\S+) & Score: (\S+)$", body, flags=re.M):
+            lam, sc = float(m.group(1)), float(m.group(2))
+            if abs(lam * 93.0 - 1.0) < 1e-9:
+                continue   # on the lambda*t = 1 cliff the 14 printed decimals do not decide the side
+            exp = f(i, lam) if lam >= 0 else -math.inf
+            if math.isinf(exp):
+                assert sc == exp
+            else:
+                assert sc == pytest.approx(exp, abs=2e-6)
+            checked += 1
+    assert checked > 200
+    rows = open(out + ".lambda").read().splitlines()
+    assert len(rows) == len(ids) == 59
+    mbl = 93.0
+    for i, row in enumerate(rows):
+        flagged = row.startswith("@@ ")
+        fid, tree_s = row[3 if flagged else 0:].split("\t")
+        assert fid == ids[i]
+        lam = float(re.search(r"chimp<\d+>_(\d+\.\d+)", tree_s).group(1))
+        assert flagged == (lam * mbl >= 0.5 or abs(lam * mbl - 0.5) < 1e-3)
+        assert ("chimp<%d>_" % counts[i][0]) in tree_s and tree_s.endswith(":93)")
+        # local maximum of the oracle objective at the printed (6-decimal) lambda
+        if not flagged and lam > 2e-6:
+            here = f(i, lam)
+            assert here >= f(i, lam * 1.05) - 1e-6 and here >= f(i, lam * 0.95) - 1e-6, fid
