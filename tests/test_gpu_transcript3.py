@@ -60,3 +60,75 @@ def test_test3_transcript_search_genfamily_lhtest(tmp_path):
             assert all(_close(x, y, 6e-15) for x, y in zip(a[2], b[2])), (i, a, b)
             assert _close(a[3], b[3], 2e-6 + 2e-10 * abs(b[3])), (i, a, b)
     assert n_eval > 2000
+
+
+def test_test4_transcript_error_model_two_classes(tmp_path):
+    # tests/integration/test4.sh: seed 10; tree (12 taxa); load; errormodel -all -model errormodel.txt;
+    # lambda -l 0.01 0.005 -t <2 classes> -score.  The transcript pins the table (12,653 families, ranges
+    # 1~112 / 0~140) and the Poisson prior fit (0.761427 / 237754.098757 / 32 iterations); the score itself is
+    # not printed there, so it is checked against the oracle (error model attached to every leaf).
+    import shutil
+    import numpy as np
+    from cafe_amd.shell import CafeShell
+    from tests import _orc as O
+    g = json.load(open(os.path.join(GOLD, "transcripts.json")))["test4"]
+    fam = str(tmp_path / "test4_families.txt")
+    with gzip.open(os.path.join(GOLD, "test4_families.txt.gz"), "rb") as f, open(fam, "wb") as o:
+        shutil.copyfileobj(f, o)
+    log = str(tmp_path / "log.txt")
+    sh = CafeShell(0, log)
+    for line in ["seed 10", "tree " + g["newick"], "load -i " + fam,
+                 "errormodel -all -model " + os.path.join(GOLD, "errormodel_test4.txt"),
+                 "lambda -l 0.01 0.005 -t %s -score" % g["lambda_tree"]]:
+        sh.dispatch(line)
+    score, pl = sh.score, sh.poisson_lambda
+    sh.close()
+    ev = parse_events(open(log).read())
+    assert ["families", g["n_families"]] in ev
+    assert ["root_range"] + g["root_range"] in ev and ["family_range"] + g["family_range"] in ev
+    po = [e for e in ev if e[0] == "poisson"][0]
+    assert po[1] == pytest.approx(g["poisson_lambda"], abs=1.5e-6)
+    assert po[2] == pytest.approx(g["poisson_score"], abs=2e-6) and po[3] == g["poisson_iters"]
+    # oracle: same table, same error model, per-class lambdas
+    sp, ids, counts = O.load_family_table(fam)
+    t = O.PyTree(g["newick"])
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    assert (rng.root_min, rng.root_max, rng.min, rng.max) == (1, 112, 0, 140)
+    # class of every node from the lambda tree (same topology, labels 1/2)
+    cls = _classes_in_nlist_order(g["lambda_tree"])
+    lam = np.where(np.array(cls) == 2, g["lambdas"][1], g["lambdas"][0])
+    E, mfs = O.load_error_model(os.path.join(GOLD, "errormodel_test4.txt"), rng.max)
+    prior = O.prior_poisson(1000, rng.root_min, pl)
+    so, fz, *_ = O.eval_posterior(t, counts, rng, lam, np.full(t.n_nodes, -1.0), prior, errormatrix=E, err_mfs=mfs,
+                                  leaf_has_err=np.ones(t.n_nodes, np.uint8),   # indexed by node id
+                                  nthreads=8)
+    assert fz < 0
+    assert score == pytest.approx(-so, rel=1e-11)
+
+
+def _classes_in_nlist_order(text):
+    """Lambda-tree labels in the reference's in-order node numbering (leaf, internal, leaf, ...)."""
+    pos = 0
+
+    def parse():
+        nonlocal pos
+        if text[pos] == "(":
+            pos += 1
+            left = parse()
+            assert text[pos] == ","
+            pos += 1
+            right = parse()
+            assert text[pos] == ")"
+            pos += 1
+            start = pos
+            while pos < len(text) and text[pos].isdigit():
+                pos += 1
+            label = int(text[start:pos]) if pos > start else 1
+            return left + [label] + right
+        start = pos
+        while pos < len(text) and text[pos].isdigit():
+            pos += 1
+        return [int(text[start:pos])]
+
+    return parse()

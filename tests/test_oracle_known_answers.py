@@ -282,3 +282,42 @@ def test_report_golden_test2_cafe():
                 assert bp is None
             else:
                 assert float("%g" % bp[2 * j]) == pair[0] and float("%g" % bp[2 * j + 1]) == pair[1]
+
+
+def test_transcript_test3_two_class_search_lines():
+    # tests/integration/test3.t, first search (lambda -s -t (((2,2)1,(1,1)1)1,1) on the example table): every
+    # printed "Lambda : l1,l2 & Score" line of the 117-iteration two-class search against the oracle.
+    # Class 2 = chimp and human (nodes 0 and 2 of the in-order numbering), class 1 = everything else.
+    import gzip
+    import json
+    ev = json.load(gzip.open(os.path.join(GOLD, "test3_transcript.json.gz"), "rt"))["events"]
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+    sp, ids, counts = O.load_family_table(os.path.join(GOLD, "example_data.tab"))
+    t = O.PyTree(newick)
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    first_poisson = next(e for e in ev if e[0] == "poisson")
+    prior = O.prior_poisson(1000, rng.root_min, first_poisson[1])
+    cls2 = np.zeros(t.n_nodes, bool)
+    cls2[[0, 2]] = True
+    mu = np.full(t.n_nodes, -1.0)
+    n = 0
+    for e in ev:
+        if e[0] == "result":
+            break
+        if e[0] != "eval":
+            continue
+        (l1, l2), exp = e[1], e[2]
+        if l1 < 0 or l2 < 0:
+            assert exp == -math.inf
+            continue
+        if abs(l1 * 93 - 1) < 1e-9 or abs(l2 * 6 - 1) < 1e-9:
+            continue  # on a lambda*t = 1 cliff the 14 printed decimals do not decide the side
+        score, fz, *_ = O.eval_posterior(t, counts, rng, np.where(cls2, l2, l1), mu, prior)
+        if math.isinf(exp):
+            assert score == exp
+        else:
+            # the printed prior lambda (6 decimals) bounds the agreement
+            assert score == pytest.approx(exp, abs=2e-4)
+        n += 1
+    assert n > 150
