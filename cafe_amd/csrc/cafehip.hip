@@ -244,6 +244,170 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
         PT[(size_t)key * KP * LD + (size_t)c * LD + s] = p;
     }
 }
+
+// ------------------------------------------------------------------------------------
+// K1, register-blocked product form.  Thread = one row s x K1Q consecutive columns c..c+K1Q-1.
+// For a fixed row the power part of term j is the same geometric sequence for every column up to a
+// per-column constant (alpha^q or beta^q), so the K1Q sums share a[j] * rho^j and slide a window over
+// the second binomial run b[c + q - j]:  per 8 terms of K1Q entries the thread issues 8 + 8 LDS reads
+// and 8 + 8 + 8*K1Q FP64 operations, instead of 2 reads + ~10 operations per single term.
+// rho^j is carried as (g in [1,2)) * 2^e, renormalised once per 8-term chunk; inside a chunk plain
+// doubles are safe because the host marks a key fast_ok == 2 only if binomials * rho^8 < 2^1000.
+// Terms are still accumulated in the reference's order (j ascending).  Negative b indices (j > c + q)
+// and a[j] beyond s read staged zeros, which add exact zeros.
+// ------------------------------------------------------------------------------------
+#ifndef CAFEHIP_K1Q
+#define CAFEHIP_K1Q 8
+#endif
+constexpr int K1Q = CAFEHIP_K1Q;
+constexpr int K1_BPAD = 24;  // zeros in front of every staged B row (window indices down to -22)
+
+__global__ __launch_bounds__(256) void k1_build_matrices_rb(const EvalParams* __restrict__ ep,
+                                                            const double* __restrict__ expA,
+                                                            const double* __restrict__ expB, int ld_lnc,
+                                                            double* __restrict__ PT, int M, int LD, int KP,
+                                                            int32_t* first_zero, int keys_per_block,
+                                                            EvalParams* __restrict__ ep_dev, int n_nodes, int n_prior,
+                                                            int nkeys)
+{
+    extern __shared__ double k1_smem[];
+    const KeyParam kp_first = ep->keys[min((int)blockIdx.z * keys_per_block, nkeys - 1)];
+    if (ep_dev && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        if (threadIdx.x == 0) ep_dev->nkeys = nkeys;
+        for (int i = threadIdx.x; i < n_nodes; i += 256) ep_dev->node_key[i] = ep->node_key[i];
+        for (int i = threadIdx.x; i < n_prior; i += 256) ep_dev->logprior[i] = ep->logprior[i];
+    }
+    if (first_zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *first_zero = INT32_MAX;
+    const int s0 = blockIdx.y * 16;
+    const int c0 = blockIdx.x * (16 * K1Q);
+    const int tx = threadIdx.x & 15;   // row within the tile (fast lane index: PT[c][s] stores are 128-byte runs)
+    const int tq = threadIdx.x >> 4;   // column group
+    const int s = s0 + tx;
+    const int cb = c0 + tq * K1Q;      // first column of this thread
+
+    // staged runs: A needs j <= min(s, c+q) (+7 chunk overrun), B needs i = c + q - j in [-22, c0 + 16*K1Q)
+    const int ldA = ld_lnc + 8;                 // odd + 8 = odd: conflict-free over the 16 rows
+    const int ldB = ld_lnc + K1_BPAD + 8;       // odd
+    const int nA = min(min(s0 + 16, c0 + 16 * K1Q), M + 1) + 8;
+    const int nB = min(c0 + 16 * K1Q, M + 1) + 8;
+    double* sA = k1_smem;
+    double* sB = k1_smem + 16 * (size_t)ldA;
+    {
+        const int r = threadIdx.x >> 4, l = threadIdx.x & 15;
+        const int sr = min(s0 + r, M);
+        const double* ga = expA + (size_t)sr * ld_lnc;
+        const double* gb = expB + (size_t)sr * ld_lnc;
+        double* da = sA + r * ldA;
+        double* db = sB + r * ldB + K1_BPAD;
+        for (int i0 = l; i0 < nA; i0 += 128) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (i0 + 16 * u <= M) ? ga[i0 + 16 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + 16 * u < nA) da[i0 + 16 * u] = v[u];
+        }
+        for (int i0 = l; i0 < nB; i0 += 128) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (i0 + 16 * u <= M) ? gb[i0 + 16 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + 16 * u < nB) db[i0 + 16 * u] = v[u];
+        }
+        for (int i = l; i < K1_BPAD; i += 16) sB[r * ldB + i] = 0.0;
+    }
+    __syncthreads();
+    if (s > M || cb > M) return;
+    const double* a = sA + tx * ldA;
+    const double* b = sB + tx * ldB + K1_BPAD;
+    const int mmax = min(s, min(cb + K1Q - 1, M));
+    const int key_end = min(nkeys, (int)(blockIdx.z + 1) * keys_per_block);
+    for (int key = blockIdx.z * keys_per_block; key < key_end; ++key) {
+        const KeyParam kp = (key == (int)blockIdx.z * keys_per_block) ? kp_first : ep->keys[key];
+        double p[K1Q];
+        if (s == 0) {
+#pragma unroll
+            for (int q = 0; q < K1Q; ++q) p[q] = (cb + q == 0) ? 1.0 : 0.0;  // row 0 is e_0 in every mode
+        } else if (kp.mode < 2) {
+#pragma unroll
+            for (int q = 0; q < K1Q; ++q) p[q] = (kp.mode == 1 && s == cb + q) ? 1.0 : 0.0;  // zero / identity
+        } else if (kp.fast_ok == 2) {
+            double gm0[K1Q];
+            int e0[K1Q];
+#pragma unroll
+            for (int q = 0; q < K1Q; ++q) {
+                const double y0 = (kp.mode == 2) ? (double)(s + cb + q) * kp.l2a
+                                                 : (double)s * kp.l2a + (double)(cb + q) * kp.l2b;
+                const double ef = floor(y0);
+                gm0[q] = exp2(y0 - ef);
+                e0[q] = (int)ef;
+                p[q] = 0.0;
+            }
+            const double rho = ldexp(kp.rho_m, kp.rho_e);
+            double g = 1.0;
+            int e = 0;
+            double win[K1Q + 7];  // win[d + 7] = b[cb - j0 + d], d in [-7, K1Q)
+#pragma unroll
+            for (int t = 0; t < K1Q + 7; ++t) win[t] = b[cb - 7 + t];
+            for (int j0 = 0; j0 <= mmax; j0 += 8) {
+                double acc[K1Q];
+#pragma unroll
+                for (int q = 0; q < K1Q; ++q) acc[q] = 0.0;
+                double gu = g;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double ag = a[j0 + u] * gu;
+#pragma unroll
+                    for (int q = 0; q < K1Q; ++q) acc[q] = fma(ag, win[q - u + 7], acc[q]);
+                    gu *= rho;
+                }
+#pragma unroll
+                for (int q = 0; q < K1Q; ++q) p[q] += ldexp(acc[q], e + e0[q]);
+                int ex;
+                g = 2.0 * frexp(gu, &ex);  // gu = g * 2^(ex - 1), g in [1, 2)
+                e += ex - 1;
+                // slide the window by 8 terms: indices move down by 8
+#pragma unroll
+                for (int t = K1Q + 6; t >= 8; --t) win[t] = win[t - 8];
+#pragma unroll
+                for (int t = 0; t < 8 && t < K1Q + 7; ++t) win[t] = b[cb - j0 - 15 + t];
+            }
+#pragma unroll
+            for (int q = 0; q < K1Q; ++q) p[q] = fmax(fmin(p[q] * gm0[q], 1.0), 0.0);
+        } else {
+            // keys whose rho^8 could leave the double range: per-term mantissa/exponent form (as k1_build_matrices)
+#pragma unroll 1
+            for (int q = 0; q < K1Q; ++q) {
+                const int c = cb + q;
+                if (c > M) {
+                    p[q] = 0.0;
+                    continue;
+                }
+                const int m = min(s, c);
+                const double y0 = (kp.mode == 2) ? (double)(s + c) * kp.l2a : (double)s * kp.l2a + (double)c * kp.l2b;
+                const double e0 = floor(y0);
+                double gm = exp2(y0 - e0);
+                int e = (int)e0;
+                double acc = 0.0;
+                for (int j = 0; j <= m; ++j) {
+                    const double term = a[j] * b[c - j] * gm;
+                    acc += ldexp(term, e);
+                    gm *= kp.rho_m;
+                    e += kp.rho_e;
+                    if (gm >= 2.0) {
+                        gm *= 0.5;
+                        e += 1;
+                    }
+                }
+                p[q] = fmax(fmin(acc, 1.0), 0.0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < K1Q; ++q)
+            if (cb + q <= M) PT[(size_t)key * KP * LD + (size_t)(cb + q) * LD + s] = p[q];
+    }
+}
 #pragma clang fp contract(fast)
 
 // ------------------------------------------------------------------------------------
@@ -655,6 +819,7 @@ struct cafehip_ctx {
     double *d_lncA = nullptr, *d_lncB = nullptr;
     double *d_expA = nullptr, *d_expB = nullptr;
     bool all_keys_fast = false, k1_product_form = false;
+    size_t k1rb_lds_attr = 0;
     size_t k1_lds_attr = 0;
     double* d_PT = nullptr;
     size_t pt_keys_cap = 0;
@@ -758,7 +923,9 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
             h->keys[k].l2b = ks.l2b;
             h->keys[k].rho_m = ks.rho_m;
             h->keys[k].rho_e = ks.rho_e;
-            h->keys[k].fast_ok = ks.fast_ok;
+            // 2: the register-blocked kernel may run rho^j in plain doubles over 8-term chunks without leaving
+            // the double range (binomial products * rho^8 stay below 2^1000); 1: per-term mantissa/exponent form
+            h->keys[k].fast_ok = !ks.fast_ok ? 0 : ((8.0 * std::abs(ks.rho_e) + c->lnc.log2_max_prod + 8.0 < 1000.0) ? 2 : 1);
             ++nk;
         }
         c->node_key[i] = k;
@@ -805,7 +972,21 @@ int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr)
     const char* k1env = getenv("CAFEHIP_K1");
     const bool product = c->lnc.product_form_ok && c->all_keys_fast && !(k1env && strcmp(k1env, "exact") == 0);
     c->k1_product_form = product;
-    if (product) {
+    const bool blocked = product && !(k1env && strcmp(k1env, "perterm") == 0);
+    const size_t lds_rb = 16 * (size_t)((c->lnc.ld + 8) + (c->lnc.ld + K1_BPAD + 8)) * sizeof(double);
+    if (blocked && lds_rb <= 150 * 1024) {
+        if (lds_rb > 48 * 1024 && lds_rb > c->k1rb_lds_attr) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_build_matrices_rb),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rb));
+            c->k1rb_lds_attr = lds_rb;
+        }
+        int kpb_rb = 1;
+        if (const char* e = getenv("CAFEHIP_K1KPB")) kpb_rb = std::max(1, atoi(e));
+        dim3 grid_rb((c->S + 16 * K1Q - 1) / (16 * K1Q), (c->S + 15) / 16, (c->nkeys + kpb_rb - 1) / kpb_rb);
+        hipLaunchKernelGGL(k1_build_matrices_rb, grid_rb, dim3(256), lds_rb, c->stream, hp, c->d_expA, c->d_expB,
+                           c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb_rb, c->d_params, c->n_nodes,
+                           n_prior, c->nkeys);
+    } else if (product) {
         // every key of this evaluation qualifies: the staged tables are exp(ln C)
         if (use_lds)
             hipLaunchKernelGGL((k1_build_matrices<true, true>), grid, dim3(256), lds, c->stream, hp,

@@ -44,6 +44,7 @@ struct LnCTables {
     // EA * EB * 2 stays finite (M up to ~300)
     std::vector<double> EA, EB;
     bool product_form_ok = false;
+    double log2_max_prod = 0;  // log2(max EA) + log2(max EB): head-room test for the blocked matrix kernel
     void build(int M_)
     {
         M = M_;
@@ -67,6 +68,7 @@ struct LnCTables {
                 }
         }
         product_form_ok = std::isfinite(maxA) && std::isfinite(maxB) && (std::log10(maxA) + std::log10(maxB) < 300.0);
+        log2_max_prod = product_form_ok ? std::log2(std::max(maxA, 1.0)) + std::log2(std::max(maxB, 1.0)) : 0.0;
     }
 };
 
