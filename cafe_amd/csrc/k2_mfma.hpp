@@ -430,6 +430,11 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     for (int i = tid; i < a.n_ops * 2; i += blockDim.x) s_key[i] = a.ep->node_key[a.ops[i >> 1].child[i & 1]];
     __syncthreads();
 
+    // this lane's families never change: their column limits are read once, not once per step
+    int cmx[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) cmx[g] = s_colmax[fbase + 4 * g + lk];
+
     double hold[G][NRT_W];
 
     for (int oi = 0; oi < a.n_ops; ++oi) {
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
             for (int g = 0; g < G; ++g) {
                 const int f = fbase + 4 * g + lk;
                 const int cnt = s_cnt[f * a.n_leaves + leafcol];
-                const bool ok = cnt <= s_colmax[f];
+                const bool ok = cnt <= cmx[g];
 #pragma unroll
                 for (int j = 0; j < NRT_W; ++j)
                     pre[g][j] = (ok && j < ntile) ? PTe[(size_t)cnt * a.LD + (rt0 + j) * 16 + li] : 0.0;
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                     const int f = fbase + 4 * g + lk;
                     const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
                     const int klo = max(cnt + a.err_dlo, 0);
-                    const int khi = min(min(cnt + a.err_dhi, a.C - 1), s_colmax[f]);
+                    const int khi = min(min(cnt + a.err_dhi, a.C - 1), cmx[g]);
                     const double* erow = a.err + (size_t)cnt * a.err_ld;
 #pragma unroll
                     for (int j = 0; j < NRT_W; ++j) {
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                 for (int g = 0; g < G; ++g) {
                     const int f = fbase + 4 * g + lk;
                     const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
-                    const bool ok = cnt <= s_colmax[f];
+                    const bool ok = cnt <= cmx[g];
 #pragma unroll
                     for (int j = 0; j < NRT_W; ++j)
                         fac[g][j] = (ok && j < ntile) ? PTe[(size_t)cnt * a.LD + (rt0 + j) * 16 + li] : 0.0;
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int f = fbase + 4 * g + lk;
-                const int cm = s_colmax[f];
+                const int cm = cmx[g];
 #pragma unroll
                 for (int j = 0; j < NRT_W; ++j) {
                     if (j < ntile) {
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int f = fbase + 4 * g + lk;
-                const int cm = s_colmax[f];
+                const int cm = cmx[g];
 #pragma unroll
                 for (int j = 0; j < NRT_W; ++j) {
                     if (j < ntile) {
