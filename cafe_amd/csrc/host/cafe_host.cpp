@@ -1969,6 +1969,29 @@ struct cafehost_session {
             if (tokens.size() < 2) throw std::runtime_error("Usage(source): source <file>");
             return run_script(tokens[1]);
         }
+        if (cmd == "log") {  // cafe_cmd_log, cafe/cafe_commands.cpp:325-344
+            if (tokens.size() == 1) {
+                printf("Log: %s\n", flog == stdout ? "stdout" : log_name.c_str());
+                fflush(stdout);
+                return 0;
+            }
+            std::string name;
+            for (size_t i = 1; i < tokens.size(); ++i) name += (i > 1 ? " " : "") + tokens[i];
+            if (name == "stdout") {
+                if (own_log) fclose(flog);
+                flog = stdout;
+                own_log = false;
+                log_name = "stdout";
+            } else {
+                FILE* f = fopen(name.c_str(), "a");
+                if (!f) throw std::runtime_error("ERROR(log): Cannot open log file: " + name);
+                if (own_log) fclose(flog);
+                flog = f;
+                own_log = true;
+                log_name = name;
+            }
+            return 0;
+        }
         if (cmd == "load") return cmd_load(tokens);
         if (cmd == "tree") return cmd_tree(tokens);
         if (cmd == "lambda") return cmd_lambda(tokens);
