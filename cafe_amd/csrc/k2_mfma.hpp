@@ -357,7 +357,7 @@ __device__ __forceinline__ void mfma4_edge(const double* __restrict__ bp, const 
 #pragma unroll
     for (int j = 0; j < NRT_W; ++j) b0[j] = bp[boff[j]];
     int ks = 0;
-    for (; ks + 2 <= ksteps; ks += 2) {
+    for (; ks + 2 < ksteps; ks += 2) {
         const double* bp1 = bp + (size_t)(ks + 1) * kstride;
         const double* ap1 = ap4 + (ks + 1) * 4;
 #pragma unroll
@@ -369,9 +369,8 @@ __device__ __forceinline__ void mfma4_edge(const double* __restrict__ bp, const 
 #pragma unroll
             for (int j = 0; j < NRT_W; ++j)
                 acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[g], b0[j], acc[g][j], 0, 0, 0);
-        const int kn = (ks + 2 < ksteps) ? ks + 2 : ksteps - 1;
-        const double* bp2 = bp + (size_t)kn * kstride;
-        const double* ap2 = ap4 + kn * 4;
+        const double* bp2 = bp + (size_t)(ks + 2) * kstride;
+        const double* ap2 = ap4 + (ks + 2) * 4;
 #pragma unroll
         for (int g = 0; g < G; ++g) a0[g] = ap2[(size_t)(4 * g) * LDv];
 #pragma unroll
@@ -382,12 +381,27 @@ __device__ __forceinline__ void mfma4_edge(const double* __restrict__ bp, const 
             for (int j = 0; j < NRT_W; ++j)
                 acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[g], b1[j], acc[g][j], 0, 0, 0);
     }
-    if (ks < ksteps) {
+    // one or two k-steps left: no loads are issued that nobody consumes (they would still have to be waited for
+    // before the result can be stored)
+    if (ks + 2 == ksteps) {
+        const double* bp1 = bp + (size_t)(ks + 1) * kstride;
+        const double* ap1 = ap4 + (ks + 1) * 4;
+#pragma unroll
+        for (int g = 0; g < G; ++g) a1[g] = ap1[(size_t)(4 * g) * LDv];
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j) b1[j] = bp1[boff[j]];
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j)
+            acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[g], b0[j], acc[g][j], 0, 0, 0);
+    if (ks + 2 == ksteps) {
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int j = 0; j < NRT_W; ++j)
-                acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[g], b0[j], acc[g][j], 0, 0, 0);
+                acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[g], b1[j], acc[g][j], 0, 0, 0);
     }
 }
 
