@@ -69,7 +69,7 @@ __device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const i
 #pragma unroll
     for (int j = 0; j < NRT_W; ++j) b0[j] = bp[boff[j]];
     int ks = 0;
-    for (; ks + 2 <= ksteps; ks += 2) {
+    for (; ks + 2 < ksteps; ks += 2) {
         const double* bp1 = bp + (size_t)(ks + 1) * kstride;
         const double* ap1 = ap + (ks + 1) * 4;
 #pragma unroll
@@ -81,10 +81,8 @@ __device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const i
 #pragma unroll
             for (int j = 0; j < NRT_W; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
-        // operands of step ks+2 (clamped to the last step: harmless reload)
-        const int kn = (ks + 2 < ksteps) ? ks + 2 : ksteps - 1;
-        const double* bp2 = bp + (size_t)kn * kstride;
-        const double* ap2 = ap + kn * 4;
+        const double* bp2 = bp + (size_t)(ks + 2) * kstride;
+        const double* ap2 = ap + (ks + 2) * 4;
 #pragma unroll
         for (int i = 0; i < NFT_W; ++i) a0[i] = ap2[i * astride];
 #pragma unroll
@@ -95,12 +93,27 @@ __device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const i
             for (int j = 0; j < NRT_W; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
     }
-    if (ks < ksteps) {
+    // one or two k-steps left: no loads are issued that nobody consumes (they would still have to be waited for
+    // before the result can be stored)
+    if (ks + 2 == ksteps) {
+        const double* bp1 = bp + (size_t)(ks + 1) * kstride;
+        const double* ap1 = ap + (ks + 1) * 4;
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i) a1[i] = ap1[i * astride];
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j) b1[j] = bp1[boff[j]];
+    }
+#pragma unroll
+    for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+    if (ks + 2 == ksteps) {
 #pragma unroll
         for (int i = 0; i < NFT_W; ++i)
 #pragma unroll
             for (int j = 0; j < NRT_W; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
     }
 }
 
