@@ -848,7 +848,7 @@ struct cafehip_ctx {
     int32_t host_seq = 0;
 
     // timing
-    bool timing = false;
+    bool timing = false, timing_pending = false;
     hipEvent_t ev[4] = {};
     double last_ms[3] = {0, 0, 0};
     int k2_nf = 0, k2_block = 0;
@@ -1423,7 +1423,24 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
         }
     }
     HIP_TRY(hipGetLastError());
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        c->timing_pending = true;
+    }
+    return 0;
+}
+
+// elapsed times of the last evaluation's three launches (blocks until its last event has completed)
+int collect_kernel_ms(cafehip_ctx* c)
+{
+    if (!c->timing || !c->timing_pending) return 0;
+    HIP_TRY(hipEventSynchronize(c->ev[3]));
+    for (int i = 0; i < 3; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        c->last_ms[i] = ms;
+    }
+    c->timing_pending = false;
     return 0;
 }
 
@@ -1814,14 +1831,7 @@ int cafehip_eval_posterior(cafehip_ctx* c, const double* node_lambda, const doub
     } else {
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    if (c->timing) {
-        HIP_TRY(hipEventSynchronize(c->ev[3]));
-        for (int i = 0; i < 3; ++i) {
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-            c->last_ms[i] = ms;
-        }
-    }
+    if (collect_kernel_ms(c)) return -1;
     // fixed-order final sum over chunks (independent of how chunks were produced)
     double s = 0.0;
     for (int i = 0; i < c->n_chunks; ++i) s += c->h_result->chunk_sums[i];
@@ -2025,6 +2035,7 @@ int cafehip_enable_timing(cafehip_ctx* c, int on)
 int cafehip_last_kernel_ms(cafehip_ctx* c, double ms[3])
 {
     if (!c) return fail("null context");
+    if (collect_kernel_ms(c)) return -1;  // the asynchronous entry point leaves the events pending
     for (int i = 0; i < 3; ++i) ms[i] = c->last_ms[i];
     return 0;
 }

@@ -85,11 +85,18 @@ def packed_buffer(torch, slots, device):
     return t, t.data_ptr(), t.data_ptr() + 8 * slots
 
 
-def exchange_packed(dist, torch, packed, gathered, slots, bounds):
+def exchange_packed(dist, torch, packed, gathered, slots, bounds, host_pinned=None):
     """The whole exchange step as ONE collective: all_gather of the packed per-rank buffers, then on the
-    host the fixed-order sum over chunks and the global first-zero index.  bounds[r] = (lo, hi) of rank r."""
+    host the fixed-order sum over chunks and the global first-zero index.  bounds[r] = (lo, hi) of rank r.
+    host_pinned: optional pinned CPU tensor of gathered's shape (one async copy + stream sync instead of a
+    pageable .cpu())."""
     dist.all_gather_into_tensor(gathered, packed)
-    host = gathered.cpu().numpy()                      # the optimiser needs the value on the host
+    if host_pinned is not None:
+        host_pinned.copy_(gathered, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        host = host_pinned.numpy()
+    else:
+        host = gathered.cpu().numpy()                  # the optimiser needs the value on the host
     world = len(bounds)
     rows = host.reshape(world, slots + 1)
     fz_local = rows[:, slots].copy().view(np.int32)[0::2]

@@ -67,9 +67,13 @@ class MultiGpuShell(CafeShell):
         self.slots = max(1, max((h - l + D.CHUNK - 1) // D.CHUNK for l, h in self.bounds))
         self.packed, p_chunks, p_fz = D.packed_buffer(self.torch, self.slots, self.device)
         self.gathered = self.torch.zeros((self.slots + 1) * self.world, dtype=self.torch.float64, device=self.device)
+        self.gathered_host = None
+        if self.device == "cuda":
+            self.gathered_host = self.torch.zeros((self.slots + 1) * self.world, dtype=self.torch.float64).pin_memory()
 
         def exchange(_user, fz_out):
-            score, fz = D.exchange_packed(self.dist, self.torch, self.packed, self.gathered, self.slots, self.bounds)
+            score, fz = D.exchange_packed(self.dist, self.torch, self.packed, self.gathered, self.slots, self.bounds,
+                                           self.gathered_host)
             fz_out[0] = -1 if fz == D.NO_ZERO else fz
             return score
 
