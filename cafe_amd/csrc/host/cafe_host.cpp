@@ -480,6 +480,38 @@ std::vector<Argument> build_argument_list(const std::vector<std::string>& tokens
 // ====================================================================================
 // session == CafeParam
 // ====================================================================================
+// Inverse-CDF sampling of a child size given the parent size (cafe_tree_random_familysize,
+// cafe/cafe_tree.c:533-569): the reference accumulates the matrix row entry by entry until the running sum
+// reaches the random number.  The running sums of a row do not depend on the draw, so they are formed once
+// per (node, parent size) -- by the same sequence of additions -- and each draw is a binary search for the
+// first prefix >= rnd (prefixes of non-negative terms are non-decreasing), capped like the reference's loop.
+struct CdfCache {
+    const std::vector<std::vector<double>>* mats = nullptr;
+    int S = 0;
+    std::vector<std::vector<double>> rows;  // [node * S + parent_size], empty until first use
+    void reset(const std::vector<std::vector<double>>& m, int side)
+    {
+        mats = &m;
+        S = side;
+        rows.assign(m.size() * (size_t)side, {});
+    }
+    int draw(int node, int parent_size, double rnd, int max_family_size)
+    {
+        std::vector<double>& pre = rows[(size_t)node * S + parent_size];
+        if (pre.empty()) {
+            pre.resize(S);
+            const double* m = (*mats)[node].data() + (size_t)parent_size * S;
+            double cumul = 0;
+            for (int c = 0; c < S; ++c) {
+                cumul += m[c];
+                pre[c] = cumul;
+            }
+        }
+        const int limit = std::min(std::max(max_family_size - 1, 0), S);
+        return (int)(std::lower_bound(pre.begin(), pre.begin() + limit, rnd) - pre.begin());
+    }
+};
+
 struct cafehost_session {
     cafehip_ctx* ctx = nullptr;
     cafehip_ctx* ctx_one = nullptr;  // one-family evaluations (lambda -e), created on first use
@@ -1293,6 +1325,8 @@ struct cafehost_session {
         }
         std::vector<int32_t> counts((size_t)R * trials * nl), lo((size_t)R * trials), hi((size_t)R * trials), cm((size_t)R * trials);
         std::vector<int> fs(tree.n);
+        CdfCache cdf;
+        cdf.reset(mats, S);
         size_t row = 0;
         for (int s = range.root_min; s <= range.root_max; ++s) {
             const int maxFamilySize = std::max(s, range.max);  // get_random_probabilities :20
@@ -1303,14 +1337,7 @@ struct cafehost_session {
                 for (int v : prefix) {
                     if (v == tree.root) continue;
                     const double rnd = unifrnd();
-                    double cumul = 0;
-                    const double* m = mats[v].data();
-                    const int ps = fs[tree.parent[v]];
-                    int c = 0;
-                    for (; c < maxFamilySize - 1; ++c) {
-                        cumul += m[(size_t)ps * S + c];
-                        if (cumul >= rnd) break;
-                    }
+                    const int c = cdf.draw(v, fs[tree.parent[v]], rnd, maxFamilySize);
                     fs[v] = c;
                     if (mx < c) mx = c;
                 }
@@ -1349,6 +1376,14 @@ struct cafehost_session {
     int cmd_report(const std::vector<std::string>& tokens)
     {  // cafe_cmd_report / cafe_do_report, cafe/cafe_commands.cpp:1010-1018, cafe/reports.cpp:650-708 (text format)
         prereqs(true, true);
+        const bool show_times = getenv("CAFEHOST_TIMING") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!show_times) return;
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "report: %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+            t_last = now;
+        };
         if ((int)params.size() != num_params || num_params == 0)
             throw std::runtime_error("ERROR: Lambda values were not set. Please set lambda values with the 'lambda' or 'lambdamu' command.\n");
         if (tokens.size() < 2) throw std::runtime_error("Usage(report): report <name>");
@@ -1369,7 +1404,9 @@ struct cafehost_session {
             int s_out = 0;
             hip_check(cafehip_get_matrix(ctx, v, mats[v].data(), &s_out));
         }
+        lap("matrices to host");
         if (cond_dist.empty()) compute_conditional_distribution(mats, S);
+        lap("Monte-Carlo null");
 
         log("Running Viterbi algorithm....\n");
         const int F = fam.F(), nl = tree.n_leaves(), ns = (int)fam.species.size(), n = tree.n;
@@ -1425,6 +1462,7 @@ struct cafehost_session {
             hip_check(cafehip_viterbi(ctx, F, counts.data(), lo.data(), hi.data(), cm.data(), rep_sizes.data()));
         }
 
+        lap("root likelihoods + Viterbi");
         rep_max_p.assign(F, 0.0);
         rep_branch_p.assign((size_t)F * (n - 1), -1.0);
         const int npairs = n - 1;
@@ -1470,6 +1508,7 @@ struct cafehost_session {
             }
         }
         for (double& v : avg_exp) v /= std::max(F, 1);
+        lap("p-values (host)");
 
         // ---- text report: operator<<(ostream&, const Report&), cafe/reports.cpp:453-501 ----
         if (shard_world > 1 && shard_rank != 0) {  // one writer
@@ -1515,6 +1554,7 @@ struct cafehost_session {
             fprintf(fp, ")\t\n");
         }
         fclose(fp);
+        lap("writing the file");
         log("Report Done\n");
         return 0;
     }
@@ -1655,21 +1695,15 @@ struct cafehost_session {
     }
 
     // cafe_tree_random_familysize, cafe/cafe_tree.c:533-569
-    int random_familysize(const std::vector<std::vector<double>>& mats, int S, const std::vector<int>& prefix,
-                          int root_size, int max_family_size, std::vector<int>& fs)
+    int random_familysize(CdfCache& cdf, const std::vector<int>& prefix, int root_size, int max_family_size,
+                          std::vector<int>& fs)
     {
         int mx = 0;
         fs[tree.root] = root_size;
         for (int v : prefix) {
             if (v == tree.root) continue;
             const double rnd = unifrnd();
-            double cumul = 0;
-            const double* m = mats[v].data() + (size_t)fs[tree.parent[v]] * S;
-            int c = 0;
-            for (; c < max_family_size - 1; ++c) {
-                cumul += m[c];
-                if (cumul >= rnd) break;
-            }
+            const int c = cdf.draw(v, fs[tree.parent[v]], rnd, max_family_size);
             fs[v] = c;
             if (mx < c) mx = c;
         }
@@ -1764,6 +1798,8 @@ struct cafehost_session {
         const int rfsize = range.root_max - range.root_min + 1;
         const int maxFamilysize = S - 1;  // probability_cache->maxFamilysize
         std::vector<int> fs(tree.n, 0);
+        CdfCache cdf;
+        cdf.reset(mats, S);
         for (int t = 0; t < num_trials; ++t) {
             const std::string base = prefix_path + "_" + std::to_string(t + 1);
             FILE* ft = fopen((base + ".tab").c_str(), "w");
@@ -1786,7 +1822,7 @@ struct cafehost_session {
             int id = 1;
             for (int i = 1; i <= rfsize && i < (int)root_dist.size(); ++i) {
                 for (int j = 0; j < root_dist[i]; ++j) {
-                    random_familysize(mats, S, prefix, i, maxFamilysize, fs);
+                    random_familysize(cdf, prefix, i, maxFamilysize, fs);
                     fprintf(ft, "root%d\t%d", i, id);  // write_leaves :696-711
                     fprintf(fr, "root%d\t%d", i, id);
                     for (int n_ = 0; n_ < tree.n; n_ += 2) fprintf(ft, "\t%d", fs[n_]);
