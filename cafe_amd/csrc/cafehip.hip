@@ -822,6 +822,9 @@ struct cafehip_ctx {
     size_t k1rb_lds_attr = 0;
     size_t k1_lds_attr = 0;
     double* d_PT = nullptr;
+    double* d_PTfold = nullptr;  // error model folded into the matrices (posterior mode), same shape as d_PT
+    size_t ptfold_cap = 0;
+    bool fold_current = false;
     size_t pt_keys_cap = 0;
 
     // per-evaluation parameters (ring of pinned staging buffers)
@@ -878,8 +881,35 @@ int ensure_matrix_storage(cafehip_ctx* c)
     c->d_PT = nullptr;
     const size_t bytes = need_keys * (size_t)c->KP * c->LD * sizeof(double);
     HIP_TRY(hipMalloc(&c->d_PT, bytes));
-    HIP_TRY(hipMemset(c->d_PT, 0, bytes));  // padding rows/cols stay zero forever
+    // padding rows/cols stay zero forever; ordered on the context's (non-blocking) stream, where K1 will run
+    HIP_TRY(hipMemsetAsync(c->d_PT, 0, bytes, c->stream));
     c->pt_keys_cap = need_keys;
+    return 0;
+}
+
+// Posterior mode with an error model: fold it into this evaluation's matrices (k1e_fold_error), so that every
+// leaf stays a column gather.  CAFEHIP_ERRFOLD=0 keeps the per-family sums (A/B runs).
+int launch_error_fold(cafehip_ctx* c)
+{
+    c->fold_current = false;
+    if (!c->d_err || c->nkeys == 0) return 0;
+    if (const char* e = getenv("CAFEHIP_ERRFOLD"))
+        if (atoi(e) == 0) return 0;
+    const size_t need = c->pt_keys_cap * (size_t)c->KP * c->LD * sizeof(double);
+    if (!c->d_PTfold || c->ptfold_cap < need) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->d_PTfold);
+        c->d_PTfold = nullptr;
+        c->ptfold_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_PTfold, need));
+        HIP_TRY(hipMemsetAsync(c->d_PTfold, 0, need, c->stream));  // rows beyond C stay zero (same stream as the fold)
+        c->ptfold_cap = need;
+    }
+    dim3 grid((c->LD + 255) / 256, c->C, c->nkeys);
+    hipLaunchKernelGGL(k1e_fold_error, grid, dim3(256), 0, c->stream, c->d_PT, c->d_PTfold, c->d_err, c->err_mfs + 1,
+                       c->err_banded, c->err_dlo, c->err_dhi, c->C, c->KP, c->LD);
+    HIP_TRY(hipGetLastError());
+    c->fold_current = true;
     return 0;
 }
 
@@ -1009,6 +1039,7 @@ int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr)
     // the pinned block may be rewritten once this launch has consumed it
     HIP_TRY(hipEventRecord(c->h_params_ev[c->cur_slot], c->stream));
     c->have_matrices = true;
+    c->fold_current = false;  // the folded copy (if any) belongs to the previous matrices
     return 0;
 }
 
@@ -1327,6 +1358,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     a.err_banded = (v1.err != nullptr) ? c->err_banded : 0;
     a.err_dlo = c->err_dlo;
     a.err_dhi = c->err_dhi;
+    a.PTfold = (v1.err != nullptr && v1.col_max == nullptr && c->fold_current) ? c->d_PTfold : nullptr;
     a.root_lo = v1.root_lo;
     a.root_hi = v1.root_hi;
     a.col_max = v1.col_max;
@@ -1395,6 +1427,7 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
     if (stage_params(c, node_lambda, node_mu, prior, &h)) return -1;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (launch_k1(c, d_first_zero)) return -1;
+    if (launch_error_fold(c)) return -1;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     K2Args a;
     fill_common_k2(c, a);
@@ -1507,6 +1540,7 @@ int cafehip_create(cafehip_ctx** out, int device_id)
     HIP_TRY(hipMalloc(&c->d_first_zero, sizeof(int32_t)));
     HIP_TRY(hipMalloc(&c->d_arrive, sizeof(int32_t)));
     HIP_TRY(hipMemset(c->d_arrive, 0, sizeof(int32_t)));
+    HIP_TRY(hipDeviceSynchronize());  // the memset ran on the null stream; later work uses a non-blocking one
     *out = c;
     return 0;
 }
@@ -1527,6 +1561,7 @@ void cafehip_destroy(cafehip_ctx* c)
     hipFree(c->d_lncB);
     hipFree(c->d_expA);
     hipFree(c->d_expB);
+    hipFree(c->d_PTfold);
     hipFree(c->d_PT);
     hipFree(c->d_params);
     hipFree(c->d_err);

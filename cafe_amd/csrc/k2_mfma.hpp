@@ -44,6 +44,7 @@ struct K2MfmaArgs {
     const uint8_t* leaf_has_err;
     int err_banded;        // 1: errormatrix[obs][true] is zero unless err_dlo <= true - obs <= err_dhi
     int err_dlo, err_dhi;
+    const double* PTfold;  // posterior mode: error model folded into the leaf matrices (k1e_fold_error), or NULL
     // batch mode (per-row extents)
     const int32_t* root_lo;
     const int32_t* root_hi;
@@ -55,6 +56,28 @@ struct K2MfmaArgs {
     int32_t* argmax;
     double* max_post;
 };
+
+// Error model folded into the matrices (posterior mode).  For a leaf with an error model the edge factor of a
+// family is  sum_k errormatrix[observed][k] * P[row][k]  (cafe/cafe_tree.c:196-203 then :213-224), a function of
+// (matrix, observed count, row) only -- not of the family.  It is formed once per evaluation,
+//   PTfold[key][observed][row] = sum_{k ascending} err[observed][k] * PT[key][k][row],
+// in the same order as the per-family sums of the walk, and the leaf becomes a plain column gather on PTfold.
+// Not usable with per-row column limits (batch mode clips the sum at col_max of each row).
+__global__ __launch_bounds__(256) void k1e_fold_error(const double* __restrict__ PT, double* __restrict__ PTfold,
+                                                      const double* __restrict__ err, int err_ld, int banded,
+                                                      int dlo, int dhi, int C, int KP, int LD)
+{
+    const int key = blockIdx.z, cnt = blockIdx.y;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= LD) return;
+    const double* P = PT + (size_t)key * KP * LD + s;
+    const double* erow = err + (size_t)cnt * err_ld;
+    const int klo = banded ? max(cnt + dlo, 0) : 0;
+    const int khi = banded ? min(cnt + dhi, C - 1) : C - 1;
+    double v = 0.0;
+    for (int k = klo; k <= khi; ++k) v += erow[k] * P[(size_t)k * LD];
+    PTfold[(size_t)key * KP * LD + (size_t)cnt * LD + s] = v;
+}
 
 // One edge: acc[i][j] += L-tile(i) x PT-tile(j) over all k-steps, operands double-buffered in
 // registers one k-step ahead of the MFMAs.
@@ -140,6 +163,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     const int ft0 = wf * NFT_W;
     const int fam0 = blockIdx.x * a.NF;
     const bool batch = (a.col_max != nullptr);
+    const bool fold = (a.PTfold != nullptr) && !batch;
     const size_t park_stride = (size_t)a.NF * a.LDv;
     double* my_park = a.park + (size_t)blockIdx.x * a.n_parks * park_stride;
 
@@ -170,8 +194,10 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            const double* PTe = a.PT + (size_t)s_key[oi * 2 + ch] * a.KP * a.LD + row_lo;
-            const bool errleaf = (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.leafcol[ch]];
+            const bool has_err = (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.leafcol[ch]];
+            const bool folded = has_err && fold;   // gathers on the folded matrix, like a one-hot leaf
+            const bool errleaf = has_err && !fold;
+            const double* PTe = (folded ? a.PTfold : a.PT) + (size_t)s_key[oi * 2 + ch] * a.KP * a.LD + row_lo;
             cafe_d4 fac[NFT_W][NRT_W];
             if (errleaf && a.err_banded) {
                 // banded error model (as read from a model file, cafe/error_model.cpp:162-189): the leaf
@@ -441,6 +467,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     const int fbase = wf * 4 * G;               // first family of this wave inside the workgroup
     const int fam0 = blockIdx.x * a.NF;
     const bool batch = (a.col_max != nullptr);
+    const bool fold = (a.PTfold != nullptr) && !batch;
     const size_t park_stride = (size_t)a.NF * a.LDv;
     double* my_park = a.park + (size_t)blockIdx.x * a.n_parks * park_stride;
 
@@ -479,12 +506,13 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         bool simple[2];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch)
-            simple[ch] = (op.kind[ch] == 0) && !(a.err != nullptr && a.leaf_has_err[op.leafcol[ch]]);
+            simple[ch] = (op.kind[ch] == 0) && (fold || !(a.err != nullptr && a.leaf_has_err[op.leafcol[ch]]));
         const int pre_ch = (simple[1] && !simple[0]) ? 1 : ((simple[0] && !simple[1]) ? 0 : -1);
         double pre[G][NRT_W];
         if (pre_ch >= 0) {
-            const double* PTe = a.PT + (size_t)s_key[oi * 2 + pre_ch] * a.KP * a.LD + row_lo;
             const int leafcol = pre_ch ? op.leafcol[1] : op.leafcol[0];
+            const bool pre_folded = fold && a.err != nullptr && a.leaf_has_err[leafcol];
+            const double* PTe = (pre_folded ? a.PTfold : a.PT) + (size_t)s_key[oi * 2 + pre_ch] * a.KP * a.LD + row_lo;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int f = fbase + 4 * g + lk;
@@ -500,8 +528,10 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             if (ch == pre_ch) continue;
-            const double* PTe = a.PT + (size_t)s_key[oi * 2 + ch] * a.KP * a.LD + row_lo;
-            const bool errleaf = (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.leafcol[ch]];
+            const bool has_err = (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.leafcol[ch]];
+            const bool folded = has_err && fold;
+            const bool errleaf = has_err && !fold;
+            const double* PTe = (folded ? a.PTfold : a.PT) + (size_t)s_key[oi * 2 + ch] * a.KP * a.LD + row_lo;
             double fac[G][NRT_W];
             if (errleaf && a.err_banded) {
 #pragma unroll
