@@ -1541,17 +1541,54 @@ struct cafehost_session {
         fprintf(fp, "\nnDecrease :");
         for (int b = 0; b < npairs / 2; ++b) fprintf(fp, "\t(%d,%d)", n_decrease[2 * b], n_decrease[2 * b + 1]);
         fprintf(fp, "\n'ID'\t'Newick'\t'Family-wide P-value'\t'Viterbi P-values'\t'cut P-value'\t'Likelihood Ratio'\n");
+        // The Newick text of a family is the tree's text with "_<size>" after every node name: the constant
+        // pieces are cut once (sentinel sizes mark the holes), each row then only formats its integers.
+        std::vector<std::string> pieces;
+        std::vector<int> hole_node;
+        {
+            const std::string marked = tree_string([&](int v) { return tree.name[v] + "_\x01" + std::to_string(v) + "\x02"; }, true);
+            size_t pos = 0;
+            while (true) {
+                const size_t a = marked.find('\x01', pos);
+                if (a == std::string::npos) {
+                    pieces.push_back(marked.substr(pos));
+                    break;
+                }
+                const size_t b = marked.find('\x02', a);
+                pieces.push_back(marked.substr(pos, a - pos));
+                hole_node.push_back(atoi(marked.substr(a + 1, b - a - 1).c_str()));
+                pos = b + 1;
+            }
+        }
+        std::string line;
+        char num[64];
         for (int i = 0; i < F; ++i) {
             const int32_t* fs = &rep_sizes[(size_t)i * n];
-            const std::string nw = tree_string([&](int v) { return tree.name[v] + "_" + std::to_string(fs[v]); }, true);
-            fprintf(fp, "%s\t%s\t%s\t(", fam.ids[i].c_str(), nw.c_str(), fmt_g(rep_max_p[i]).c_str());
+            line.clear();
+            line += fam.ids[i];
+            line += '\t';
+            for (size_t h = 0; h < hole_node.size(); ++h) {
+                line += pieces[h];
+                snprintf(num, sizeof num, "%d", fs[hole_node[h]]);
+                line += num;
+            }
+            line += pieces.back();
+            line += '\t';
+            snprintf(num, sizeof num, "%g", rep_max_p[i]);
+            line += num;
+            line += "\t(";
             for (int b = 0; b < npairs / 2; ++b) {
                 const double p1 = rep_branch_p[(size_t)i * (n - 1) + 2 * b], p2 = rep_branch_p[(size_t)i * (n - 1) + 2 * b + 1];
-                if (p1 < 0) fprintf(fp, "(-,-)");
-                else fprintf(fp, "(%s,%s)", fmt_g(p1).c_str(), fmt_g(p2).c_str());
-                if (b < npairs / 2 - 1) fprintf(fp, ",");
+                if (p1 < 0) {
+                    line += "(-,-)";
+                } else {
+                    snprintf(num, sizeof num, "(%g,%g)", p1, p2);
+                    line += num;
+                }
+                if (b < npairs / 2 - 1) line += ',';
             }
-            fprintf(fp, ")\t\n");
+            line += ")\t\n";
+            fwrite(line.data(), 1, line.size(), fp);
         }
         fclose(fp);
         lap("writing the file");
