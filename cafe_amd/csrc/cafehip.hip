@@ -1126,19 +1126,37 @@ int launch_mfma_nrt(cafehip_ctx* c, const K2MfmaArgs& a, int nrt_w, int grid, in
 
 // The park buffers (node vectors waiting for their sibling) stay in LDS when the whole set still lets two
 // workgroups share a CU; otherwise they live in global scratch and are fetched back when consumed.
-bool mfma_lds_parks(const cafehip_ctx* c, int nf)
+size_t mfma_lds_bytes_with(const cafehip_ctx* c, int nf, int lds_parks)
 {
-    const char* e = getenv("CAFEHIP_LDSPARK");
-    if (e && atoi(e) == 0) return false;
-    if (c->msched.n_parks <= 0) return false;
-    return (size_t)nf * c->LDv * sizeof(double) * (1 + c->msched.n_parks) <= (size_t)72 * 1024;
+    return (size_t)nf * c->LDv * sizeof(double) * (1 + lds_parks) + (size_t)nf * c->n_leaves * 4 + (size_t)nf * 4 +
+           c->msched.ops.size() * (sizeof(cafehip::MfmaOp) + 2 * sizeof(int));
 }
 
-size_t mfma_lds_bytes(const cafehip_ctx* c, int nf)
+// Number of park buffers (node vectors waiting for their sibling; slot 0 is the busiest) kept in LDS behind the
+// working buffer; the rest live in global scratch and are fetched back when consumed.  LDS parks save the global
+// round trip but cost residency: they are used only as far as the CU still holds as many workgroups as the grid
+// can put on it (measured at the configs[3] shape: one LDS park at the price of 5 -> 3 workgroups per CU is
+// 25 % slower; at configs[1], where 500 workgroups give every CU two either way, it is 4 % faster).
+// CAFEHIP_LDSPARK=<n> overrides (0 = none).
+int mfma_lds_parks(const cafehip_ctx* c, int nf, int n_items)
 {
-    return (size_t)nf * c->LDv * sizeof(double) * (mfma_lds_parks(c, nf) ? 1 + c->msched.n_parks : 1) +
-           (size_t)nf * c->n_leaves * 4 + (size_t)nf * 4 +
-           c->msched.ops.size() * (sizeof(cafehip::MfmaOp) + 2 * sizeof(int));
+    if (c->msched.n_parks <= 0) return 0;
+    if (const char* e = getenv("CAFEHIP_LDSPARK")) return std::min(std::max(atoi(e), 0), c->msched.n_parks);
+    const size_t cu_lds = 160 * 1024;
+    const int grid = (n_items + nf - 1) / nf;
+    const int wanted = std::max(1, (grid + c->n_cu - 1) / std::max(c->n_cu, 1));
+    const int resident0 = (int)(cu_lds / std::max<size_t>(mfma_lds_bytes_with(c, nf, 0), 1));
+    const int keep = std::max(1, std::min(wanted, resident0));
+    int n = 0;
+    while (n < c->msched.n_parks && (int)(cu_lds / mfma_lds_bytes_with(c, nf, n + 1)) >= keep &&
+           mfma_lds_bytes_with(c, nf, n + 1) <= (size_t)c->lds_limit)
+        ++n;
+    return n;
+}
+
+size_t mfma_lds_bytes(const cafehip_ctx* c, int nf, int n_items)
+{
+    return mfma_lds_bytes_with(c, nf, mfma_lds_parks(c, nf, n_items));
 }
 
 // Cost model fitted to sweeps on MI355X (tools/sweep_k2.py): every workgroup is resident at once,
@@ -1184,7 +1202,7 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_
         K2Cfg k;
         if (sscanf(e, "%d,%d,%d,%d", &k.nft_w, &k.nrt_w, &k.wf, &k.wr) == 4 && k.nft_w >= 1 && k.nft_w <= 2 &&
             k.nrt_w >= 1 && k.nrt_w <= 7 && k.nft_w * k.nrt_w <= 8 && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 && k.wr * k.nrt_w >= RT &&
-            mfma_lds_bytes(c, 16 * k.nft_w * k.wf) <= (size_t)c->lds_limit) {
+            mfma_lds_bytes(c, 16 * k.nft_w * k.wf, n_items) <= (size_t)c->lds_limit) {
             *out = k;
             *out_cost = 0;
             return true;
@@ -1199,7 +1217,7 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_
             if (nft_w * nrt_w > 8) continue;
             for (int wf = 1; wf * wr <= 8; wf *= 2) {
                 const int nf = 16 * nft_w * wf;
-                if (mfma_lds_bytes(c, nf) > (size_t)c->lds_limit) continue;
+                if (mfma_lds_bytes(c, nf, n_items) > (size_t)c->lds_limit) continue;
                 const double cost = k2_cost(c, n_items, nf, 4 * nft_w, wf, wr, RTc);
                 if (cost < best) {
                     best = cost;
@@ -1223,7 +1241,7 @@ bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out
         K2Cfg k;
         if (sscanf(e, "%d,%d,%d,%d", &k.nft_w, &k.nrt_w, &k.wf, &k.wr) == 4 && k.nft_w >= 1 && k.nft_w <= 8 &&
             k.nrt_w >= 1 && k.nrt_w <= 7 && k.nft_w * k.nrt_w <= kMaxGroupTiles && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 &&
-            k.wr * k.nrt_w >= RT && mfma_lds_bytes(c, 4 * k.nft_w * k.wf) <= (size_t)c->lds_limit) {
+            k.wr * k.nrt_w >= RT && mfma_lds_bytes(c, 4 * k.nft_w * k.wf, n_items) <= (size_t)c->lds_limit) {
             *out = k;
             *out_cost = 0;
             return true;
@@ -1238,7 +1256,7 @@ bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out
             if (G * nrt_w > kMaxGroupTiles) continue;
             for (int wf = 1; wf * wr <= 8 && wf <= 2; wf *= 2) {
                 const int nf = 4 * G * wf;
-                if (mfma_lds_bytes(c, nf) > (size_t)c->lds_limit) continue;
+                if (mfma_lds_bytes(c, nf, n_items) > (size_t)c->lds_limit) continue;
                 // measured: per flop this shape runs ~7 % behind the 16x16x4 one inside the kernel, and
                 // few groups per wave amortise the B-operand loads badly (G = 1: 2x, G = 2: 1.2x)
                 const double cost = 1.07 * (1.0 + 0.9 / (G * G)) * k2_cost(c, n_items, nf, G, wf, wr, RTc);
@@ -1320,7 +1338,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     const int nf = use4 ? 4 * k.nft_w * k.wf : 16 * k.nft_w * k.wf;
     const int grid = (n_items + nf - 1) / nf;
     const int block = 64 * k.wf * k.wr;
-    const size_t lds = mfma_lds_bytes(c, nf);
+    const size_t lds = mfma_lds_bytes(c, nf, n_items);
     const size_t park_bytes = (size_t)grid * std::max(c->msched.n_parks, 1) * nf * c->LDv * sizeof(double);
     if (park_bytes > c->park_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1351,7 +1369,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     a.NF = nf;
     a.park = c->d_park;
     a.n_parks = std::max(c->msched.n_parks, 1);
-    a.lds_parks = mfma_lds_parks(c, nf) ? 1 : 0;
+    a.lds_parks = mfma_lds_parks(c, nf, n_items);
     a.err = v1.err;
     a.err_ld = v1.err_ld;
     a.leaf_has_err = v1.leaf_has_err;

@@ -27,7 +27,7 @@ struct K2MfmaArgs {
     const EvalParams* ep;
     const cafehip::MfmaOp* ops;
     int n_ops;
-    int lds_parks;         // 1: the park buffers live in LDS behind the node buffer (no global round trip)
+    int lds_parks;         // park slots [0, lds_parks) live in LDS behind the node buffer (no global round trip)
     const int32_t* counts;
     int Fu;
     int n_leaves;
@@ -144,7 +144,7 @@ template <int NFT_W, int NRT_W>
 __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 {
     extern __shared__ double Lbuf[];                          // [NF][LDv]
-    int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv * (a.lds_parks ? 1 + a.n_parks : 1));  // [NF][n_leaves]
+    int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv * (1 + a.lds_parks));  // [NF][n_leaves]
     int* s_colmax = s_cnt + a.NF * a.n_leaves;                // [NF]
     // the walk's step list and each step's matrix index, copied to LDS once: the step loop then never
     // waits on a chain of dependent global loads (step record -> node_key -> matrix base)
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                 }
             } else {
                 const double* Lsrc = Lbuf;
-                if (op.kind[ch] == 1 && op.src_park[ch] >= 0 && a.lds_parks) {
+                if (op.kind[ch] == 1 && op.src_park[ch] >= 0 && op.src_park[ch] < a.lds_parks) {
                     Lsrc = Lbuf + (size_t)(1 + op.src_park[ch]) * park_stride;  // read the parked vector in place
                 } else if (op.kind[ch] == 1 && op.src_park[ch] >= 0) {
                     // fetch the parked vector into the LDS buffer
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 
         // ---- result: Hadamard product in `hold` (D layout) -> LDS buffer or park ----
         // (two explicit address spaces: a pointer that may be either makes every store a flat_store)
-        if (op.dst_park >= 0 && !a.lds_parks) {
+        if (op.dst_park >= a.lds_parks) {
             double* dst = my_park + (size_t)op.dst_park * park_stride;
 #pragma unroll
             for (int i = 0; i < NFT_W; ++i) {
@@ -448,7 +448,7 @@ template <int G, int NRT_W>
 __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 {
     extern __shared__ double Lbuf[];                          // [NF][LDv]
-    int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv * (a.lds_parks ? 1 + a.n_parks : 1));  // [NF][n_leaves]
+    int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv * (1 + a.lds_parks));  // [NF][n_leaves]
     int* s_colmax = s_cnt + a.NF * a.n_leaves;                // [NF]
     // the walk's step list and each step's matrix index, copied to LDS once: the step loop then never
     // waits on a chain of dependent global loads (step record -> node_key -> matrix base)
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                 }
             } else {
                 const double* Lsrc = Lbuf;
-                if (op.kind[ch] == 1 && op.src_park[ch] >= 0 && a.lds_parks) {
+                if (op.kind[ch] == 1 && op.src_park[ch] >= 0 && op.src_park[ch] < a.lds_parks) {
                     Lsrc = Lbuf + (size_t)(1 + op.src_park[ch]) * park_stride;
                 } else if (op.kind[ch] == 1 && op.src_park[ch] >= 0) {
                     __syncthreads();
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                 for (int j = 0; j < NRT_W; ++j) hold[g][j] *= pre[g][j];
         }
 
-        if (op.dst_park >= 0 && !a.lds_parks) {
+        if (op.dst_park >= a.lds_parks) {
             double* dst = my_park + (size_t)op.dst_park * park_stride;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
