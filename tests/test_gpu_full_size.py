@@ -1,4 +1,5 @@
-"""Full-size configs (BASELINE.json configs[1] and the configs[2] shape) through size-independent
+"""BASELINE.json full sizes -- configs[1] (10 k families, 16 taxa), configs[2] (100 k families, 32 taxa,
+lambda/mu) and one GPU shard of configs[3] (500 k / 8 = 62,464 families, 64 taxa) -- through size-independent
 properties, plus an oracle spot check on a random sample:
   * a family's values do not depend on which batch it is evaluated in (bit-exact);
   * an identity error model is the same as no error model (the one-hot leaf GEMM adds exact zeros);
@@ -16,7 +17,8 @@ from tests import _orc as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[("cfg2", 10000), ("cfg3", 12000)])
+@pytest.fixture(scope="module", params=[("cfg2", 10000), ("cfg3", 100000), ("cfg4", 62464)],
+                ids=["configs1-10k", "configs2-100k", "configs3-shard-62k"])
 def problem(request):
     import torch
     torch.cuda.init()  # torch's bundled HIP runtime must come up before libcafehip's (as in bench.py)
