@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <dirent.h>
 #include <map>
 #include <vector>
 
@@ -1908,16 +1909,13 @@ struct cafehost_session {
         if (!outfile.empty() && !(fout = fopen(outfile.c_str(), "w"))) throw std::runtime_error("Failed to open output file");
         std::vector<std::string> files;
         {
-            std::string cmd = "ls -1 '" + dir + "' 2>/dev/null";
-            FILE* pp = popen(cmd.c_str(), "r");
-            if (!pp) throw std::runtime_error("Failed to read directory");
-            char buf[4096];
-            while (fgets(buf, sizeof buf, pp)) {
-                std::string f = buf;
-                while (!f.empty() && (f.back() == '\n' || f.back() == '\r')) f.pop_back();
+            DIR* d = opendir(dir.c_str());  // cafe/cafe_commands.cpp:1483-1490 walks the directory the same way
+            if (!d) throw std::runtime_error("Failed to read directory " + dir);
+            while (struct dirent* e = readdir(d)) {
+                const std::string f = e->d_name;
                 if (f.size() > 4 && f.substr(f.size() - 4) == ".tab" && f[0] != '.') files.push_back(f);
             }
-            pclose(pp);
+            closedir(d);
         }
         std::sort(files.begin(), files.end());  // the reference uses readdir order; sorted here for reproducibility
         const std::string tree_str = tree_string([&](int v) { return tree.name[v]; }, true);
