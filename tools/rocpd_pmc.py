@@ -16,7 +16,8 @@ def main():
     for (name, cn), vs in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         avg = sum(vs) / len(vs)
         extra = "  (x2 gfx950 correction: %.1f KiB)" % (2 * avg) if cn == "FETCH_SIZE" else ""
-        print("%-60s %-11s calls %4d  avg %12.1f KiB per launch%s" % (name[:60], cn, len(vs), avg, extra))
+        unit = "KiB per launch" if cn in ("FETCH_SIZE", "WRITE_SIZE") else "(avg per counter instance record)"
+        print("%-60s %-24s records %5d  avg %12.1f %s%s" % (name[:60], cn, len(vs), avg, unit, extra))
 
 
 if __name__ == "__main__":
