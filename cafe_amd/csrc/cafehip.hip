@@ -1129,7 +1129,7 @@ int launch_mfma_nrt(cafehip_ctx* c, const K2MfmaArgs& a, int nrt_w, int grid, in
 size_t mfma_lds_bytes_with(const cafehip_ctx* c, int nf, int lds_parks)
 {
     return (size_t)nf * c->LDv * sizeof(double) * (1 + lds_parks) + (size_t)nf * c->n_leaves * 4 + (size_t)nf * 4 +
-           c->msched.ops.size() * (sizeof(cafehip::MfmaOp) + 2 * sizeof(int));
+           c->msched.ops.size() * (sizeof(cafehip::MfmaOp) + 4 * sizeof(int));
 }
 
 // Number of park buffers (node vectors waiting for their sibling; slot 0 is the busiest) kept in LDS behind the

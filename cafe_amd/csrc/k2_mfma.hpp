@@ -150,6 +150,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     // waits on a chain of dependent global loads (step record -> node_key -> matrix base)
     int* s_ops = s_colmax + a.NF;                             // [n_ops][12]  (cafehip::MfmaOp)
     int* s_key = s_ops + a.n_ops * 12;                        // [n_ops][2]
+    int* s_err = s_key + a.n_ops * 2;                         // [n_ops][2]  1: leaf child that carries the error model
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -177,7 +178,11 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
         s_colmax[f] = (batch && u < a.Fu) ? a.col_max[u] : (a.C - 1);
     }
     for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
-    for (int i = tid; i < a.n_ops * 2; i += blockDim.x) s_key[i] = a.ep->node_key[a.ops[i >> 1].child[i & 1]];
+    for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
+        const cafehip::MfmaOp& o = a.ops[i >> 1];
+        s_key[i] = a.ep->node_key[o.child[i & 1]];
+        s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
+    }
     __syncthreads();
 
     cafe_d4 hold[NFT_W][NRT_W];
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            const bool has_err = (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.leafcol[ch]];
+            const bool has_err = s_err[oi * 2 + ch] != 0;
             const bool folded = has_err && fold;   // gathers on the folded matrix, like a one-hot leaf
             const bool errleaf = has_err && !fold;
             const double* PTe = (folded ? a.PTfold : a.PT) + (size_t)s_key[oi * 2 + ch] * a.KP * a.LD + row_lo;
@@ -454,6 +459,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     // waits on a chain of dependent global loads (step record -> node_key -> matrix base)
     int* s_ops = s_colmax + a.NF;                             // [n_ops][12]  (cafehip::MfmaOp)
     int* s_key = s_ops + a.n_ops * 12;                        // [n_ops][2]
+    int* s_err = s_key + a.n_ops * 2;                         // [n_ops][2]  1: leaf child that carries the error model
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -481,7 +487,11 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         s_colmax[f] = (batch && u < a.Fu) ? a.col_max[u] : (a.C - 1);
     }
     for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
-    for (int i = tid; i < a.n_ops * 2; i += blockDim.x) s_key[i] = a.ep->node_key[a.ops[i >> 1].child[i & 1]];
+    for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
+        const cafehip::MfmaOp& o = a.ops[i >> 1];
+        s_key[i] = a.ep->node_key[o.child[i & 1]];
+        s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
+    }
     __syncthreads();
 
     // this lane's families never change: their column limits are read once, not once per step
@@ -506,12 +516,12 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         bool simple[2];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch)
-            simple[ch] = (op.kind[ch] == 0) && (fold || !(a.err != nullptr && a.leaf_has_err[op.leafcol[ch]]));
+            simple[ch] = (op.kind[ch] == 0) && (fold || !s_err[oi * 2 + ch]);
         const int pre_ch = (simple[1] && !simple[0]) ? 1 : ((simple[0] && !simple[1]) ? 0 : -1);
         double pre[G][NRT_W];
         if (pre_ch >= 0) {
             const int leafcol = pre_ch ? op.leafcol[1] : op.leafcol[0];
-            const bool pre_folded = fold && a.err != nullptr && a.leaf_has_err[leafcol];
+            const bool pre_folded = fold && s_err[oi * 2 + pre_ch] != 0;
             const double* PTe = (pre_folded ? a.PTfold : a.PT) + (size_t)s_key[oi * 2 + pre_ch] * a.KP * a.LD + row_lo;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             if (ch == pre_ch) continue;
-            const bool has_err = (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.leafcol[ch]];
+            const bool has_err = s_err[oi * 2 + ch] != 0;
             const bool folded = has_err && fold;
             const bool errleaf = has_err && !fold;
             const double* PTe = (folded ? a.PTfold : a.PT) + (size_t)s_key[oi * 2 + ch] * a.KP * a.LD + row_lo;
