@@ -20,6 +20,8 @@
 #include <string>
 #include <unordered_map>
 #include <dirent.h>
+#include <thread>
+#include <atomic>
 #include <map>
 #include <vector>
 
@@ -496,18 +498,27 @@ struct CdfCache {
         S = side;
         rows.assign(m.size() * (size_t)side, {});
     }
+    void fill(int node, int parent_size)
+    {
+        std::vector<double>& pre = rows[(size_t)node * S + parent_size];
+        pre.resize(S);
+        const double* m = (*mats)[node].data() + (size_t)parent_size * S;
+        double cumul = 0;
+        for (int c = 0; c < S; ++c) {
+            cumul += m[c];
+            pre[c] = cumul;
+        }
+    }
+    void build_all()  // every row now, so that concurrent draws only read
+    {
+        for (size_t node = 0; node < mats->size(); ++node)
+            if (!(*mats)[node].empty())
+                for (int ps = 0; ps < S; ++ps) fill((int)node, ps);
+    }
     int draw(int node, int parent_size, double rnd, int max_family_size)
     {
         std::vector<double>& pre = rows[(size_t)node * S + parent_size];
-        if (pre.empty()) {
-            pre.resize(S);
-            const double* m = (*mats)[node].data() + (size_t)parent_size * S;
-            double cumul = 0;
-            for (int c = 0; c < S; ++c) {
-                cumul += m[c];
-                pre[c] = cumul;
-            }
-        }
+        if (pre.empty()) fill(node, parent_size);
         const int limit = std::min(std::max(max_family_size - 1, 0), S);
         return (int)(std::lower_bound(pre.begin(), pre.begin() + limit, rnd) - pre.begin());
     }
@@ -1325,20 +1336,29 @@ struct cafehost_session {
             }
         }
         std::vector<int32_t> counts((size_t)R * trials * nl), lo((size_t)R * trials), hi((size_t)R * trials), cm((size_t)R * trials);
-        std::vector<int> fs(tree.n);
+        // The random numbers are drawn first, in the reference's global order (root size, trial, node in prefix
+        // order); root sizes are then independent of each other (the running-minimum column limit is per root
+        // size), so worker threads take whole root sizes -- the reference threads split them the same way
+        // (cafe/conditional_distribution.cpp:88-108) -- and the result does not depend on the thread count.
+        const size_t per_family = prefix.size() - 1;
+        std::vector<double> rnd((size_t)R * trials * per_family);
+        for (double& x : rnd) x = unifrnd();
         CdfCache cdf;
         cdf.reset(mats, S);
-        size_t row = 0;
-        for (int s = range.root_min; s <= range.root_max; ++s) {
+        cdf.build_all();  // read-only afterwards
+        auto sample_root_size = [&](int si) {
+            const int s = range.root_min + si;
             const int maxFamilySize = std::max(s, range.max);  // get_random_probabilities :20
             int rmax = range.max;
+            std::vector<int> fs(tree.n);
+            size_t row = (size_t)si * trials;
+            const double* r = rnd.data() + row * per_family;
             for (int t = 0; t < trials; ++t, ++row) {
                 int mx = 0;
                 fs[tree.root] = s;
                 for (int v : prefix) {
                     if (v == tree.root) continue;
-                    const double rnd = unifrnd();
-                    const int c = cdf.draw(v, fs[tree.parent[v]], rnd, maxFamilySize);
+                    const int c = cdf.draw(v, fs[tree.parent[v]], *r++, maxFamilySize);
                     fs[v] = c;
                     if (mx < c) mx = c;
                 }
@@ -1347,7 +1367,19 @@ struct cafehost_session {
                 lo[row] = hi[row] = s;
                 cm[row] = rmax;
             }
+        };
+        {
+            const int workers = std::max(1, std::min<int>({(int)std::thread::hardware_concurrency(), 32, R}));
+            std::atomic<int> next{0};
+            std::vector<std::thread> pool;
+            for (int w = 0; w < workers; ++w)
+                pool.emplace_back([&] {
+                    for (int si = next++; si < R; si = next++) sample_root_size(si);
+                });
+            for (auto& th : pool) th.join();
         }
+        const bool show_times = getenv("CAFEHOST_TIMING") != nullptr;
+        const auto t_sampled = std::chrono::steady_clock::now();
         std::vector<double> probs((size_t)R * trials);
         if (report_sharded()) {
             // the draws above follow the reference's global order on every rank; the likelihoods of the simulated
@@ -1367,6 +1399,9 @@ struct cafehost_session {
         } else {
             hip_check(cafehip_eval_root_likelihoods(ctx, R * trials, counts.data(), lo.data(), hi.data(), cm.data(), probs.data()));
         }
+        if (show_times)
+            fprintf(stderr, "null: likelihoods of %d simulated families %.3f s (GPU)\n", R * trials,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_sampled).count());
         cond_dist.assign(R, std::vector<double>(trials));
         for (int i = 0; i < R; ++i) {
             std::copy(probs.begin() + (size_t)i * trials, probs.begin() + (size_t)(i + 1) * trials, cond_dist[i].begin());
