@@ -309,3 +309,37 @@ def test_bad_inputs_fail_loudly(eng):
         eng.set_families(np.array([[1, -2, 3]], np.int32), cafe_amd.FamilySizeRange(0, 60, 1, 30))
     with pytest.raises(cafe_amd.CafeHipError):
         eng.set_families(np.array([[1, 2, 3]], np.int32), cafe_amd.FamilySizeRange(1, 60, 1, 30))
+
+
+@pytest.mark.parametrize("m", [34, 100, 200])
+def test_matrices_extreme_rates_all_k1_forms(eng, m):
+    # the three K1 forms (register-blocked product, per-term product, exact) over rates from 1e-14 to the
+    # lambda*t = 1 cliff: tiny rates push rho = coeff/(alpha*beta) to 2^90 and beyond, where the blocked form
+    # must hand the key to the per-term form (binomials * rho^8 would leave the double range); near the cliff
+    # rho tends to 0.  Matrix sides 85, 151 and 251.
+    t = O.PyTree("((A:1,B:3):40,(C:17,D:93):2)")
+    counts = np.array([[1, 2, 3, 4]], np.int32)
+    rng = O.range_from_max(m)
+    setup(eng, "((A:1,B:3):40,(C:17,D:93):2)", counts, rng)
+    M = max(rng.max, rng.root_max)
+    rates = [1e-14, 1e-10, 1e-7, 1e-5, 1e-3, 0.004, 0.0053, 0.005376, 0.00537634]   # 0.00537634 * 93 = 0.49999962
+    try:
+        for mode, rtol in (("", 5e-12), ("perterm", 5e-12), ("exact", MAT_RTOL)):
+            if mode:
+                os.environ["CAFEHIP_K1"] = mode
+            else:
+                os.environ.pop("CAFEHIP_K1", None)
+            for lam_v in rates:
+                for mu_v in (-1.0, lam_v * 0.7):
+                    lam = np.full(t.n_nodes, lam_v)
+                    mu = np.full(t.n_nodes, mu_v)
+                    eng.reset_birthdeath_cache(lam, mu)
+                    for node in range(t.n_nodes):
+                        if node == t.root:
+                            continue
+                        ref = O.birthdeath_matrix(int(t.branchlength[node]), lam_v, mu_v, M)
+                        got = eng.get_matrix(node)
+                        ok, worst = rel_close(got, ref, rtol, atol=1e-300)
+                        assert ok, "K1=%s lambda %g mu %g node %d: worst rel err %g" % (mode or "blocked", lam_v, mu_v, node, worst)
+    finally:
+        os.environ.pop("CAFEHIP_K1", None)
