@@ -81,16 +81,16 @@ __global__ __launch_bounds__(256) void k1e_fold_error(const double* __restrict__
 
 // One edge: acc[i][j] += L-tile(i) x PT-tile(j) over all k-steps, operands double-buffered in
 // registers one k-step ahead of the MFMAs.
-template <int NFT_W, int NRT_W>
+template <int NFT_W, int NRT_W, int NT>   // NT <= NRT_W live row tiles (see mfma4_edge)
 __device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const int (&boff)[NRT_W],
                                           size_t kstride, const double* ap, int astride, int ksteps,
                                           cafe_d4 (&acc)[NFT_W][NRT_W])
 {
-    double a0[NFT_W], a1[NFT_W], b0[NRT_W], b1[NRT_W];
+    double a0[NFT_W], a1[NFT_W], b0[NT], b1[NT];
 #pragma unroll
     for (int i = 0; i < NFT_W; ++i) a0[i] = ap[i * astride];
 #pragma unroll
-    for (int j = 0; j < NRT_W; ++j) b0[j] = bp[boff[j]];
+    for (int j = 0; j < NT; ++j) b0[j] = bp[boff[j]];
     int ks = 0;
     for (; ks + 2 < ksteps; ks += 2) {
         const double* bp1 = bp + (size_t)(ks + 1) * kstride;
@@ -98,22 +98,22 @@ __device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const i
 #pragma unroll
         for (int i = 0; i < NFT_W; ++i) a1[i] = ap1[i * astride];
 #pragma unroll
-        for (int j = 0; j < NRT_W; ++j) b1[j] = bp1[boff[j]];
+        for (int j = 0; j < NT; ++j) b1[j] = bp1[boff[j]];
 #pragma unroll
         for (int i = 0; i < NFT_W; ++i)
 #pragma unroll
-            for (int j = 0; j < NRT_W; ++j)
+            for (int j = 0; j < NT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
         const double* bp2 = bp + (size_t)(ks + 2) * kstride;
         const double* ap2 = ap + (ks + 2) * 4;
 #pragma unroll
         for (int i = 0; i < NFT_W; ++i) a0[i] = ap2[i * astride];
 #pragma unroll
-        for (int j = 0; j < NRT_W; ++j) b0[j] = bp2[boff[j]];
+        for (int j = 0; j < NT; ++j) b0[j] = bp2[boff[j]];
 #pragma unroll
         for (int i = 0; i < NFT_W; ++i)
 #pragma unroll
-            for (int j = 0; j < NRT_W; ++j)
+            for (int j = 0; j < NT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
     }
     // one or two k-steps left: no loads are issued that nobody consumes (they would still have to be waited for
@@ -124,18 +124,18 @@ __device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const i
 #pragma unroll
         for (int i = 0; i < NFT_W; ++i) a1[i] = ap1[i * astride];
 #pragma unroll
-        for (int j = 0; j < NRT_W; ++j) b1[j] = bp1[boff[j]];
+        for (int j = 0; j < NT; ++j) b1[j] = bp1[boff[j]];
     }
 #pragma unroll
     for (int i = 0; i < NFT_W; ++i)
 #pragma unroll
-        for (int j = 0; j < NRT_W; ++j)
+        for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
     if (ks + 2 == ksteps) {
 #pragma unroll
         for (int i = 0; i < NFT_W; ++i)
 #pragma unroll
-            for (int j = 0; j < NRT_W; ++j)
+            for (int j = 0; j < NT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
     }
 }
@@ -274,7 +274,14 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                         boff[j] = ((j < ntile) ? (rt0 + j) : rt0) * 16;  // inactive tiles re-read tile rt0
                     const double* bp = PTe + (size_t)lk * a.LD + li;
                     const double* ap = Lsrc + (size_t)(ft0 * 16 + li) * a.LDv + lk;
-                    mfma_edge<NFT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                    if constexpr (NRT_W > 1) {
+                        if (ntile == NRT_W - 1)
+                            mfma_edge<NFT_W, NRT_W, NRT_W - 1>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                        else
+                            mfma_edge<NFT_W, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                    } else {
+                        mfma_edge<NFT_W, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                    }
                 }
             }
             if (ch == 0) {
@@ -390,16 +397,19 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 // Y[fam_base + 4g + (l>>4)][row0 + (l&15)]: the same walk, gathers and stores as k2_prune_mfma with
 // (i, r) flattened to g = 4i + r.
 // ====================================================================================
-template <int G, int NRT_W>
+// NT <= NRT_W: the wave's live row tiles; columns NT.. of acc are left untouched (a wave that was dealt one tile
+// fewer than the widest must not burn matrix-pipe cycles on a dummy column: the other workgroup's wave on the
+// same SIMD can use them).
+template <int G, int NRT_W, int NT>
 __device__ __forceinline__ void mfma4_edge(const double* __restrict__ bp, const int (&boff)[NRT_W],
                                            size_t kstride, const double* ap4, int LDv, int ksteps,
                                            double (&acc)[G][NRT_W])
 {
-    double a0[G], a1[G], b0[NRT_W], b1[NRT_W];
+    double a0[G], a1[G], b0[NT], b1[NT];
 #pragma unroll
     for (int g = 0; g < G; ++g) a0[g] = ap4[(size_t)(4 * g) * LDv];
 #pragma unroll
-    for (int j = 0; j < NRT_W; ++j) b0[j] = bp[boff[j]];
+    for (int j = 0; j < NT; ++j) b0[j] = bp[boff[j]];
     int ks = 0;
     for (; ks + 2 < ksteps; ks += 2) {
         const double* bp1 = bp + (size_t)(ks + 1) * kstride;
@@ -407,22 +417,22 @@ __device__ __forceinline__ void mfma4_edge(const double* __restrict__ bp, const 
 #pragma unroll
         for (int g = 0; g < G; ++g) a1[g] = ap1[(size_t)(4 * g) * LDv];
 #pragma unroll
-        for (int j = 0; j < NRT_W; ++j) b1[j] = bp1[boff[j]];
+        for (int j = 0; j < NT; ++j) b1[j] = bp1[boff[j]];
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int j = 0; j < NRT_W; ++j)
+            for (int j = 0; j < NT; ++j)
                 acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[g], b0[j], acc[g][j], 0, 0, 0);
         const double* bp2 = bp + (size_t)(ks + 2) * kstride;
         const double* ap2 = ap4 + (ks + 2) * 4;
 #pragma unroll
         for (int g = 0; g < G; ++g) a0[g] = ap2[(size_t)(4 * g) * LDv];
 #pragma unroll
-        for (int j = 0; j < NRT_W; ++j) b0[j] = bp2[boff[j]];
+        for (int j = 0; j < NT; ++j) b0[j] = bp2[boff[j]];
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int j = 0; j < NRT_W; ++j)
+            for (int j = 0; j < NT; ++j)
                 acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[g], b1[j], acc[g][j], 0, 0, 0);
     }
     // one or two k-steps left: no loads are issued that nobody consumes (they would still have to be waited for
@@ -433,18 +443,18 @@ __device__ __forceinline__ void mfma4_edge(const double* __restrict__ bp, const 
 #pragma unroll
         for (int g = 0; g < G; ++g) a1[g] = ap1[(size_t)(4 * g) * LDv];
 #pragma unroll
-        for (int j = 0; j < NRT_W; ++j) b1[j] = bp1[boff[j]];
+        for (int j = 0; j < NT; ++j) b1[j] = bp1[boff[j]];
     }
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int j = 0; j < NRT_W; ++j)
+        for (int j = 0; j < NT; ++j)
             acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[g], b0[j], acc[g][j], 0, 0, 0);
     if (ks + 2 == ksteps) {
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int j = 0; j < NRT_W; ++j)
+            for (int j = 0; j < NT; ++j)
                 acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[g], b1[j], acc[g][j], 0, 0, 0);
     }
 }
@@ -597,7 +607,14 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                     for (int j = 0; j < NRT_W; ++j) boff[j] = ((j < ntile) ? (rt0 + j) : rt0) * 16;
                     const double* bp = PTe + (size_t)lk * a.LD + li;
                     const double* ap4 = Lsrc + (size_t)(fbase + (lane & 3)) * a.LDv + lk;
-                    mfma4_edge<G, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
+                    if constexpr (NRT_W > 1) {
+                        if (ntile == NRT_W - 1)
+                            mfma4_edge<G, NRT_W, NRT_W - 1>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
+                        else
+                            mfma4_edge<G, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
+                    } else {
+                        mfma4_edge<G, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
+                    }
                 }
             }
 #pragma unroll
