@@ -778,6 +778,16 @@ __global__ __launch_bounds__(1024) void k4_viterbi(K4Args a)
 // ====================================================================================
 // context
 // ====================================================================================
+// wave grid of a K2 launch (16x16x4 shape: nft_w family tiles per wave; 4x4x4 shape: nft_w carries G)
+struct K2Cfg {
+    int nft_w, nrt_w, wf, wr;
+};
+struct K2Cand {
+    double cost;
+    bool use4;
+    K2Cfg cfg;
+};
+
 struct cafehip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -856,6 +866,15 @@ struct cafehip_ctx {
     double last_ms[3] = {0, 0, 0};
     int k2_nf = 0, k2_block = 0;
     size_t k2_lds = 0;
+    // measured choice of the K2 wave grid (posterior path): see launch_k2_mfma
+    struct {
+        int n_items = -1;
+        std::vector<K2Cand> cands;
+        std::vector<float> best_ms;
+        int cur = 0, round = 0, locked = -1;
+        bool pending = false;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+    } tune;
     std::string desc;
 };
 
@@ -1090,10 +1109,6 @@ int launch_k2_v1(cafehip_ctx* c, K2Args& a, int n_items)
 
 
 // ---- MFMA launcher -------------------------------------------------------------------
-struct K2Cfg {
-    int nft_w, nrt_w, wf, wr;
-};
-
 template <int NFT_W, int NRT_W>
 int launch_mfma_inst(cafehip_ctx* c, const K2MfmaArgs& a, int grid, int block, size_t lds)
 {
@@ -1184,17 +1199,18 @@ double k2_cost(const cafehip_ctx* c, int n_items, int nf, int groups, int wf, in
     }
     const double simds = std::min(4, std::max(1, wg_on_cu * active_waves));  // a lone 2-wave workgroup uses 2 SIMDs
     const double maxload = wg_on_cu * per_wg / simds;
-    static const double wpen[9] = {0, 1.25, 1.09, 1.05, 1.0, 1.1, 1.2, 1.25, 1.3};
+    // constants re-fitted on tools/sweep_k2*.py data (tools/fit_k2_cost.py) after waves stopped issuing dummy columns
+    static const double wpen[9] = {0, 1.1, 1.0, 1.0, 1.0, 0.975, 0.95, 0.925, 0.9};
     double cost = maxload * wpen[W];
-    cost *= 1.0 + 0.002 * (n_wg * wf) / (double)n_cu;
+    cost *= 1.0 + 0.001 * (n_wg * wf) / (double)n_cu;
     const int hi_t = RTc / wr + (RTc % wr ? 1 : 0);
     const double mean_t = (double)RTc / wr;
-    cost *= 1.0 + 0.8 * (hi_t / mean_t - 1.0);
+    cost *= 1.0 + 0.2 * (hi_t / mean_t - 1.0);
     return cost;
 }
 
 // 16x16x4 shape: NF = 16 * nft_w * wf.  CAFEHIP_K2CFG="nftw,nrtw,wf,wr" overrides (tuning sweeps).
-bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_cost)
+bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_cost, std::vector<K2Cand>* all = nullptr)
 {
     const int RT = (std::max(c->C, c->R) + 15) / 16;
     const int RTc = (c->C + 15) / 16;
@@ -1219,6 +1235,7 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_
                 const int nf = 16 * nft_w * wf;
                 if (mfma_lds_bytes(c, nf, n_items) > (size_t)c->lds_limit) continue;
                 const double cost = k2_cost(c, n_items, nf, 4 * nft_w, wf, wr, RTc);
+                if (all) all->push_back(K2Cand{cost, false, K2Cfg{nft_w, nrt_w, wf, wr}});
                 if (cost < best) {
                     best = cost;
                     *out = K2Cfg{nft_w, nrt_w, wf, wr};
@@ -1233,7 +1250,7 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_
 
 // 4x4x4_4b shape: NF = 4 * G * wf (K2Cfg.nft_w carries G).  CAFEHIP_K2CFG4="G,nrtw,wf,wr" overrides.
 constexpr int kMaxGroupTiles = 24;  // G * NRT_W accumulators per wave (register budget)
-bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_cost)
+bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_cost, std::vector<K2Cand>* all = nullptr)
 {
     const int RT = (std::max(c->C, c->R) + 15) / 16;
     const int RTc = (c->C + 15) / 16;
@@ -1259,7 +1276,8 @@ bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out
                 if (mfma_lds_bytes(c, nf, n_items) > (size_t)c->lds_limit) continue;
                 // measured: per flop this shape runs ~7 % behind the 16x16x4 one inside the kernel, and
                 // few groups per wave amortise the B-operand loads badly (G = 1: 2x, G = 2: 1.2x)
-                const double cost = 1.07 * (1.0 + 0.9 / (G * G)) * k2_cost(c, n_items, nf, G, wf, wr, RTc);
+                const double cost = 1.07 * (1.0 + 0.5 / (G * G)) * k2_cost(c, n_items, nf, G, wf, wr, RTc);
+                if (all) all->push_back(K2Cand{cost, true, K2Cfg{G, nrt_w, wf, wr}});
                 if (cost < best) {
                     best = cost;
                     *out = K2Cfg{G, nrt_w, wf, wr};
@@ -1333,8 +1351,63 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
         K2Args a1 = v1;
         return launch_k2_v1(c, a1, n_items);
     }
-    const bool use4 = have4 && (!have16 || cost4 < cost16);
-    const K2Cfg k = use4 ? k4 : k16;
+    bool use4 = have4 && (!have16 || cost4 < cost16);
+    K2Cfg k = use4 ? k4 : k16;
+    // The cost model ranks the wave grids to within ~10 %; every grid produces bit-identical values (same
+    // accumulation order), so the objective path MEASURES its few best candidates on the first evaluations of a
+    // table (each of them a normal, valid evaluation) and keeps the fastest.  CAFEHIP_K2TUNE=0 disables;
+    // explicit CAFEHIP_K2CFG / CAFEHIP_K2CFG4 / CAFEHIP_MFMA overrides do too.
+    bool tuning_launch = false;
+    {
+        const char* te = getenv("CAFEHIP_K2TUNE");
+        const bool enabled = v1.col_max == nullptr && !(te && atoi(te) == 0) && !shape_env && !getenv("CAFEHIP_K2CFG") &&
+                             !getenv("CAFEHIP_K2CFG4");
+        auto& t = c->tune;
+        if (!enabled) {
+            t.n_items = -1;
+        } else {
+            if (t.n_items != n_items) {  // new table (set_families / set_tree reset n_items to -1)
+                t.n_items = n_items;
+                t.cands.clear();
+                std::vector<K2Cand> all16, all4;
+                K2Cfg dummy;
+                double dc;
+                choose_mfma_cfg(c, n_items, &dummy, &dc, &all16);
+                choose_mfma4_cfg(c, n_items, &dummy, &dc, &all4);
+                auto by_cost = [](const K2Cand& x, const K2Cand& y) { return x.cost < y.cost; };
+                std::sort(all16.begin(), all16.end(), by_cost);
+                std::sort(all4.begin(), all4.end(), by_cost);
+                for (size_t i = 0; i < all16.size() && i < 5; ++i) t.cands.push_back(all16[i]);
+                for (size_t i = 0; i < all4.size() && i < 5; ++i) t.cands.push_back(all4[i]);
+                t.best_ms.assign(t.cands.size(), 1e30f);
+                t.cur = t.round = 0;
+                t.locked = t.cands.size() <= 1 ? 0 : -1;
+                t.pending = false;
+                if (!t.e0) {
+                    HIP_TRY(hipEventCreate(&t.e0));
+                    HIP_TRY(hipEventCreate(&t.e1));
+                }
+            }
+            if (t.locked < 0 && t.pending) {  // collect the previous evaluation's measurement
+                HIP_TRY(hipEventSynchronize(t.e1));
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, t.e0, t.e1));
+                t.best_ms[t.cur] = std::min(t.best_ms[t.cur], ms);
+                t.pending = false;
+                if (++t.cur == (int)t.cands.size()) {
+                    t.cur = 0;
+                    if (++t.round == 2)  // best of two: round 0 also pays first-launch costs
+                        t.locked = (int)(std::min_element(t.best_ms.begin(), t.best_ms.end()) - t.best_ms.begin());
+                }
+            }
+            if (!t.cands.empty()) {
+                const K2Cand& pick = t.cands[t.locked >= 0 ? t.locked : t.cur];
+                use4 = pick.use4;
+                k = pick.cfg;
+                tuning_launch = t.locked < 0;
+            }
+        }
+    }
     const int nf = use4 ? 4 * k.nft_w * k.wf : 16 * k.nft_w * k.wf;
     const int grid = (n_items + nf - 1) / nf;
     const int block = 64 * k.wf * k.wr;
@@ -1394,9 +1467,16 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     c->k2_lds = lds;
     c->k2_used_mfma = true;
     c->k2_shape4 = use4;
-    if (use4) return launch_mfma4_g(c, a, k.nft_w, k.nrt_w, grid, block, lds);
-    if (k.nft_w == 1) return launch_mfma_nrt<1>(c, a, k.nrt_w, grid, block, lds);
-    return launch_mfma_nrt<2>(c, a, k.nrt_w, grid, block, lds);
+    if (tuning_launch) HIP_TRY(hipEventRecord(c->tune.e0, c->stream));
+    int rc;
+    if (use4) rc = launch_mfma4_g(c, a, k.nft_w, k.nrt_w, grid, block, lds);
+    else if (k.nft_w == 1) rc = launch_mfma_nrt<1>(c, a, k.nrt_w, grid, block, lds);
+    else rc = launch_mfma_nrt<2>(c, a, k.nrt_w, grid, block, lds);
+    if (rc == 0 && tuning_launch) {
+        HIP_TRY(hipEventRecord(c->tune.e1, c->stream));
+        c->tune.pending = true;
+    }
+    return rc;
 }
 
 int launch_k2(cafehip_ctx* c, K2Args& a, int n_items)
@@ -1610,6 +1690,7 @@ int cafehip_set_tree(cafehip_ctx* c, int n_nodes, const int32_t* parent, const i
                      const int32_t* right, const double* branchlength)
 {
     if (!c) return fail("null context");
+    c->tune.n_items = -1;  // a new problem: measure the wave grids again
     if (n_nodes < 3 || (n_nodes & 1) == 0) return fail("a binary tree has an odd number (>= 3) of nodes, got %d", n_nodes);
     if (n_nodes > kMaxNodes - 1) return fail("at most %d nodes supported, got %d", kMaxNodes - 1, n_nodes);
     HIP_TRY(hipSetDevice(c->device));
@@ -1688,6 +1769,7 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
                          int root_max)
 {
     if (!c) return fail("null context");
+    c->tune.n_items = -1;  // a new problem: measure the wave grids again
     if (F < 0 || n_leaves <= 0 || n_leaves > kMaxLeaves) return fail("bad table shape %d x %d", F, n_leaves);
     if (range_min != 0) return fail("range_min must be 0 (cafe/cafe_family.c:357-364), got %d", range_min);
     if (range_max < 0 || root_min < 0 || root_max < root_min) return fail("bad ranges");
@@ -1807,6 +1889,7 @@ int cafehip_set_error_model(cafehip_ctx* c, int mfs, const double* errormatrix,
                             const uint8_t* leaf_has_model)
 {
     if (!c) return fail("null context");
+    c->tune.n_items = -1;  // a new problem: measure the wave grids again
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     hipFree(c->d_err);
