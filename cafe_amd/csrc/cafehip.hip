@@ -23,6 +23,9 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <mutex>
+#include <map>
+#include <array>
 #include <vector>
 
 #include "../../include/cafehip.h"
@@ -1335,6 +1338,15 @@ int launch_mfma4_g(cafehip_ctx* c, const K2MfmaArgs& a, int G, int nrt_w, int gr
     return fail("unsupported G %d", G);
 }
 
+// measured wave-grid choices of this process, by problem shape
+std::mutex g_tuned_mu;
+std::map<std::array<long, 8>, K2Cand> g_tuned;
+std::array<long, 8> tune_key(const cafehip_ctx* c, int n_items)
+{
+    return {(long)c->device, (long)n_items, (long)c->C, (long)c->R, (long)c->n_leaves, (long)c->msched.ops.size(),
+            (long)c->msched.n_parks, (long)(c->d_err != nullptr)};
+}
+
 int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
 {
     if (n_items <= 0) return 0;
@@ -1382,6 +1394,15 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
                 t.best_ms.assign(t.cands.size(), 1e30f);
                 t.cur = t.round = 0;
                 t.locked = t.cands.size() <= 1 ? 0 : -1;
+                {  // a table of the same shape was measured before in this process (e.g. lhtest's simulated tables)
+                    std::lock_guard<std::mutex> g(g_tuned_mu);
+                    auto it = g_tuned.find(tune_key(c, n_items));
+                    if (it != g_tuned.end()) {
+                        t.cands.assign(1, it->second);
+                        t.best_ms.assign(1, 0.0f);
+                        t.locked = 0;
+                    }
+                }
                 t.pending = false;
                 if (!t.e0) {
                     HIP_TRY(hipEventCreate(&t.e0));
@@ -1394,10 +1415,19 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
                 HIP_TRY(hipEventElapsedTime(&ms, t.e0, t.e1));
                 t.best_ms[t.cur] = std::min(t.best_ms[t.cur], ms);
                 t.pending = false;
-                if (++t.cur == (int)t.cands.size()) {
-                    t.cur = 0;
-                    if (++t.round == 2)  // best of two: round 0 also pays first-launch costs
-                        t.locked = (int)(std::min_element(t.best_ms.begin(), t.best_ms.end()) - t.best_ms.begin());
+                // next candidate; the second round (round 0 also pays first-launch costs) only re-times the
+                // grids within 12 % of the best
+                const float best = *std::min_element(t.best_ms.begin(), t.best_ms.end());
+                do {
+                    if (++t.cur == (int)t.cands.size()) {
+                        t.cur = 0;
+                        ++t.round;
+                    }
+                } while (t.round == 1 && t.best_ms[t.cur] > 1.12f * best);
+                if (t.round >= 2) {
+                    t.locked = (int)(std::min_element(t.best_ms.begin(), t.best_ms.end()) - t.best_ms.begin());
+                    std::lock_guard<std::mutex> g(g_tuned_mu);
+                    g_tuned[tune_key(c, n_items)] = t.cands[t.locked];
                 }
             }
             if (!t.cands.empty()) {
