@@ -343,3 +343,30 @@ def test_matrices_extreme_rates_all_k1_forms(eng, m):
                         assert ok, "K1=%s lambda %g mu %g node %d: worst rel err %g" % (mode or "blocked", lam_v, mu_v, node, worst)
     finally:
         os.environ.pop("CAFEHIP_K1", None)
+
+
+def test_measured_grid_choice_never_changes_a_bit():
+    # the first evaluations of a table run different K2 wave grids (both instruction shapes) while the engine
+    # measures them; every one of those evaluations must return exactly the same per-family values
+    import cafe_amd
+    from cafe_amd import synth
+    tree, counts, cfg = synth.make_config("cfg2", F=2500)
+    rng = O.range_from_max(cfg["m"])
+    t = O.PyTree(cfg["newick"])
+    prior = O.prior_poisson(1000, rng.root_min, 8.0)
+    lam = np.full(t.n_nodes, cfg["lam"])
+    mu = np.full(t.n_nodes, -1.0)
+    eng = cafe_amd.Engine(0)
+    try:
+        eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+        eng.set_families(counts, cafe_amd.FamilySizeRange(rng.min, rng.max, rng.root_min, rng.root_max))
+        first = eng.get_posterior(lam, mu, prior, per_family=True)
+        seen = set()
+        for _ in range(30):
+            r = eng.get_posterior(lam, mu, prior, per_family=True)
+            seen.add(eng.describe().split("k2:")[1])
+            assert r[0] == first[0] and r[1] == first[1]
+            assert np.array_equal(r[2], first[2]) and np.array_equal(r[3], first[3]) and np.array_equal(r[4], first[4])
+        assert len(seen) >= 3, seen   # several grids were really exercised
+    finally:
+        eng.close()
