@@ -63,3 +63,28 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dp, fn), errors="replace").read()
                 assert "oracle" not in txt.replace("NOT the oracle", ""), os.path.join(dp, fn)
+
+
+def test_headers_are_plain_c_and_link(tmp_path):
+    # the boundary must be bindable from C (cgo / JNI / ctypes style): compile a C translation unit that includes
+    # both headers with -std=c99 -pedantic, takes the address of every declared entry point, and link it against
+    # the built libraries (no call is made: no GPU here)
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = []
+    for h in ("cafehip.h", "cafehost.h"):
+        text = open(os.path.join(root, "include", h)).read()
+        names += re.findall(r"\b(cafe(?:hip|host)_[a-z_0-9]+)\s*\(", text)
+    names = sorted(set(n for n in names if not n.endswith("_fn")))
+    assert len(names) > 30
+    src = tmp_path / "abi.c"
+    src.write_text('#include "cafehip.h"\n#include "cafehost.h"\n#include <stdio.h>\n'
+                   "int main(void) {\n  const void *p[] = {" + ", ".join("(const void *)" + n for n in names) +
+                   "};\n  printf(\"%d\\n\", (int)(sizeof p / sizeof p[0]));\n  return p[0] == 0;\n}\n")
+    exe = tmp_path / "abi"
+    libdir = os.path.join(root, "cafe_amd", "lib")
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-Wno-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+           "-L", libdir, "-lcafehip", "-Wl,-rpath," + libdir]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
