@@ -136,7 +136,7 @@ def main():
             return score
         eng.eval_posterior_async(nl, nm, prior, p_chunks, p_fz)
         # the one exchange step: a single RCCL all_gather of (chunk sums, first-zero index) per rank
-        score, fz = D.exchange_packed(dist, torch, packed, gathered, n_chunks, bounds, gathered_host)
+        score, fz = D.exchange_packed(dist, torch, packed, gathered, n_chunks, bounds, gathered_host, engine=eng)
         if timed:
             kernel_ms.append(eng.last_kernel_ms())  # the exchange has synchronised the stream
         return score

@@ -30,6 +30,7 @@ SIGNATURES = {
     "cafehip_eval_root_likelihoods": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip, _dp]),
     "cafehip_viterbi": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip, _ip]),
     "cafehip_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "cafehip_fetch_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "cafehip_last_kernel_ms": (C.c_int, [C.c_void_p, _dp]),
     "cafehip_describe": (C.c_char_p, [C.c_void_p]),
     "cafehip_last_error": (C.c_char_p, []),

@@ -622,6 +622,16 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(const double* __restri
 }
 
 
+// device words -> pinned host mirror, then a sequence number (cafehip_fetch_small)
+__global__ __launch_bounds__(256) void k_fetch_small(const uint64_t* __restrict__ src, uint64_t* host_dst, size_t n_words,
+                                                     volatile int32_t* host_seq, int32_t seq)
+{
+    for (size_t i = threadIdx.x; i < n_words; i += 256) host_dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *host_seq = seq;
+}
+
 #include "k2_mfma.hpp"
 
 // ------------------------------------------------------------------------------------
@@ -860,6 +870,9 @@ struct cafehip_ctx {
     // pinned, device-visible result block of the synchronous path
     HostResult* h_result = nullptr;
     size_t h_result_chunks = 0;
+    uint64_t* h_fetch = nullptr;   // cafehip_fetch_small: [0] sequence word, [1..] data
+    size_t h_fetch_words = 0;
+    int32_t fetch_seq = 0;
     int32_t* d_arrive = nullptr;
     int32_t host_seq = 0;
 
@@ -1689,6 +1702,7 @@ void cafehip_destroy(cafehip_ctx* c)
     hipFree(c->d_lncB);
     hipFree(c->d_expA);
     hipFree(c->d_expB);
+    if (c->h_fetch) hipHostFree(c->h_fetch);
     hipFree(c->d_PTfold);
     hipFree(c->d_PT);
     hipFree(c->d_params);
@@ -2188,6 +2202,42 @@ int cafehip_viterbi(cafehip_ctx* c, int B, const int32_t* counts, const int32_t*
     TRY3(hipStreamSynchronize(c->stream));
 #undef TRY3
     cleanup();
+    return 0;
+}
+
+int cafehip_fetch_small(cafehip_ctx* c, const void* d_src, size_t nbytes, const void** host_ptr)
+{
+    if (!c) return fail("null context");
+    if (!d_src || !host_ptr || nbytes == 0 || (nbytes & 7) || nbytes > (1u << 20)) return fail("bad fetch of %zu bytes", nbytes);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n_words = nbytes / 8;
+    if (!c->h_fetch || c->h_fetch_words < n_words) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->h_fetch) hipHostFree(c->h_fetch);
+        c->h_fetch = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&c->h_fetch, (n_words + 1) * 8, hipHostMallocMapped | hipHostMallocCoherent));
+        c->h_fetch_words = n_words;
+        c->h_fetch[0] = 0;
+        c->fetch_seq = 0;
+    }
+    const int32_t want = ++c->fetch_seq;
+    volatile int32_t* flag = reinterpret_cast<volatile int32_t*>(c->h_fetch);
+    hipLaunchKernelGGL(k_fetch_small, dim3(1), dim3(256), 0, c->stream, static_cast<const uint64_t*>(d_src), c->h_fetch + 1,
+                       n_words, flag, want);
+    HIP_TRY(hipGetLastError());
+    unsigned long spins = 0;
+    while (*flag != want) {
+        if ((++spins & 0x3FFFF) == 0) {  // a faulted launch must not hang the caller
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) {
+                if (*flag != want) HIP_TRY(hipStreamSynchronize(c->stream));
+                if (*flag != want) return fail("fetch kernel finished without publishing");
+                break;
+            }
+            if (q != hipErrorNotReady) return fail("stream error while waiting: %s", hipGetErrorString(q));
+        }
+    }
+    *host_ptr = c->h_fetch + 1;
     return 0;
 }
 

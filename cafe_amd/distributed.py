@@ -85,13 +85,17 @@ def packed_buffer(torch, slots, device):
     return t, t.data_ptr(), t.data_ptr() + 8 * slots
 
 
-def exchange_packed(dist, torch, packed, gathered, slots, bounds, host_pinned=None):
+def exchange_packed(dist, torch, packed, gathered, slots, bounds, host_pinned=None, engine=None):
     """The whole exchange step as ONE collective: all_gather of the packed per-rank buffers, then on the
     host the fixed-order sum over chunks and the global first-zero index.  bounds[r] = (lo, hi) of rank r.
     host_pinned: optional pinned CPU tensor of gathered's shape (one async copy + stream sync instead of a
     pageable .cpu())."""
     dist.all_gather_into_tensor(gathered, packed)
-    if host_pinned is not None:
+    if engine is not None:
+        # the collective ran on the engine's stream: a one-workgroup kernel behind it writes the result into
+        # pinned host memory and a flag the host polls (no copy command, no stream synchronisation)
+        host = engine.fetch_small(gathered.data_ptr(), gathered.numel())
+    elif host_pinned is not None:
         host_pinned.copy_(gathered, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         host = host_pinned.numpy()

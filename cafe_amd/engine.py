@@ -165,6 +165,13 @@ class Engine:
         _lib.check(self._L.cafehip_viterbi(self._h, c.shape[0], _i(c), _i(lo), _i(hi), _i(cm), _i(out)))
         return out
 
+    def fetch_small(self, device_ptr, n_doubles):
+        """Device doubles (e.g. the output of a collective on this engine's stream) -> numpy view of the engine's
+        pinned host mirror, without a copy command or a stream synchronisation (cafehip_fetch_small)."""
+        out = C.c_void_p()
+        _lib.check(self._L.cafehip_fetch_small(self._h, C.c_void_p(device_ptr), C.c_size_t(8 * n_doubles), C.byref(out)))
+        return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_double)), shape=(n_doubles,))
+
     def enable_timing(self, on=True):
         _lib.check(self._L.cafehip_enable_timing(self._h, 1 if on else 0))
 

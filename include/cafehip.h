@@ -26,6 +26,7 @@
 #ifndef CAFEHIP_H
 #define CAFEHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -136,6 +137,13 @@ int cafehip_eval_root_likelihoods(cafehip_ctx *ctx, int B, const int32_t *counts
  * under the per-family ranges of cafe_family_set_size_with_family_forced (cafe/cafe_family.c:236-255). */
 int cafehip_viterbi(cafehip_ctx *ctx, int B, const int32_t *counts, const int32_t *root_lo,
                     const int32_t *root_hi, const int32_t *col_max, int32_t *node_sizes);
+
+/* Multi-GPU exchange helper: bring `nbytes` (a multiple of 8, <= 1 MiB) of device memory -- the output of the
+ * caller's collective, enqueued on the context's stream -- to the host without a copy command or a stream
+ * synchronisation: a one-workgroup kernel on the same stream stores the words into the context's pinned host
+ * mirror and then a sequence number, which the host polls.  *host_ptr stays valid until the next call.
+ * (No reference counterpart: the reference's reduction is a host loop, cafe/lambda.cpp:698-722.) */
+int cafehip_fetch_small(cafehip_ctx *ctx, const void *d_src, size_t nbytes, const void **host_ptr);
 
 /* Timing of the kernels of the last cafehip_eval_posterior call, measured with HIP
  * events on the context's stream: ms[0] = matrix build, ms[1] = pruning+posterior,
