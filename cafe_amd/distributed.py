@@ -56,10 +56,12 @@ def final_score(all_chunk_sums, first_zero):
     (cafe/lambda.cpp:715-720, 753-760)."""
     if first_zero != NO_ZERO:
         return -math.inf
-    s = 0.0
-    for x in np.asarray(all_chunk_sums, np.float64):
-        s += float(x)
-    return s
+    a = np.asarray(all_chunk_sums, np.float64)
+    if a.size == 0:
+        return 0.0
+    # strictly left-to-right (ufunc.accumulate is a plain sequential loop, unlike the pairwise add.reduce): the
+    # same additions as the C loop of the single-GPU path, without a Python-level loop per chunk
+    return float(np.add.accumulate(a)[-1])
 
 
 def exchange(dist, torch, chunk_sums, first_zero_local, lo, n_local, slots, device):
