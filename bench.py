@@ -40,8 +40,8 @@ def algorithmic_bytes_per_family(n_leaves, R, C):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--families", type=int, default=None, help="families per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
