@@ -538,9 +538,10 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                 const int f = fbase + 4 * g + lk;
                 const int cnt = s_cnt[f * a.n_leaves + leafcol];
                 const bool ok = cnt <= cmx[g];
+                // one address per family group; the row tiles are constant byte offsets from it
+                const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
-                for (int j = 0; j < NRT_W; ++j)
-                    pre[g][j] = (ok && j < ntile) ? PTe[(size_t)cnt * a.LD + (rt0 + j) * 16 + li] : 0.0;
+                for (int j = 0; j < NRT_W; ++j) pre[g][j] = (ok && j < ntile) ? col[j * 16] : 0.0;
             }
         }
 
@@ -575,9 +576,9 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                     const int f = fbase + 4 * g + lk;
                     const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
                     const bool ok = cnt <= cmx[g];
+                    const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
-                    for (int j = 0; j < NRT_W; ++j)
-                        fac[g][j] = (ok && j < ntile) ? PTe[(size_t)cnt * a.LD + (rt0 + j) * 16 + li] : 0.0;
+                    for (int j = 0; j < NRT_W; ++j) fac[g][j] = (ok && j < ntile) ? col[j * 16] : 0.0;
                 }
             } else {
                 const double* Lsrc = Lbuf;
@@ -647,17 +648,14 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         } else {
             __syncthreads();
             double* dst = Lbuf + ((op.dst_park >= 0) ? (size_t)(1 + op.dst_park) * park_stride : 0);
+            const int row0 = rt0 * 16 + li;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const int f = fbase + 4 * g + lk;
-                const int cm = cmx[g];
+                double* d = dst + (fbase + 4 * g + lk) * a.LDv + row0;   // row tiles: constant offsets
+                const int lim = op.is_root ? INT_MAX : cmx[g];
 #pragma unroll
-                for (int j = 0; j < NRT_W; ++j) {
-                    if (j < ntile) {
-                        const int row = (rt0 + j) * 16 + li;
-                        dst[f * a.LDv + row] = (!op.is_root && row > cm) ? 0.0 : hold[g][j];
-                    }
-                }
+                for (int j = 0; j < NRT_W; ++j)
+                    if (j < ntile) d[j * 16] = (row0 + j * 16 > lim) ? 0.0 : hold[g][j];
             }
             __syncthreads();
         }
