@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     // the walk's step list and each step's matrix index, copied to LDS once: the step loop then never
     // waits on a chain of dependent global loads (step record -> node_key -> matrix base)
     int* s_ops = s_colmax + a.NF;                             // [n_ops][12]  (cafehip::MfmaOp)
-    int* s_key = s_ops + a.n_ops * 12;                        // [n_ops][2]
+    int* s_key = s_ops + a.n_ops * 12;                        // [n_ops][2] matrix offsets
     int* s_err = s_key + a.n_ops * 2;                         // [n_ops][2]  1: leaf child that carries the error model
 
     const int tid = threadIdx.x;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
     for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
         const cafehip::MfmaOp& o = a.ops[i >> 1];
-        s_key[i] = a.ep->node_key[o.child[i & 1]];
+        s_key[i] = a.ep->node_key[o.child[i & 1]] * a.KP * a.LD;   // element offset of the child's matrix (< 2^31)
         s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
     }
     __syncthreads();
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
             const bool has_err = s_err[oi * 2 + ch] != 0;
             const bool folded = has_err && fold;   // gathers on the folded matrix, like a one-hot leaf
             const bool errleaf = has_err && !fold;
-            const double* PTe = (folded ? a.PTfold : a.PT) + (size_t)s_key[oi * 2 + ch] * a.KP * a.LD + row_lo;
+            const double* PTe = (folded ? a.PTfold : a.PT) + s_key[oi * 2 + ch] + row_lo;
             cafe_d4 fac[NFT_W][NRT_W];
             if (errleaf && a.err_banded) {
                 // banded error model (as read from a model file, cafe/error_model.cpp:162-189): the leaf
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     // the walk's step list and each step's matrix index, copied to LDS once: the step loop then never
     // waits on a chain of dependent global loads (step record -> node_key -> matrix base)
     int* s_ops = s_colmax + a.NF;                             // [n_ops][12]  (cafehip::MfmaOp)
-    int* s_key = s_ops + a.n_ops * 12;                        // [n_ops][2]
+    int* s_key = s_ops + a.n_ops * 12;                        // [n_ops][2] matrix offsets
     int* s_err = s_key + a.n_ops * 2;                         // [n_ops][2]  1: leaf child that carries the error model
 
     const int tid = threadIdx.x;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
     for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
         const cafehip::MfmaOp& o = a.ops[i >> 1];
-        s_key[i] = a.ep->node_key[o.child[i & 1]];
+        s_key[i] = a.ep->node_key[o.child[i & 1]] * a.KP * a.LD;   // element offset of the child's matrix (< 2^31)
         s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
     }
     __syncthreads();
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         if (pre_ch >= 0) {
             const int leafcol = pre_ch ? op.leafcol[1] : op.leafcol[0];
             const bool pre_folded = fold && s_err[oi * 2 + pre_ch] != 0;
-            const double* PTe = (pre_folded ? a.PTfold : a.PT) + (size_t)s_key[oi * 2 + pre_ch] * a.KP * a.LD + row_lo;
+            const double* PTe = (pre_folded ? a.PTfold : a.PT) + s_key[oi * 2 + pre_ch] + row_lo;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int f = fbase + 4 * g + lk;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
             const bool has_err = s_err[oi * 2 + ch] != 0;
             const bool folded = has_err && fold;
             const bool errleaf = has_err && !fold;
-            const double* PTe = (folded ? a.PTfold : a.PT) + (size_t)s_key[oi * 2 + ch] * a.KP * a.LD + row_lo;
+            const double* PTe = (folded ? a.PTfold : a.PT) + s_key[oi * 2 + ch] + row_lo;
             double fac[G][NRT_W];
             if (errleaf && a.err_banded) {
 #pragma unroll
