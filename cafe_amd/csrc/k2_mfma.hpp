@@ -236,11 +236,10 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                         const int f = (ft0 + i) * 16 + lk + 4 * r;
                         const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
                         const bool ok = cnt <= s_colmax[f];
+                        // one address per family; the row tiles are constant byte offsets from it
+                        const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
-                        for (int j = 0; j < NRT_W; ++j) {
-                            const bool act = j < ntile;
-                            fac[i][j][r] = (ok && act) ? PTe[(size_t)cnt * a.LD + (rt0 + j) * 16 + li] : 0.0;
-                        }
+                        for (int j = 0; j < NRT_W; ++j) fac[i][j][r] = (ok && j < ntile) ? col[j * 16] : 0.0;
                     }
                 }
             } else {
@@ -320,19 +319,17 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
         } else {
             __syncthreads();  // every wave is done reading the buffers: overwrite in place
             double* dst = Lbuf + ((op.dst_park >= 0) ? (size_t)(1 + op.dst_park) * park_stride : 0);
+            const int row0 = rt0 * 16 + li;
 #pragma unroll
             for (int i = 0; i < NFT_W; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = (ft0 + i) * 16 + lk + 4 * r;
-                    const int cm = s_colmax[f];
+                    double* d = dst + f * a.LDv + row0;   // row tiles: constant offsets
+                    const int lim = op.is_root ? INT_MAX : s_colmax[f];
 #pragma unroll
-                    for (int j = 0; j < NRT_W; ++j) {
-                        if (j < ntile) {
-                            const int row = (rt0 + j) * 16 + li;
-                            dst[f * a.LDv + row] = (!op.is_root && row > cm) ? 0.0 : hold[i][j][r];
-                        }
-                    }
+                    for (int j = 0; j < NRT_W; ++j)
+                        if (j < ntile) d[j * 16] = (row0 + j * 16 > lim) ? 0.0 : hold[i][j][r];
                 }
             }
             __syncthreads();
