@@ -185,6 +185,13 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     }
     __syncthreads();
 
+    // this lane's families never change: their column limits are read once, not once per step
+    int cmx[NFT_W][4];
+#pragma unroll
+    for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cmx[i][r] = s_colmax[(ft0 + i) * 16 + lk + 4 * r];
+
     cafe_d4 hold[NFT_W][NRT_W];
 
     for (int oi = 0; oi < a.n_ops; ++oi) {
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                         const int f = (ft0 + i) * 16 + lk + 4 * r;
                         const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
                         const int klo = max(cnt + a.err_dlo, 0);
-                        const int khi = min(min(cnt + a.err_dhi, a.C - 1), s_colmax[f]);
+                        const int khi = min(min(cnt + a.err_dhi, a.C - 1), cmx[i][r]);
                         const double* erow = a.err + (size_t)cnt * a.err_ld;
 #pragma unroll
                         for (int j = 0; j < NRT_W; ++j) {
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                     for (int r = 0; r < 4; ++r) {
                         const int f = (ft0 + i) * 16 + lk + 4 * r;
                         const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
-                        const bool ok = cnt <= s_colmax[f];
+                        const bool ok = cnt <= cmx[i][r];
                         // one address per family; the row tiles are constant byte offsets from it
                         const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = (ft0 + i) * 16 + lk + 4 * r;
-                    const int cm = s_colmax[f];
+                    const int cm = cmx[i][r];
 #pragma unroll
                     for (int j = 0; j < NRT_W; ++j) {
                         if (j < ntile) {
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                 for (int r = 0; r < 4; ++r) {
                     const int f = (ft0 + i) * 16 + lk + 4 * r;
                     double* d = dst + f * a.LDv + row0;   // row tiles: constant offsets
-                    const int lim = op.is_root ? INT_MAX : s_colmax[f];
+                    const int lim = op.is_root ? INT_MAX : cmx[i][r];
 #pragma unroll
                     for (int j = 0; j < NRT_W; ++j)
                         if (j < ntile) d[j * 16] = (row0 + j * 16 > lim) ? 0.0 : hold[i][j][r];
