@@ -47,6 +47,7 @@ HOST_SIGNATURES = {
     "cafehost_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cafehost_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cafehost_set_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cafehost_fetch_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_ulong, C.POINTER(C.c_void_p)]),
     "cafehost_upload": (C.c_int, [C.c_void_p]),
     "cafehost_num_params": (C.c_int, [C.c_void_p]),
     "cafehost_get_params": (C.c_int, [C.c_void_p, _dp, C.c_int]),

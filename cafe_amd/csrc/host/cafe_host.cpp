@@ -2232,6 +2232,14 @@ int cafehost_set_allgather(cafehost_session* s, cafehost_allgather_fn fn, void* 
     return 0;
 }
 
+int cafehost_fetch_small(cafehost_session* s, const void* d_src, unsigned long nbytes, const void** host_ptr)
+{
+    if (!s) return host_fail("null session");
+    if (cafehip_fetch_small(s->ctx, d_src, (size_t)nbytes, host_ptr) != 0)
+        return host_fail(std::string("cafehip: ") + cafehip_last_error());
+    return 0;
+}
+
 int cafehost_set_stream(cafehost_session* s, void* hip_stream)
 {
     if (!s) return host_fail("null session");

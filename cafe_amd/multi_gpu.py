@@ -71,9 +71,20 @@ class MultiGpuShell(CafeShell):
         if self.device == "cuda":
             self.gathered_host = self.torch.zeros((self.slots + 1) * self.world, dtype=self.torch.float64).pin_memory()
 
+        shell = self
+
+        class _Fetch:   # what exchange_packed needs of an engine: the session's device context does the fetch
+            def fetch_small(self, device_ptr, n_doubles):
+                out = C.c_void_p()
+                shell._check(shell._L.cafehost_fetch_small(shell._h, C.c_void_p(device_ptr), C.c_ulong(8 * n_doubles),
+                                                           C.byref(out)))
+                return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_double)), shape=(n_doubles,))
+
+        fetch = _Fetch() if self.device == "cuda" else None
+
         def exchange(_user, fz_out):
             score, fz = D.exchange_packed(self.dist, self.torch, self.packed, self.gathered, self.slots, self.bounds,
-                                           self.gathered_host)
+                                           self.gathered_host, engine=fetch)
             fz_out[0] = -1 if fz == D.NO_ZERO else fz
             return score
 

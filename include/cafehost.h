@@ -58,6 +58,8 @@ typedef int (*cafehost_allgather_fn)(void *user, const void *mine, long long nby
                                      long long nbytes_slot);
 int cafehost_set_allgather(cafehost_session *s, cafehost_allgather_fn fn, void *user);
 int cafehost_set_stream(cafehost_session *s, void *hip_stream);
+/* cafehip_fetch_small on the session's device context (for the exchange callback: collective output -> host). */
+int cafehost_fetch_small(cafehost_session *s, const void *d_src, unsigned long nbytes, const void **host_ptr);
 /* Upload tree + (sharded) table now instead of at the first lambda command (so that the caller can size
  * its exchange buffers from cafehost_shard_bounds). */
 int cafehost_upload(cafehost_session *s);
