@@ -1402,8 +1402,14 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
                 auto by_cost = [](const K2Cand& x, const K2Cand& y) { return x.cost < y.cost; };
                 std::sort(all16.begin(), all16.end(), by_cost);
                 std::sort(all4.begin(), all4.end(), by_cost);
-                for (size_t i = 0; i < all16.size() && i < 5; ++i) t.cands.push_back(all16[i]);
-                for (size_t i = 0; i < all4.size() && i < 5; ++i) t.cands.push_back(all4[i]);
+                // five per shape, but none the model itself prices more than 35 % above its best
+                double floor_cost = 1e300;
+                if (!all16.empty()) floor_cost = std::min(floor_cost, all16[0].cost);
+                if (!all4.empty()) floor_cost = std::min(floor_cost, all4[0].cost);
+                for (size_t i = 0; i < all16.size() && i < 5; ++i)
+                    if (i == 0 || all16[i].cost <= 1.35 * floor_cost) t.cands.push_back(all16[i]);
+                for (size_t i = 0; i < all4.size() && i < 5; ++i)
+                    if (i == 0 || all4[i].cost <= 1.35 * floor_cost) t.cands.push_back(all4[i]);
                 t.best_ms.assign(t.cands.size(), 1e30f);
                 t.cur = t.round = 0;
                 t.locked = t.cands.size() <= 1 ? 0 : -1;
