@@ -74,3 +74,21 @@ def test_sharded_report_equals_golden_test2_cafe(tmp_path, nproc):
     # the conditional distribution written by `pvalue -o`: root sizes x 1000 sorted likelihoods
     rows = open(out + ".pv").read().splitlines()
     assert len(rows) == 30 and all(len(r.split("\t")) == 1000 for r in rows)
+
+
+def test_sharded_error_model_pipeline_equals_single_process(tmp_path):
+    # BASELINE configs[4] in miniature: error model on every leaf, lambda -s, report (Monte-Carlo null sharded by
+    # root size, 59 observed families sharded by block) on 3 ranks -- fitted lambda, score and the whole report
+    # text must equal the single-process run
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+    out_m, out_s = str(tmp_path / "multi"), str(tmp_path / "single")
+    common = ["seed 10", "load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"), "tree " + newick,
+              "errormodel -model %s -all" % os.path.join(GOLD, "error1.txt"), "lambda -s"]
+    script = tmp_path / "run.sh"
+    script.write_text("\n".join(common + ["report " + out_m]) + "\n")
+    p1, s1, it1, ev1 = _run_single(common + ["report " + out_s])
+    pm, sm, itm, evm = _run_multi(str(script), 3, 29655)
+    assert pm == p1 and sm == s1 and itm == it1 and evm == ev1
+    a = open(out_m + ".cafe").read()
+    b = open(out_s + ".cafe").read()
+    assert a == b and a.count("\n") > 60
