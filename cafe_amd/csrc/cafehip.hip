@@ -661,6 +661,7 @@ struct K4Args {
     const int32_t* root_hi;
     const int32_t* col_max;
     int32_t* node_sizes;       // [B][n_nodes]
+    unsigned short* vit_global;  // argmax tables in global scratch [grid][n_tables][NF][LDv], or NULL: in LDS
 };
 
 template <int NF>
@@ -668,7 +669,12 @@ __global__ __launch_bounds__(1024) void k4_viterbi(K4Args a)
 {
     extern __shared__ double smem4[];
     double* slots = smem4;                                                  // [n_slots][NF][LDv]
-    unsigned short* vit = reinterpret_cast<unsigned short*>(slots + (size_t)a.n_slots * NF * a.LDv);  // [n_tables][NF][LDv]
+    // argmax tables [n_tables][NF][LDv]: written once per (node, row), read ~n_nodes times per family by the
+    // backtrack -- in global scratch they cost next to no traffic and leave LDS to the node vectors, i.e. several
+    // workgroups per CU instead of one (the k loop is latency-bound at one wave per SIMD)
+    unsigned short* vit = a.vit_global
+                              ? a.vit_global + (size_t)blockIdx.x * a.n_tables * NF * a.LDv
+                              : reinterpret_cast<unsigned short*>(slots + (size_t)a.n_slots * NF * a.LDv);
     __shared__ int s_cnt[NF][kMaxLeaves];
     __shared__ int s_colmax[NF];
 
@@ -683,7 +689,8 @@ __global__ __launch_bounds__(1024) void k4_viterbi(K4Args a)
         s_cnt[f][j] = (u < a.B) ? a.counts[(size_t)u * a.n_leaves + j] : 0;
     }
     if (tid < NF) s_colmax[tid] = (fam0 + tid < a.B) ? a.col_max[fam0 + tid] : (a.C - 1);
-    for (int i = tid; i < a.n_tables * NF * a.LDv; i += blockDim.x) vit[i] = 0;
+    if (!a.vit_global)   // (every entry the backtrack reads is written by the walk; the LDS copy is cleared for tidiness)
+        for (int i = tid; i < a.n_tables * NF * a.LDv; i += blockDim.x) vit[i] = 0;
     __syncthreads();
 
     int root_slot = 0;
@@ -745,6 +752,8 @@ __global__ __launch_bounds__(1024) void k4_viterbi(K4Args a)
         root_slot = op.dst;
     }
 
+    __threadfence_block();
+    __syncthreads();
     // backtrack (cafe/viterbi.cpp:322-351): one thread per family, prefix order
     if (tid < NF && fam0 + tid < a.B) {
         const int f = tid;
@@ -845,6 +854,8 @@ struct cafehip_ctx {
     size_t k1rb_lds_attr = 0;
     size_t k1_lds_attr = 0;
     double* d_PT = nullptr;
+    unsigned short* d_vit = nullptr;   // Viterbi argmax tables (global scratch, grow-only)
+    size_t vit_cap = 0;
     double* d_PTfold = nullptr;  // error model folded into the matrices (posterior mode), same shape as d_PT
     size_t ptfold_cap = 0;
     bool fold_current = false;
@@ -1709,6 +1720,7 @@ void cafehip_destroy(cafehip_ctx* c)
     hipFree(c->d_expA);
     hipFree(c->d_expB);
     if (c->h_fetch) hipHostFree(c->h_fetch);
+    hipFree(c->d_vit);
     hipFree(c->d_PTfold);
     hipFree(c->d_PT);
     hipFree(c->d_params);
@@ -2153,11 +2165,35 @@ int cafehip_viterbi(cafehip_ctx* c, int B, const int32_t* counts, const int32_t*
     int nf = 8;
     size_t lds = 0;
     const size_t stat = 8 * kMaxLeaves * 4 + 64;
-    for (; nf >= 1; nf >>= 1) {
-        lds = (size_t)c->sched.n_slots * nf * c->LDv * sizeof(double) + (size_t)c->n_vit_tables * nf * c->LDv * sizeof(unsigned short) + 16;
-        if (lds + stat <= (size_t)c->lds_limit) break;
+    // argmax tables in global scratch (default): LDS holds the node-vector slots only, sized for >= 4 workgroups
+    // per CU; CAFEHIP_VITLDS=1 keeps the tables in LDS (one workgroup per CU at the larger shapes)
+    const char* vl = getenv("CAFEHIP_VITLDS");
+    bool tables_global = !(vl && atoi(vl) == 1);
+    const size_t per_family_tables = (size_t)c->n_vit_tables * c->LDv * sizeof(unsigned short);
+    if (tables_global) {
+        for (nf = 8; nf >= 1; nf >>= 1) {
+            lds = (size_t)c->sched.n_slots * nf * c->LDv * sizeof(double) + 16;
+            if (lds + stat <= (size_t)40 * 1024 || nf == 1) break;
+        }
+        if (lds + stat > (size_t)c->lds_limit) return fail("Viterbi node vectors of this tree do not fit LDS");
+        const size_t max_batch = 65536;
+        const size_t need = std::min<size_t>((size_t)B, max_batch) * per_family_tables + 8 * per_family_tables;
+        if (need > c->vit_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            hipFree(c->d_vit);
+            c->d_vit = nullptr;
+            c->vit_cap = 0;
+            if (hipMalloc(&c->d_vit, need) == hipSuccess) c->vit_cap = need;
+            else { (void)hipGetLastError(); tables_global = false; }   // no room: tables in LDS as before
+        }
     }
-    if (nf < 1) return fail("Viterbi tables of this tree do not fit LDS");
+    if (!tables_global) {
+        for (nf = 8; nf >= 1; nf >>= 1) {
+            lds = (size_t)c->sched.n_slots * nf * c->LDv * sizeof(double) + (size_t)nf * per_family_tables + 16;
+            if (lds + stat <= (size_t)c->lds_limit) break;
+        }
+        if (nf < 1) return fail("Viterbi tables of this tree do not fit LDS");
+    }
     int32_t *d_cnt = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_cm = nullptr, *d_out = nullptr;
     auto cleanup = [&]() { hipFree(d_cnt); hipFree(d_lo); hipFree(d_hi); hipFree(d_cm); hipFree(d_out); };
 #define TRY3(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail("%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
@@ -2196,12 +2232,24 @@ int cafehip_viterbi(cafehip_ctx* c, int B, const int32_t* counts, const int32_t*
     a.root_hi = d_hi;
     a.col_max = d_cm;
     a.node_sizes = d_out;
-    int rc;
-    switch (nf) {
-        case 8: rc = launch_k4_nf<8>(c, a, block, lds); break;
-        case 4: rc = launch_k4_nf<4>(c, a, block, lds); break;
-        case 2: rc = launch_k4_nf<2>(c, a, block, lds); break;
-        default: rc = launch_k4_nf<1>(c, a, block, lds); break;
+    int rc = 0;
+    // sub-batches bound the table scratch (65,536 families = 1 GB at 31 internal nodes x 258 rows)
+    const int batch = tables_global ? 65536 : B;
+    for (int b0 = 0; b0 < B && rc == 0; b0 += batch) {
+        K4Args ab = a;
+        ab.B = std::min(batch, B - b0);
+        ab.counts = d_cnt + (size_t)b0 * c->n_leaves;
+        ab.root_lo = d_lo + b0;
+        ab.root_hi = d_hi + b0;
+        ab.col_max = d_cm + b0;
+        ab.node_sizes = d_out + (size_t)b0 * c->n_nodes;
+        ab.vit_global = tables_global ? c->d_vit : nullptr;
+        switch (nf) {
+            case 8: rc = launch_k4_nf<8>(c, ab, block, lds); break;
+            case 4: rc = launch_k4_nf<4>(c, ab, block, lds); break;
+            case 2: rc = launch_k4_nf<2>(c, ab, block, lds); break;
+            default: rc = launch_k4_nf<1>(c, ab, block, lds); break;
+        }
     }
     if (rc) { cleanup(); return -1; }
     TRY3(hipMemcpyAsync(node_sizes, d_out, (size_t)B * c->n_nodes * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
