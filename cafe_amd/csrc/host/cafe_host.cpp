@@ -1504,7 +1504,18 @@ struct cafehost_session {
         const int npairs = n - 1;
         std::vector<double> avg_exp(npairs, 0.0);
         std::vector<int> n_expand(npairs, 0), n_remain(npairs, 0), n_decrease(npairs, 0);
-        for (int i = 0; i < F; ++i) {
+        // families are independent here; worker threads take contiguous blocks and keep private integer tallies
+        // (exact in any order), so the report does not depend on the thread count
+        struct Tally {
+            std::vector<long long> delta;
+            std::vector<int> expand, remain, decrease;
+        };
+        auto work = [&](int i0, int i1, Tally& t) {
+            t.delta.assign(npairs, 0);
+            t.expand.assign(npairs, 0);
+            t.remain.assign(npairs, 0);
+            t.decrease.assign(npairs, 0);
+            for (int i = i0; i < i1; ++i) {
             // cafe_tree_p_values (cafe/pvalue.cpp:143-154) + viterbi_set_max_pvalue (cafe/viterbi.cpp:32-39)
             const int rf = hi[i] - lo[i] + 1;
             double maxp = 0;
@@ -1520,10 +1531,10 @@ struct cafehost_session {
                 const int child[2] = {tree.left[node], tree.right[node]};
                 for (int k = 0; k < 2; ++k) {
                     const int m = 2 * j + k;
-                    if (fs[child[k]] > fs[node]) n_expand[m]++;
-                    else if (fs[child[k]] == fs[node]) n_remain[m]++;
-                    else n_decrease[m]++;
-                    avg_exp[m] += fs[child[k]] - fs[node];
+                    if (fs[child[k]] > fs[node]) t.expand[m]++;
+                    else if (fs[child[k]] == fs[node]) t.remain[m]++;
+                    else t.decrease[m]++;
+                    t.delta[m] += fs[child[k]] - fs[node];
                 }
             }
             if (maxp > pvalue) continue;  // cafe/viterbi.cpp:105-114: branch p-values stay -1
@@ -1542,6 +1553,24 @@ struct cafehost_session {
                     rep_branch_p[(size_t)i * (n - 1) + 2 * j + k] = acc;
                 }
             }
+            }
+        };
+        {
+            const int workers = std::max(1, std::min<int>({(int)std::thread::hardware_concurrency(), 32, (F + 1023) / 1024}));
+            std::vector<Tally> tallies(workers);
+            std::vector<std::thread> pool;
+            for (int w = 0; w < workers; ++w)
+                pool.emplace_back([&, w] { work((int)((long long)F * w / workers), (int)((long long)F * (w + 1) / workers), tallies[w]); });
+            for (auto& th : pool) th.join();
+            std::vector<long long> delta(npairs, 0);
+            for (auto& t : tallies)
+                for (int m = 0; m < npairs; ++m) {
+                    delta[m] += t.delta[m];
+                    n_expand[m] += t.expand[m];
+                    n_remain[m] += t.remain[m];
+                    n_decrease[m] += t.decrease[m];
+                }
+            for (int m = 0; m < npairs; ++m) avg_exp[m] = (double)delta[m];
         }
         for (double& v : avg_exp) v /= std::max(F, 1);
         lap("p-values (host)");
@@ -1596,35 +1625,44 @@ struct cafehost_session {
                 pos = b + 1;
             }
         }
-        std::string line;
-        char num[64];
-        for (int i = 0; i < F; ++i) {
-            const int32_t* fs = &rep_sizes[(size_t)i * n];
-            line.clear();
-            line += fam.ids[i];
-            line += '\t';
-            for (size_t h = 0; h < hole_node.size(); ++h) {
-                line += pieces[h];
-                snprintf(num, sizeof num, "%d", fs[hole_node[h]]);
-                line += num;
-            }
-            line += pieces.back();
-            line += '\t';
-            snprintf(num, sizeof num, "%g", rep_max_p[i]);
-            line += num;
-            line += "\t(";
-            for (int b = 0; b < npairs / 2; ++b) {
-                const double p1 = rep_branch_p[(size_t)i * (n - 1) + 2 * b], p2 = rep_branch_p[(size_t)i * (n - 1) + 2 * b + 1];
-                if (p1 < 0) {
-                    line += "(-,-)";
-                } else {
-                    snprintf(num, sizeof num, "(%g,%g)", p1, p2);
-                    line += num;
+        // rows are formatted by worker threads over contiguous blocks of families and written in family order
+        auto format_rows = [&](int i0, int i1, std::string& out) {
+            char num[64];
+            for (int i = i0; i < i1; ++i) {
+                const int32_t* fs = &rep_sizes[(size_t)i * n];
+                out += fam.ids[i];
+                out += '\t';
+                for (size_t h = 0; h < hole_node.size(); ++h) {
+                    out += pieces[h];
+                    snprintf(num, sizeof num, "%d", fs[hole_node[h]]);
+                    out += num;
                 }
-                if (b < npairs / 2 - 1) line += ',';
+                out += pieces.back();
+                out += '\t';
+                snprintf(num, sizeof num, "%g", rep_max_p[i]);
+                out += num;
+                out += "\t(";
+                for (int b = 0; b < npairs / 2; ++b) {
+                    const double p1 = rep_branch_p[(size_t)i * (n - 1) + 2 * b], p2 = rep_branch_p[(size_t)i * (n - 1) + 2 * b + 1];
+                    if (p1 < 0) {
+                        out += "(-,-)";
+                    } else {
+                        snprintf(num, sizeof num, "(%g,%g)", p1, p2);
+                        out += num;
+                    }
+                    if (b < npairs / 2 - 1) out += ',';
+                }
+                out += ")\t\n";
             }
-            line += ")\t\n";
-            fwrite(line.data(), 1, line.size(), fp);
+        };
+        {
+            const int workers = std::max(1, std::min<int>({(int)std::thread::hardware_concurrency(), 32, (F + 2047) / 2048}));
+            std::vector<std::string> chunks(workers);
+            std::vector<std::thread> pool;
+            for (int w = 0; w < workers; ++w)
+                pool.emplace_back([&, w] { format_rows((int)((long long)F * w / workers), (int)((long long)F * (w + 1) / workers), chunks[w]); });
+            for (auto& th : pool) th.join();
+            for (auto& c : chunks) fwrite(c.data(), 1, c.size(), fp);
         }
         fclose(fp);
         lap("writing the file");
