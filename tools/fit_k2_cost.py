@@ -71,7 +71,7 @@ def regret(P, data, verbose=False):
 
 
 def main():
-    data = load(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/sw")
+    data = load(sys.argv[1] if len(sys.argv) > 1 else "profiles/r01_k2_sweeps")
     P0 = {"wpen": [0, 1.25, 1.09, 1.05, 1.0, 1.1, 1.2, 1.25, 1.3], "restream": 0.002, "imb": 0.8, "f4": 1.07, "gpen": 0.9}
     print("current constants: mean regret %.2f %%" % (100 * regret(P0, data, True)))
     rnd = random.Random(1)
