@@ -72,7 +72,7 @@ def regret(P, data, verbose=False):
 
 def main():
     data = load(sys.argv[1] if len(sys.argv) > 1 else "profiles/r01_k2_sweeps")
-    P0 = {"wpen": [0, 1.25, 1.09, 1.05, 1.0, 1.1, 1.2, 1.25, 1.3], "restream": 0.002, "imb": 0.8, "f4": 1.07, "gpen": 0.9}
+    P0 = {"wpen": [0, 1.1, 1.0, 1.0, 1.0, 0.975, 0.95, 0.925, 0.9], "restream": 0.001, "imb": 0.2, "f4": 1.07, "gpen": 0.5}  # as in cafehip.hip
     print("current constants: mean regret %.2f %%" % (100 * regret(P0, data, True)))
     rnd = random.Random(1)
     best, bestP = regret(P0, data), P0
