@@ -1,14 +1,16 @@
 // cafehip.hip -- MI355X (gfx950) kernels and C ABI for CAFE's per-family likelihood
 // hot path.  See include/cafehip.h for the boundary and DESIGN.md for the layout.
 //
-//   K1  k1_build_matrices   birth-death transition matrices for every unique
+//   K1  k1_build_matrices[_rb]  birth-death transition matrices for every unique
 //                           (int branch length, lambda, mu) key of one evaluation
 //                           == compute_birthdeath_rates, libtree/birthdeath.c:238-286
-//   K2  k2_prune_*          post-order pruning of ALL families in one launch + the
-//                           per-family posterior == compute_tree_likelihoods +
-//                           compute_posterior, cafe/cafe_tree.c:191-323, cafe/lambda.cpp:657-689
+//       k1e_fold_error      error model folded into those matrices (posterior path), cafe/cafe_tree.c:196-203
+//   K2  k2_prune_mfma[4]    post-order pruning of ALL families in one launch + the
+//       (k2_mfma.hpp),      per-family posterior == compute_tree_likelihoods +
+//       k2_prune_v1         compute_posterior, cafe/cafe_tree.c:191-323, cafe/lambda.cpp:657-689
 //   K3  k3_score            per-chunk sums of log max-posterior in family order and the
 //                           first zero-likelihood family == get_posterior, cafe/lambda.cpp:691-724
+//   K4  k4_viterbi          max-product walk + backtrack == cafe_tree_viterbi, cafe/viterbi.cpp:208-351
 //
 // gfx950 only.  No CPU fallback: every entry point fails if the device work fails.
 #include <hip/hip_runtime.h>
