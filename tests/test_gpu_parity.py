@@ -345,6 +345,8 @@ def test_matrices_extreme_rates_all_k1_forms(eng, m):
         os.environ.pop("CAFEHIP_K1", None)
 
 
+@pytest.mark.skipif(any(os.environ.get(k) for k in ("CAFEHIP_MFMA", "CAFEHIP_K2CFG", "CAFEHIP_K2CFG4", "CAFEHIP_K2")) or
+                    os.environ.get("CAFEHIP_K2TUNE") == "0", reason="the wave grid is pinned by the environment")
 def test_measured_grid_choice_never_changes_a_bit():
     # the first evaluations of a table run different K2 wave grids (both instruction shapes) while the engine
     # measures them; every one of those evaluations must return exactly the same per-family values
