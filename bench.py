@@ -149,9 +149,10 @@ def main():
     # engine priming (not part of the W warm-up steps the caller asked for): the first launches after set-up
     # allocate the scratch buffers, measure the K2 wave grids (~15 evaluations) and run while the GPU is still
     # leaving its idle power state -- at least 30 evaluations and at least 0.25 s of them
+    # (with several ranks every step contains a collective, so the count must be the same everywhere: fixed)
     PRIMING = 0
     t_prime = time.perf_counter()
-    while PRIMING < 30 or time.perf_counter() - t_prime < 0.25:
+    while (PRIMING < 1000) if multi else (PRIMING < 30 or time.perf_counter() - t_prime < 0.25):
         one_step(PRIMING % max(1, args.warmup + args.steps))
         PRIMING += 1
     last = None
