@@ -1,0 +1,40 @@
+"""bench.py's output contract: ONE JSON line on stdout with the keys the driver reads, the roofline object of the
+dominant kernel and the CPU baseline timed beside it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "2"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 16 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["unit"] == "family-evals/s" and d["value"] > 1e6          # north-star floor: 10^6 evaluations/s
+    assert abs(d["value"] - d["config"]["families_per_gpu"] * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and 0 < c["value"] < d["value"]
+    # the parity gate recorded with the timing: per-family log posterior vs the oracle
+    assert c["gpu_vs_oracle_max_rel_err_log_posterior"] < 1e-6
