@@ -27,11 +27,13 @@ SIGNATURES = {
     "cafehip_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int)]),
     "cafehip_matrix_size": (C.c_int, [C.c_void_p]),
     "cafehip_reset_birthdeath_cache": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "cafehip_set_exact_matrices": (C.c_int, [C.c_void_p, C.c_int]),
     "cafehip_eval_root_likelihoods": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip, _dp]),
     "cafehip_viterbi": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip, _ip]),
     "cafehip_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cafehip_fetch_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "cafehip_last_kernel_ms": (C.c_int, [C.c_void_p, _dp]),
+    "cafehip_last_batch_ms": (C.c_int, [C.c_void_p, _dp]),
     "cafehip_describe": (C.c_char_p, [C.c_void_p]),
     "cafehip_last_error": (C.c_char_p, []),
 }

@@ -12,6 +12,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcafehip.so")
 
 SOURCES = ["cafehip.hip", os.path.join("host", "cafe_host.cpp")]
+PROBE_LIB = os.path.join(LIBDIR, "libcafeprobe.so")   # measured HBM / MFMA ceilings for bench.py (csrc/probe.hip)
 BINDIR = os.path.join(HERE, "bin")
 CLI = os.path.join(BINDIR, "cafehip")
 DEPS = ["cafehip.hip", "k2_mfma.hpp", "host_math.hpp", "schedule.hpp", os.path.join("host", "cafe_host.cpp"),
@@ -29,13 +30,21 @@ def hipcc():
 
 
 def needs_build():
-    if not os.path.exists(LIB) or not os.path.exists(CLI):
+    if not os.path.exists(LIB) or not os.path.exists(CLI) or not os.path.exists(PROBE_LIB):
         return True
     t = os.path.getmtime(LIB)
+    if os.path.getmtime(os.path.join(CSRC, "probe.hip")) > os.path.getmtime(PROBE_LIB):
+        return True
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
 def build(force=False, verbose=False):
+    # debugging / A-B runs: CAFEHIP_LIB=<path> loads a variant library built by tools/build_variant.py
+    override = os.environ.get("CAFEHIP_LIB")
+    if override:
+        if not os.path.exists(override):
+            raise RuntimeError("CAFEHIP_LIB=%s does not exist" % override)
+        return override
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
@@ -50,6 +59,11 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cli))
     subprocess.check_call(cli)
+    probe = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", PROBE_LIB,
+             os.path.join(CSRC, "probe.hip")]
+    if verbose:
+        print(" ".join(probe))
+    subprocess.check_call(probe)
     return LIB
 
 

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdarg>
@@ -853,8 +854,13 @@ struct cafehip_ctx {
     double *d_lncA = nullptr, *d_lncB = nullptr;
     double *d_expA = nullptr, *d_expB = nullptr;
     bool all_keys_fast = false, k1_product_form = false;
+    bool force_exact = false;   // cafehip_set_exact_matrices: the reference's per-term arithmetic for the next builds
     size_t k1rb_lds_attr = 0;
     size_t k1_lds_attr = 0;
+    // hipFuncAttributeMaxDynamicSharedMemorySize already granted, per kernel instantiation: the attribute is
+    // per DEVICE, so the high-water marks live in the context (several contexts of one process may sit on
+    // different GPUs)
+    std::unordered_map<const void*, size_t> lds_attr;
     double* d_PT = nullptr;
     unsigned short* d_vit = nullptr;   // Viterbi argmax tables (global scratch, grow-only)
     size_t vit_cap = 0;
@@ -893,6 +899,7 @@ struct cafehip_ctx {
     bool timing = false, timing_pending = false;
     hipEvent_t ev[4] = {};
     double last_ms[3] = {0, 0, 0};
+    double last_batch_ms = 0;   // pruning launch of the last cafehip_eval_root_likelihoods call
     int k2_nf = 0, k2_block = 0;
     size_t k2_lds = 0;
     // measured choice of the K2 wave grid (posterior path): see launch_k2_mfma
@@ -905,6 +912,10 @@ struct cafehip_ctx {
         hipEvent_t e0 = nullptr, e1 = nullptr;
     } tune;
     std::string desc;
+#ifdef CAFE_K2_STAMPS
+    unsigned long long* d_stamps = nullptr;   // debug timeline of the last K2 launch (tools/k2_stamps.py)
+    size_t stamps_cap = 0;
+#endif
 };
 
 namespace {
@@ -919,6 +930,17 @@ void free_family_buffers(cafehip_ctx* c)
     hipFree(c->d_chunk_sums);
     c->d_counts = c->d_fam2u = c->d_argmax = nullptr;
     c->d_max_lik = c->d_max_post = c->d_chunk_sums = nullptr;
+}
+
+// dynamic LDS above the default limit must be granted per kernel and per device
+int grant_lds(cafehip_ctx* c, const void* fn, size_t lds, size_t default_limit)
+{
+    if (lds <= default_limit) return 0;
+    size_t& have = c->lds_attr[fn];
+    if (lds <= have) return 0;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    have = lds;
+    return 0;
 }
 
 int ensure_matrix_storage(cafehip_ctx* c)
@@ -1048,7 +1070,7 @@ int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr)
         c->k1_lds_attr = lds;
     }
     const char* k1env = getenv("CAFEHIP_K1");
-    const bool product = c->lnc.product_form_ok && c->all_keys_fast && !(k1env && strcmp(k1env, "exact") == 0);
+    const bool product = c->lnc.product_form_ok && c->all_keys_fast && !c->force_exact && !(k1env && strcmp(k1env, "exact") == 0);
     c->k1_product_form = product;
     const bool blocked = product && !(k1env && strcmp(k1env, "perterm") == 0);
     const size_t lds_rb = 16 * (size_t)((c->lnc.ld + 8) + (c->lnc.ld + K1_BPAD + 8)) * sizeof(double);
@@ -1138,15 +1160,11 @@ int launch_k2_v1(cafehip_ctx* c, K2Args& a, int n_items)
 
 
 // ---- MFMA launcher -------------------------------------------------------------------
+constexpr int kMaxTiles16 = 8;      // NFT_W * NRT_W accumulator tiles per wave (16x16x4 shape)
 template <int NFT_W, int NRT_W>
 int launch_mfma_inst(cafehip_ctx* c, const K2MfmaArgs& a, int grid, int block, size_t lds)
 {
-    static size_t attr_bytes = 0;
-    if (lds > 64 * 1024 && lds > attr_bytes) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_prune_mfma<NFT_W, NRT_W>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_bytes = lds;
-    }
+    if (grant_lds(c, reinterpret_cast<const void*>(&k2_prune_mfma<NFT_W, NRT_W>), lds, 64 * 1024)) return -1;
     hipLaunchKernelGGL((k2_prune_mfma<NFT_W, NRT_W>), dim3(grid), dim3(block), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1155,17 +1173,18 @@ int launch_mfma_inst(cafehip_ctx* c, const K2MfmaArgs& a, int grid, int block, s
 template <int NFT_W>
 int launch_mfma_nrt(cafehip_ctx* c, const K2MfmaArgs& a, int nrt_w, int grid, int block, size_t lds)
 {
+    // only the (NFT_W, NRT_W) pairs within the register budget (NFT_W * NRT_W <= 8 accumulator tiles, NRT_W <= 7:
+    // no scratch spills) are instantiated
+#define CAFE_M16(N)                                                             \
+    case N:                                                                     \
+        if constexpr (NFT_W * N <= kMaxTiles16 && N <= 7)                       \
+            return launch_mfma_inst<NFT_W, N>(c, a, grid, block, lds);          \
+        break;
     switch (nrt_w) {
-        case 1: return launch_mfma_inst<NFT_W, 1>(c, a, grid, block, lds);
-        case 2: return launch_mfma_inst<NFT_W, 2>(c, a, grid, block, lds);
-        case 3: return launch_mfma_inst<NFT_W, 3>(c, a, grid, block, lds);
-        case 4: return launch_mfma_inst<NFT_W, 4>(c, a, grid, block, lds);
-        case 5: return launch_mfma_inst<NFT_W, 5>(c, a, grid, block, lds);
-        case 6: return launch_mfma_inst<NFT_W, 6>(c, a, grid, block, lds);
-        case 7: return launch_mfma_inst<NFT_W, 7>(c, a, grid, block, lds);
-        case 8: return launch_mfma_inst<NFT_W, 8>(c, a, grid, block, lds);
+        CAFE_M16(1) CAFE_M16(2) CAFE_M16(3) CAFE_M16(4) CAFE_M16(5) CAFE_M16(6) CAFE_M16(7)
     }
-    return fail("unsupported NRT_W %d", nrt_w);
+#undef CAFE_M16
+    return fail("unsupported 16x16 wave grid NFT_W=%d NRT_W=%d", NFT_W, nrt_w);
 }
 
 // The park buffers (node vectors waiting for their sibling) stay in LDS when the whole set still lets two
@@ -1246,7 +1265,7 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_
     if (const char* e = getenv("CAFEHIP_K2CFG")) {
         K2Cfg k;
         if (sscanf(e, "%d,%d,%d,%d", &k.nft_w, &k.nrt_w, &k.wf, &k.wr) == 4 && k.nft_w >= 1 && k.nft_w <= 2 &&
-            k.nrt_w >= 1 && k.nrt_w <= 7 && k.nft_w * k.nrt_w <= 8 && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 && k.wr * k.nrt_w >= RT &&
+            k.nrt_w >= 1 && k.nrt_w <= 7 && k.nft_w * k.nrt_w <= kMaxTiles16 && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 && k.wr * k.nrt_w >= RT &&
             mfma_lds_bytes(c, 16 * k.nft_w * k.wf, n_items) <= (size_t)c->lds_limit) {
             *out = k;
             *out_cost = 0;
@@ -1259,7 +1278,7 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_
         const int nrt_w = (RT + wr - 1) / wr;
         if (nrt_w > 7) continue;  // register budget: NFT_W * NRT_W <= 8 accumulator tiles, no spills
         for (int nft_w = 1; nft_w <= 2; ++nft_w) {
-            if (nft_w * nrt_w > 8) continue;
+            if (nft_w * nrt_w > kMaxTiles16) continue;
             for (int wf = 1; wf * wr <= 8; wf *= 2) {
                 const int nf = 16 * nft_w * wf;
                 if (mfma_lds_bytes(c, nf, n_items) > (size_t)c->lds_limit) continue;
@@ -1278,7 +1297,7 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_
 }
 
 // 4x4x4_4b shape: NF = 4 * G * wf (K2Cfg.nft_w carries G).  CAFEHIP_K2CFG4="G,nrtw,wf,wr" overrides.
-constexpr int kMaxGroupTiles = 24;  // G * NRT_W accumulators per wave (register budget)
+constexpr int kMaxGroupTiles = 21;  // G * NRT_W accumulators per wave (register budget: 24 spills to scratch)
 bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_cost, std::vector<K2Cand>* all = nullptr)
 {
     const int RT = (std::max(c->C, c->R) + 15) / 16;
@@ -1322,12 +1341,7 @@ bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out
 template <int G, int NRT_W>
 int launch_mfma4_inst(cafehip_ctx* c, const K2MfmaArgs& a, int grid, int block, size_t lds)
 {
-    static size_t attr_bytes = 0;
-    if (lds > 64 * 1024 && lds > attr_bytes) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_prune_mfma4<G, NRT_W>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_bytes = lds;
-    }
+    if (grant_lds(c, reinterpret_cast<const void*>(&k2_prune_mfma4<G, NRT_W>), lds, 64 * 1024)) return -1;
     hipLaunchKernelGGL((k2_prune_mfma4<G, NRT_W>), dim3(grid), dim3(block), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1529,6 +1543,21 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     c->k2_lds = lds;
     c->k2_used_mfma = true;
     c->k2_shape4 = use4;
+#ifdef CAFE_K2_STAMPS
+    const char* stamps_file = getenv("CAFEHIP_STAMPS_FILE");
+    const size_t stamps_n = (size_t)grid * 8 * K2_STAMP_SLOTS;
+    if (stamps_file) {
+        if (stamps_n > c->stamps_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            hipFree(c->d_stamps);
+            c->d_stamps = nullptr;
+            HIP_TRY(hipMalloc(&c->d_stamps, stamps_n * sizeof(unsigned long long)));
+            c->stamps_cap = stamps_n;
+        }
+        HIP_TRY(hipMemsetAsync(c->d_stamps, 0, stamps_n * sizeof(unsigned long long), c->stream));
+        a.stamps = c->d_stamps;
+    }
+#endif
     if (tuning_launch) HIP_TRY(hipEventRecord(c->tune.e0, c->stream));
     int rc;
     if (use4) rc = launch_mfma4_g(c, a, k.nft_w, k.nrt_w, grid, block, lds);
@@ -1538,6 +1567,21 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
         HIP_TRY(hipEventRecord(c->tune.e1, c->stream));
         c->tune.pending = true;
     }
+#ifdef CAFE_K2_STAMPS
+    if (rc == 0 && stamps_file) {
+        // header: grid, waves per workgroup, slots, n_ops, NF, shape (4 / 16), then the raw stamps (overwritten per launch)
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<unsigned long long> h(stamps_n);
+        HIP_TRY(hipMemcpy(h.data(), c->d_stamps, stamps_n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(stamps_file, "wb")) {
+            const long long hdr[8] = {grid, block / 64, K2_STAMP_SLOTS, a.n_ops, nf, use4 ? 4 : 16, k.wf, k.wr};
+            fwrite(hdr, sizeof hdr, 1, f);
+            fwrite(c->msched.ops.data(), sizeof(cafehip::MfmaOp), c->msched.ops.size(), f);
+            fwrite(h.data(), sizeof(unsigned long long), stamps_n, f);
+            fclose(f);
+        }
+    }
+#endif
     return rc;
 }
 
@@ -1642,12 +1686,7 @@ int collect_kernel_ms(cafehip_ctx* c)
 template <int NF>
 static int launch_k4_nf(cafehip_ctx* c, const K4Args& a, int block, size_t lds)
 {
-    static size_t attr_bytes = 0;
-    if (lds > 48 * 1024 && lds > attr_bytes) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k4_viterbi<NF>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_bytes = lds;
-    }
+    if (grant_lds(c, reinterpret_cast<const void*>(&k4_viterbi<NF>), lds, 48 * 1024)) return -1;
     const int grid = (a.B + NF - 1) / NF;
     hipLaunchKernelGGL(k4_viterbi<NF>, dim3(grid), dim3(block), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
@@ -1743,6 +1782,7 @@ void cafehip_destroy(cafehip_ctx* c)
 int cafehip_set_stream(cafehip_ctx* c, void* hip_stream)
 {
     if (!c) return fail("null context");
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     // NULL is a real stream in HIP (the legacy default stream, which is also what
     // torch.cuda.current_stream().cuda_stream returns unless a side stream is current)
@@ -2031,6 +2071,9 @@ int cafehip_eval_posterior(cafehip_ctx* c, const double* node_lambda, const doub
     } else {
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    // the payload below was written before the sequence number (device-side system fence): order our reads after
+    // the flag read
+    std::atomic_thread_fence(std::memory_order_acquire);
     if (collect_kernel_ms(c)) return -1;
     // fixed-order final sum over chunks (independent of how chunks were produced)
     double s = 0.0;
@@ -2066,6 +2109,13 @@ int cafehip_reset_birthdeath_cache(cafehip_ctx* c, const double* node_lambda, co
     if (stage_params(c, node_lambda, node_mu, nullptr, &h)) return -1;
     if (launch_k1(c)) return -1;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int cafehip_set_exact_matrices(cafehip_ctx* c, int on)
+{
+    if (!c) return fail("null context");
+    c->force_exact = on != 0;
     return 0;
 }
 
@@ -2135,11 +2185,18 @@ int cafehip_eval_root_likelihoods(cafehip_ctx* c, int B, const int32_t* counts, 
     // the reference drops the error model on tree copies (cafe/cafe_tree.c:485-494): not applied here
     double* saved_err = c->d_err;
     c->d_err = nullptr;
+    if (c->timing) TRY2(hipEventRecord(c->ev[1], c->stream));
     rc = launch_k2(c, a, B);
     c->d_err = saved_err;
     if (rc) { cleanup(); return -1; }
+    if (c->timing) TRY2(hipEventRecord(c->ev[2], c->stream));
     TRY2(hipMemcpyAsync(out, d_out, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TRY2(hipStreamSynchronize(c->stream));
+    if (c->timing) {
+        float ms = 0;
+        TRY2(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+        c->last_batch_ms = ms;
+    }
 #undef TRY2
     cleanup();
     return 0;
@@ -2293,6 +2350,7 @@ int cafehip_fetch_small(cafehip_ctx* c, const void* d_src, size_t nbytes, const 
             if (q != hipErrorNotReady) return fail("stream error while waiting: %s", hipGetErrorString(q));
         }
     }
+    std::atomic_thread_fence(std::memory_order_acquire);  // payload reads stay behind the flag read
     *host_ptr = c->h_fetch + 1;
     return 0;
 }
@@ -2309,6 +2367,13 @@ int cafehip_last_kernel_ms(cafehip_ctx* c, double ms[3])
     if (!c) return fail("null context");
     if (collect_kernel_ms(c)) return -1;  // the asynchronous entry point leaves the events pending
     for (int i = 0; i < 3; ++i) ms[i] = c->last_ms[i];
+    return 0;
+}
+
+int cafehip_last_batch_ms(cafehip_ctx* c, double* ms)
+{
+    if (!c || !ms) return fail("null argument");
+    *ms = c->last_batch_ms;
     return 0;
 }
 

@@ -1431,7 +1431,7 @@ struct cafehost_session {
         // for the exact ==/< comparisons of viterbi_sum_probabilities
         std::vector<double> nl_, nm_;
         node_rates(params.data(), nl_, nm_);
-        hip_check(cafehip_reset_birthdeath_cache(ctx, nl_.data(), nm_.data()));
+        reset_cache_exact(nl_, nm_);
         const int S = cafehip_matrix_size(ctx);
         std::vector<std::vector<double>> mats(tree.n);
         for (int v = 0; v < tree.n; ++v) {
@@ -1785,6 +1785,18 @@ struct cafehost_session {
         return prefix;
     }
 
+    // Matrices of the report phase (Monte-Carlo null, Viterbi, branch p-values, genfamily, rootdist) are built in
+    // the reference's per-term arithmetic: random draws are compared with cumulative sums of matrix rows
+    // (cafe/cafe_tree.c:533-569) and viterbi_sum_probabilities uses exact == / < on entries
+    // (cafe/viterbi.cpp:60-67), so a last-bit difference can flip a decision; the build is a one-off here.
+    void reset_cache_exact(const std::vector<double>& nl_, const std::vector<double>& nm_)
+    {
+        hip_check(cafehip_set_exact_matrices(ctx, 1));
+        const int rc = cafehip_reset_birthdeath_cache(ctx, nl_.data(), nm_.data());
+        cafehip_set_exact_matrices(ctx, 0);
+        hip_check(rc);
+    }
+
     // matrices for the current parameters on the device + host copies (node -> S x S)
     int fetch_matrices(std::vector<std::vector<double>>& mats)
     {
@@ -1793,7 +1805,7 @@ struct cafehost_session {
         upload();
         std::vector<double> nl_, nm_;
         node_rates(params.data(), nl_, nm_);
-        hip_check(cafehip_reset_birthdeath_cache(ctx, nl_.data(), nm_.data()));
+        reset_cache_exact(nl_, nm_);
         const int S = cafehip_matrix_size(ctx);
         mats.assign(tree.n, {});
         for (int v = 0; v < tree.n; ++v) {
@@ -1952,6 +1964,9 @@ struct cafehost_session {
     // get_posterior for the current parameters and a given prior (cafe/lambda.cpp:691-724), -inf on a zero family
     double posterior_with_prior(const std::vector<double>& pr)
     {
+        if (shard_world > 1)
+            throw std::runtime_error("lhtest scores whole tables with its own prior: run it on one rank "
+                                     "(the exchange buffers of a sharded session are sized for the table of the last `lambda`)");
         upload();
         std::vector<double> nl_, nm_;
         node_rates(params.data(), nl_, nm_);
@@ -1968,6 +1983,9 @@ struct cafehost_session {
     int cmd_lhtest(const std::vector<std::string>& tokens)
     {  // cafe_cmd_lhtest, cafe/cafe_commands.cpp:1473-1536
         prereqs(false, true);
+        if (shard_world > 1)
+            throw std::runtime_error("lhtest is not sharded: every file it loads would need the exchange re-wired; "
+                                     "run it on one rank (its searches are independent: split the directory over ranks instead)");
         std::string dir, ltree, outfile;
         double lam = 0.0;
         for (auto& a : build_argument_list(tokens)) {

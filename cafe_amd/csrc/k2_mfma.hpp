@@ -55,7 +55,24 @@ struct K2MfmaArgs {
     double* max_lik;
     int32_t* argmax;
     double* max_post;
+    // debug builds (-DCAFE_K2_STAMPS): s_memtime stamps [workgroup][wave][K2_STAMP_SLOTS], else NULL and unused
+    unsigned long long* stamps;
 };
+
+// Phase timeline of the walk for tools/k2_stamps.py: lane 0 of every wave records the shader clock at fixed points
+// (slot 0 kernel start, 1 after the prologue, 2 + 6 * step + {0: leaf gathers issued, 1: first child factor done,
+// 2: second child factor done, 3: past the read barrier, 4: result written + visible}, last: after the epilogue).
+// Compiled out of the product library.
+constexpr int K2_STAMP_SLOTS = 512;
+#ifdef CAFE_K2_STAMPS
+#define K2_STAMP(slot)                                                                                         \
+    do {                                                                                                       \
+        if (a.stamps && lane == 0 && (slot) < K2_STAMP_SLOTS)                                                  \
+            a.stamps[((size_t)blockIdx.x * 8 + wave) * K2_STAMP_SLOTS + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define K2_STAMP(slot) ((void)0)
+#endif
 
 // Error model folded into the matrices (posterior mode).  For a leaf with an error model the edge factor of a
 // family is  sum_k errormatrix[observed][k] * P[row][k]  (cafe/cafe_tree.c:196-203 then :213-224), a function of
@@ -140,6 +157,137 @@ __device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const i
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Explicitly software-pipelined edge product (CAFE_K2_DEPTH = D >= 2, the default).
+// hipcc schedules the two-stage source loop above (mfma_edge / mfma4_edge) into
+//     [3 B loads for k+1] [15 MFMAs of k] [3 B loads for k+2, 5 ds_read2 for k+1 AND k+2] wait lgkmcnt [15 MFMAs of k+1]
+// i.e. the LDS latency of the A operand is exposed once per two k-steps and the B operand has ONE k-step of
+// MFMAs (240 cycles alone, ~400 shared with the SIMD's other wave) to cover an L2 round trip of ~500 cycles
+// (disassembly of k2_prune_mfma4<5,3>, round 2).  Here both operands live in rings of D k-steps: region k
+// (fenced by sched_barrier, so no load can sink below or hoist above it) issues the loads of k-step k + D - 1
+// and the matrix instructions of k-step k, so every operand has D - 1 whole regions to arrive wherever the
+// in-region scheduler puts its load.  Loads past the last k-step are clamped to it (valid addresses, values
+// unused).  Same instructions on the same operands in the same order per accumulator: bit-identical results.
+// ---------------------------------------------------------------------------------------------------
+#ifndef CAFE_K2_DEPTH
+#define CAFE_K2_DEPTH 3
+#endif
+#ifndef CAFE_K2_INTERLEAVE
+#define CAFE_K2_INTERLEAVE 1
+#endif
+
+// inside a region: one operand load, then its share of the matrix instructions, ... so that the loads issue in
+// the shadow of this wave's own MFMAs instead of ahead of them (sched_group_barrier: 0x20 VMEM read, 0x100 DS
+// read, 0x8 MFMA)
+template <int N_VMEM, int N_DS, int N_MFMA>
+__device__ __forceinline__ void k2_region_pattern()
+{
+#if CAFE_K2_INTERLEAVE
+    constexpr int n_loads = N_VMEM + N_DS;
+    constexpr int q = N_MFMA / n_loads > 0 ? N_MFMA / n_loads : 1;
+#pragma unroll
+    for (int i = 0; i < N_VMEM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, q, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < N_DS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, q, 0);
+    }
+    if constexpr (N_MFMA - q * n_loads > 0) __builtin_amdgcn_sched_group_barrier(0x8, N_MFMA - q * n_loads, 0);
+#endif
+}
+
+template <int NFT_W, int NRT_W, int NT, int D>
+__device__ __forceinline__ void mfma_edge_p(const double* __restrict__ bp, const int (&boff)[NRT_W],
+                                            size_t kstride, const double* ap, int astride, int ksteps,
+                                            cafe_d4 (&acc)[NFT_W][NRT_W])
+{
+    double aq[D][NFT_W], bq[D][NT];
+    const int klast = ksteps - 1;
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) {
+        const int kk = min(d, klast);
+#pragma unroll
+        for (int i = 0; i < NFT_W; ++i) aq[d][i] = ap[kk * 4 + i * astride];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bq[d][j] = bp[(size_t)kk * kstride + boff[j]];
+    }
+    int k0 = 0;
+#define CAFE_REGION16(u, k)                                                                                    \
+    {                                                                                                          \
+        const int kn = min((k) + D - 1, klast);                                                                \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[((u) + D - 1) % D][j] = bp[(size_t)kn * kstride + boff[j]]; \
+        _Pragma("unroll") for (int i = 0; i < NFT_W; ++i) aq[((u) + D - 1) % D][i] = ap[kn * 4 + i * astride];  \
+        _Pragma("unroll") for (int i = 0; i < NFT_W; ++i)                                                      \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[(u) % D][i], bq[(u) % D][j], acc[i][j], 0, 0, 0); \
+        k2_region_pattern<NT, NFT_W, NFT_W * NT>();                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (; k0 + D <= ksteps; k0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) CAFE_REGION16(u, k0 + u)
+    }
+#pragma unroll
+    for (int u = 0; u < D - 1; ++u)
+        if (k0 + u < ksteps) CAFE_REGION16(u, k0 + u)
+#undef CAFE_REGION16
+}
+
+template <int G, int NRT_W, int NT, int D>
+__device__ __forceinline__ void mfma4_edge_p(const double* __restrict__ bp, const int (&boff)[NRT_W],
+                                             size_t kstride, const double* ap4, int LDv, int ksteps,
+                                             double (&acc)[G][NRT_W])
+{
+    double aq[D][G], bq[D][NT];
+    const int klast = ksteps - 1;
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) {
+        const int kk = min(d, klast);
+#pragma unroll
+        for (int g = 0; g < G; ++g) aq[d][g] = ap4[kk * 4 + (size_t)(4 * g) * LDv];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bq[d][j] = bp[(size_t)kk * kstride + boff[j]];
+    }
+    int k0 = 0;
+#define CAFE_REGION4(u, k)                                                                                     \
+    {                                                                                                          \
+        const int kn = min((k) + D - 1, klast);                                                                \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[((u) + D - 1) % D][j] = bp[(size_t)kn * kstride + boff[j]]; \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) aq[((u) + D - 1) % D][g] = ap4[kn * 4 + (size_t)(4 * g) * LDv]; \
+        _Pragma("unroll") for (int g = 0; g < G; ++g)                                                          \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                     \
+                acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(aq[(u) % D][g], bq[(u) % D][j], acc[g][j], 0, 0, 0); \
+        k2_region_pattern<NT, G, G * NT>();                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (; k0 + D <= ksteps; k0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) CAFE_REGION4(u, k0 + u)
+    }
+#pragma unroll
+    for (int u = 0; u < D - 1; ++u)
+        if (k0 + u < ksteps) CAFE_REGION4(u, k0 + u)
+#undef CAFE_REGION4
+}
+
+
+template <int NFT_W, int NRT_W, int NT>
+__device__ __forceinline__ void k2_edge16(const double* __restrict__ bp, const int (&boff)[NRT_W], size_t kstride,
+                                          const double* ap, int astride, int ksteps, cafe_d4 (&acc)[NFT_W][NRT_W])
+{
+#if CAFE_K2_DEPTH >= 2
+    mfma_edge_p<NFT_W, NRT_W, NT, CAFE_K2_DEPTH>(bp, boff, kstride, ap, astride, ksteps, acc);
+#else
+    mfma_edge<NFT_W, NRT_W, NT>(bp, boff, kstride, ap, astride, ksteps, acc);
+#endif
+}
+
 template <int NFT_W, int NRT_W>
 __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 {
@@ -157,6 +305,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     const int wave = tid >> 6;
     const int li = lane & 15;   // row within a tile (B/D) or family within a tile (A)
     const int lk = lane >> 4;   // k within a step (A/B) or family group within a tile (D)
+    K2_STAMP(0);
     const int wf = wave % a.Wf;
     // workgroups of the second dispatch round share a CU with one of the first: rotate their row-tile deal by
     // half so that the waves carrying the odd extra tile do not pile up on the same SIMDs
@@ -184,6 +333,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
         s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
     }
     __syncthreads();
+    K2_STAMP(1);
 
     // this lane's families never change: their column limits are read once, not once per step
     int cmx[NFT_W][4];
@@ -282,14 +432,15 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                     const double* ap = Lsrc + (size_t)(ft0 * 16 + li) * a.LDv + lk;
                     if constexpr (NRT_W > 1) {
                         if (ntile == NRT_W - 1)
-                            mfma_edge<NFT_W, NRT_W, NRT_W - 1>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                            k2_edge16<NFT_W, NRT_W, NRT_W - 1>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
                         else
-                            mfma_edge<NFT_W, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                            k2_edge16<NFT_W, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
                     } else {
-                        mfma_edge<NFT_W, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                        k2_edge16<NFT_W, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
                     }
                 }
             }
+            K2_STAMP(2 + 6 * oi + 1 + ch);
             if (ch == 0) {
 #pragma unroll
                 for (int i = 0; i < NFT_W; ++i)
@@ -325,6 +476,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
             }
         } else {
             __syncthreads();  // every wave is done reading the buffers: overwrite in place
+            K2_STAMP(2 + 6 * oi + 3);
             double* dst = Lbuf + ((op.dst_park >= 0) ? (size_t)(1 + op.dst_park) * park_stride : 0);
             const int row0 = rt0 * 16 + li;
 #pragma unroll
@@ -341,6 +493,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
             }
             __syncthreads();
         }
+        K2_STAMP(2 + 6 * oi + 4);
     }
 
     // ---- root vector (in Lbuf) -> posterior (cafe/lambda.cpp:657-689) or packed root rows ----
@@ -384,6 +537,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
             a.max_post[u] = bestp;
         }
     }
+    K2_STAMP(2 + 6 * a.n_ops);
 }
 
 
@@ -463,6 +617,18 @@ __device__ __forceinline__ void mfma4_edge(const double* __restrict__ bp, const 
     }
 }
 
+
+template <int G, int NRT_W, int NT>
+__device__ __forceinline__ void k2_edge4(const double* __restrict__ bp, const int (&boff)[NRT_W], size_t kstride,
+                                         const double* ap4, int LDv, int ksteps, double (&acc)[G][NRT_W])
+{
+#if CAFE_K2_DEPTH >= 2
+    mfma4_edge_p<G, NRT_W, NT, CAFE_K2_DEPTH>(bp, boff, kstride, ap4, LDv, ksteps, acc);
+#else
+    mfma4_edge<G, NRT_W, NT>(bp, boff, kstride, ap4, LDv, ksteps, acc);
+#endif
+}
+
 template <int G, int NRT_W>
 __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 {
@@ -480,6 +646,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     const int wave = tid >> 6;
     const int li = lane & 15;
     const int lk = lane >> 4;
+    K2_STAMP(0);
     const int wf = wave % a.Wf;
     // workgroups of the second dispatch round share a CU with one of the first: rotate their row-tile deal by
     // half so that the waves carrying the odd extra tile do not pile up on the same SIMDs
@@ -507,6 +674,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
     }
     __syncthreads();
+    K2_STAMP(1);
 
     // this lane's families never change: their column limits are read once, not once per step
     int cmx[G];
@@ -549,6 +717,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
             }
         }
 
+        K2_STAMP(2 + 6 * oi + 0);
         bool first = true;
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
@@ -614,11 +783,11 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                     const double* ap4 = Lsrc + (size_t)(fbase + (lane & 3)) * a.LDv + lk;
                     if constexpr (NRT_W > 1) {
                         if (ntile == NRT_W - 1)
-                            mfma4_edge<G, NRT_W, NRT_W - 1>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
+                            k2_edge4<G, NRT_W, NRT_W - 1>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
                         else
-                            mfma4_edge<G, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
+                            k2_edge4<G, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
                     } else {
-                        mfma4_edge<G, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
+                        k2_edge4<G, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
                     }
                 }
             }
@@ -627,6 +796,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 #pragma unroll
                 for (int j = 0; j < NRT_W; ++j) hold[g][j] = first ? fac[g][j] : hold[g][j] * fac[g][j];
             first = false;
+            K2_STAMP(2 + 6 * oi + 1 + ch);
         }
         if (pre_ch >= 0) {
 #pragma unroll
@@ -651,6 +821,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
             }
         } else {
             __syncthreads();
+            K2_STAMP(2 + 6 * oi + 3);
             double* dst = Lbuf + ((op.dst_park >= 0) ? (size_t)(1 + op.dst_park) * park_stride : 0);
             const int row0 = rt0 * 16 + li;
 #pragma unroll
@@ -663,6 +834,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
             }
             __syncthreads();
         }
+        K2_STAMP(2 + 6 * oi + 4);
     }
 
     const int nwaves = blockDim.x >> 6;
@@ -704,4 +876,5 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
             a.max_post[u] = bestp;
         }
     }
+    K2_STAMP(2 + 6 * a.n_ops);
 }

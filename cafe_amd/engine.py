@@ -138,6 +138,10 @@ class Engine:
         nm = np.ascontiguousarray(node_mu, np.float64)
         _lib.check(self._L.cafehip_reset_birthdeath_cache(self._h, _d(nl), _d(nm)))
 
+    def set_exact_matrices(self, on=True):
+        """Matrix builds in the reference's per-term arithmetic (report phase) instead of the product form."""
+        _lib.check(self._L.cafehip_set_exact_matrices(self._h, 1 if on else 0))
+
     def get_matrix(self, node):
         S = self._L.cafehip_matrix_size(self._h)
         out = np.zeros((S, S))
@@ -179,6 +183,12 @@ class Engine:
         ms = (C.c_double * 3)()
         _lib.check(self._L.cafehip_last_kernel_ms(self._h, ms))
         return list(ms)
+
+    def last_batch_ms(self):
+        """Pruning-launch duration of the last eval_root_likelihoods call (timing enabled)."""
+        ms = C.c_double()
+        _lib.check(self._L.cafehip_last_batch_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def describe(self):
         return self._L.cafehip_describe(self._h).decode()

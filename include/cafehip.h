@@ -119,6 +119,15 @@ int cafehip_matrix_size(cafehip_ctx *ctx);
 int cafehip_reset_birthdeath_cache(cafehip_ctx *ctx, const double *node_lambda,
                                    const double *node_mu);
 
+/* on != 0: the following matrix builds use the exact form -- exp() per term, running product for coeff^j,
+ * no contraction: the IEEE operation sequence of the reference's compute_birthdeath_rates
+ * (libtree/birthdeath.c:34-73, 238-286) -- instead of the faster product form (<= 5e-12 relative apart).
+ * The report phase asks for it: Monte-Carlo draws compare uniform numbers with cumulative sums of matrix rows
+ * (cafe/cafe_tree.c:533-569) and viterbi_sum_probabilities compares entries with exact == and <
+ * (cafe/viterbi.cpp:60-67), so its matrices should round like the reference's.  Objective evaluations may
+ * keep the default. */
+int cafehip_set_exact_matrices(cafehip_ctx *ctx, int on);
+
 /* Root likelihood vectors for a batch of B count rows with per-row extents, using
  * the matrices of the last evaluation / reset: row b is scored with root rows
  * [root_lo[b], root_hi[b]] and columns [0, col_max[b]].  out is packed,
@@ -153,6 +162,9 @@ int cafehip_fetch_small(cafehip_ctx *ctx, const void *d_src, size_t nbytes, cons
  * ms[2] = score reduction.  Enabled by cafehip_enable_timing(ctx, 1). */
 int cafehip_enable_timing(cafehip_ctx *ctx, int on);
 int cafehip_last_kernel_ms(cafehip_ctx *ctx, double ms[3]);
+/* With timing enabled: duration of the pruning launch of the last cafehip_eval_root_likelihoods call (HIP
+ * events on the context's stream; the copies either side of it are not included). */
+int cafehip_last_batch_ms(cafehip_ctx *ctx, double *ms);
 
 /* Human-readable description of the last launch geometry (for logs/tests). */
 const char *cafehip_describe(cafehip_ctx *ctx);

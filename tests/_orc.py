@@ -11,10 +11,15 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 
 def _build():
-    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    # CAFE_ORACLE_NATIVE=1 (bench.py's cpu_baseline leg): the same source built ON THIS BOX with
+    # -O3 -march=native; the tests use the portable -O2 build that travels with the repo.
+    # Both builds keep -ffp-contract=off, and gcc does not reassociate without -ffast-math: same bits.
+    native = os.environ.get("CAFE_ORACLE_NATIVE") == "1"
+    name = "liboracle_native.so" if native else "liboracle.so"
+    so = os.path.join(ORACLE_DIR, name)
     src = os.path.join(ORACLE_DIR, "cafe_oracle.c")
-    if (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if native or (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-B" if native else "-s", "-C", ORACLE_DIR, name], stdout=subprocess.DEVNULL)
     return so
 
 
@@ -382,3 +387,94 @@ def load_error_model(path, range_max):
     for c in range(max(mfs - diff + 1, 0), mfs + 1):
         E[mfs, c] += 1 - colsum(c)
     return E, mfs
+
+
+def mc_null_rows(tree, rng, mats, trials, seed, root_sizes):
+    """The simulated families of the Monte-Carlo null for SOME root sizes, drawn in the reference's `-t 1`
+    order (root sizes ascending, trials sequential, libc rand(): cafe/conditional_distribution.cpp:10-44,
+    cafe/cafe_tree.c:533-569) -- the whole stream is consumed so that the selected root sizes see the draws
+    they would see in orc_conditional_distribution.  Returns {s: (counts[trials, n_leaves], col_max[trials])}."""
+    L = lib()
+    libc = C.CDLL(None)
+    libc.srand(seed)
+    ct = tree.ctree()
+    fs = np.zeros(tree.n_nodes, np.int32)
+    want = set(int(s) for s in root_sizes)
+    out = {}
+    n_leaves = (tree.n_nodes + 1) // 2
+    for s in range(rng.root_min, rng.root_max + 1):
+        mfs = max(s, rng.max)
+        rmax = rng.max
+        keep = s in want
+        if keep:
+            cnt = np.zeros((trials, n_leaves), np.int32)
+            cm = np.zeros(trials, np.int32)
+        for i in range(trials):
+            mx = L.orc_tree_random_familysize(C.byref(ct), mats, s, mfs, iptr(fs))
+            rmax = min(mx + max(50, mx // 5), rmax)
+            if keep:
+                cnt[i] = fs[0::2]
+                cm[i] = rmax
+        if keep:
+            out[s] = (cnt, cm)
+    return out
+
+
+def eval_root_likelihoods(tree, mats, counts, root_lo, root_hi, col_max, nthreads=1):
+    """orc_eval_root_likelihoods over row blocks on worker threads (ctypes releases the GIL; rows are independent)."""
+    from concurrent.futures import ThreadPoolExecutor
+    L = lib()
+    counts = np.ascontiguousarray(counts, np.int32)
+    lo = np.ascontiguousarray(root_lo, np.int32)
+    hi = np.ascontiguousarray(root_hi, np.int32)
+    cm = np.ascontiguousarray(col_max, np.int32)
+    B, nl = counts.shape
+    off = np.concatenate([[0], np.cumsum(hi - lo + 1)])
+    out = np.zeros(int(off[-1]))
+    ct = tree.ctree()
+    edges = np.linspace(0, B, max(1, min(nthreads, B)) + 1).astype(int)
+
+    def work(k):
+        a, b = int(edges[k]), int(edges[k + 1])
+        if b > a:
+            L.orc_eval_root_likelihoods(C.byref(ct), b - a, nl, iptr(counts[a:b]), iptr(lo[a:b]), iptr(hi[a:b]),
+                                        iptr(cm[a:b]), mats, dptr(out[off[a]:off[b]]))
+
+    with ThreadPoolExecutor(len(edges) - 1) as ex:
+        list(ex.map(work, range(len(edges) - 1)))
+    return out
+
+
+def build_matrices(tree, rng, node_lambda, node_mu, nthreads=1):
+    """orc_matrices handle for (node_lambda, node_mu) at M = max(range.max, range.root_max); free with free_matrices."""
+    ct = tree.ctree()
+    M = max(rng.max, rng.root_max)
+    return lib().orc_matrices_build(C.byref(ct), dptr(np.ascontiguousarray(node_lambda, np.float64)),
+                                    dptr(np.ascontiguousarray(node_mu, np.float64)), M, nthreads)
+
+
+def free_matrices(h):
+    lib().orc_matrices_free(h)
+
+
+def viterbi_and_pvalues(tree, mats, row, cd, trials, pvalue_cut):
+    """One family of the report on the oracle: (max p over root sizes, Viterbi node sizes, branch p-values or None)."""
+    L = lib()
+    ct = tree.ctree()
+    r = Range()
+    row = np.ascontiguousarray(row, np.int32)
+    L.orc_family_forced_range(C.byref(r), len(row), iptr(row))
+    fs = np.full(tree.n_nodes, -1, np.int32)
+    fs[0::2] = row
+    pv = np.zeros(max(r.root_max, 1))
+    L.orc_tree_p_values(C.byref(ct), C.byref(r), mats, iptr(fs), dptr(cd), trials, dptr(pv))
+    maxp = float(pv[:max(r.root_max, 0)].max()) if r.root_max >= 1 else 0.0
+    sof = L.orc_matrices_size(mats) + 1
+    vit = np.zeros(tree.n_nodes * sof, np.int32)
+    Lb = np.zeros(tree.n_nodes * sof)
+    L.orc_tree_viterbi(C.byref(ct), C.byref(r), mats, iptr(fs), iptr(vit), dptr(Lb), sof)
+    bp = None
+    if not (maxp > pvalue_cut):
+        bp = np.zeros(tree.n_nodes - 1)
+        L.orc_viterbi_sum_probabilities(C.byref(ct), C.byref(r), mats, iptr(fs), dptr(bp))
+    return maxp, fs, bp

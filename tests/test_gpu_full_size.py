@@ -1,6 +1,7 @@
 """BASELINE.json full sizes -- configs[1] (10 k families, 16 taxa), configs[2] (100 k families, 32 taxa,
-lambda/mu) and one GPU shard of configs[3] (500 k / 8 = 62,464 families, 64 taxa) -- through size-independent
-properties, plus an oracle spot check on a random sample:
+lambda/mu), one GPU shard of configs[3] (500 k / 8 = 62,500 families, 64 taxa, three lambda classes by clade) and
+configs[4] (100 k families, error model on every leaf, Monte-Carlo null 250 x 1000, report) -- through
+size-independent properties, plus oracle spot checks on random samples:
   * a family's values do not depend on which batch it is evaluated in (bit-exact);
   * an identity error model is the same as no error model (the one-hot leaf GEMM adds exact zeros);
   * chunk-aligned shards evaluated separately combine to the single-table score bit for bit;
@@ -17,8 +18,8 @@ from tests import _orc as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[("cfg2", 10000), ("cfg3", 100000), ("cfg4", 62464)],
-                ids=["configs1-10k", "configs2-100k", "configs3-shard-62k"])
+@pytest.fixture(scope="module", params=[("cfg2", 10000), ("cfg3", 100000), ("cfg4", 62500), ("cfg5", 100000)],
+                ids=["configs1-10k", "configs2-100k", "configs3-shard-62k-3-lambda-classes", "configs4-100k-errormodel"])
 def problem(request):
     import torch
     torch.cuda.init()  # torch's bundled HIP runtime must come up before libcafehip's (as in bench.py)
@@ -29,14 +30,20 @@ def problem(request):
     rng = O.range_from_max(cfg["m"])
     t = O.PyTree(cfg["newick"])
     prior = O.prior_poisson(1000, rng.root_min, 8.0)
-    lam = np.full(t.n_nodes, cfg["lam"])
-    mu = np.full(t.n_nodes, cfg["mu"])
+    assert np.array_equal(t.parent, tree.parent) and np.array_equal(t.left, tree.left)   # same nlist numbering
+    lam, mu = synth.node_rates(tree, cfg)   # one lambda per clade class for configs[3]
+    if cfg.get("n_classes"):
+        assert len(set(lam.tolist())) == cfg["n_classes"]
     eng = cafe_amd.Engine(0)
     eng.set_tree(t.parent, t.left, t.right, t.branchlength)
     fr = cafe_amd.FamilySizeRange(rng.min, rng.max, rng.root_min, rng.root_max)
     eng.set_families(counts, fr)
+    err = synth.banded_error_matrix(rng.max) if cfg.get("error_model") else None
+    if err is not None:
+        eng.set_error_model(err)   # +-2 band on every leaf; posterior evaluations fold it into the matrices
     full = eng.get_posterior(lam, mu, prior, per_family=True)
-    yield dict(eng=eng, t=t, counts=counts, rng=rng, fr=fr, prior=prior, lam=lam, mu=mu, full=full, cfg=cfg)
+    yield dict(eng=eng, t=t, tree=tree, counts=counts, rng=rng, fr=fr, prior=prior, lam=lam, mu=mu, full=full, cfg=cfg,
+               err=err, name=name)
     eng.close()
 
 
@@ -63,8 +70,9 @@ def test_oracle_spot_check_on_a_sample(problem):
     score, fz, ml, am, mp = p["full"]
     rs = np.random.RandomState(3)
     idx = np.sort(rs.choice(len(p["counts"]), 160, replace=False))
+    ekw = dict(errormatrix=p["err"], err_mfs=p["rng"].max) if p["err"] is not None else {}
     so, fzo, mlo, amo, mpo = O.eval_posterior(p["t"], p["counts"][idx], p["rng"], p["lam"], p["mu"], p["prior"],
-                                              nthreads=os.cpu_count() or 1)
+                                              nthreads=os.cpu_count() or 1, **ekw)
     assert np.max(np.abs(ml[idx] - mlo) / mlo) < 1e-9
     assert np.max(np.abs(mp[idx] - mpo) / mpo) < 1e-9
     assert np.array_equal(am[idx], amo)
@@ -72,6 +80,8 @@ def test_oracle_spot_check_on_a_sample(problem):
 
 def test_identity_error_model_is_a_no_op(problem):
     p = problem
+    if p["err"] is not None:
+        pytest.skip("this configuration carries its own error model")
     mfs = p["rng"].max
     p["eng"].set_error_model(np.eye(mfs + 1))
     try:
@@ -108,3 +118,159 @@ def test_chunk_aligned_shards_combine_bit_exactly(problem):
         assert all(not (0 <= fz_local[r] < bounds[r][1] - bounds[r][0]) for r in range(world))
         assert D.final_score(host[:, :slots].reshape(-1), D.NO_ZERO) == score
     p["eng"].set_families(p["counts"], p["fr"])
+
+
+# ---- BASELINE configs[4]: error model + Monte-Carlo null + report at full size ------------------------------------
+
+def test_unfolded_error_model_equals_the_folded_one(problem):
+    # the objective path folds the error model into the matrices once per evaluation (k1e_fold_error); with
+    # CAFEHIP_ERRFOLD=0 every family sums its band itself (cafe/cafe_tree.c:196-203 then :213-224): the two
+    # must agree to rounding on a block of the table
+    p = problem
+    if p["err"] is None:
+        pytest.skip("no error model in this configuration")
+    sub = p["counts"][:4096]
+    p["eng"].set_families(sub, p["fr"])
+    folded = p["eng"].get_posterior(p["lam"], p["mu"], p["prior"], per_family=True)
+    os.environ["CAFEHIP_ERRFOLD"] = "0"
+    try:
+        unfolded = p["eng"].get_posterior(p["lam"], p["mu"], p["prior"], per_family=True)
+    finally:
+        del os.environ["CAFEHIP_ERRFOLD"]
+        p["eng"].set_families(p["counts"], p["fr"])
+    assert np.max(np.abs(folded[2] - unfolded[2]) / unfolded[2]) < 1e-12
+    assert np.array_equal(folded[3], unfolded[3])
+    assert np.array_equal(folded[2], p["full"][2][:4096])   # and a block equals the full-table values bit for bit
+
+
+@pytest.fixture(scope="module")
+def cfg5_report(tmp_path_factory):
+    """configs[4] through the host driver at full size: 100 k families, error model on every leaf, lambda -s,
+    Monte-Carlo null (250 root sizes x 1000 simulated families) and the report."""
+    import torch
+    torch.cuda.init()
+    from cafe_amd import synth
+    from cafe_amd.shell import CafeShell
+    d = tmp_path_factory.mktemp("cfg5")
+    tree, counts, cfg = synth.make_config("cfg5")
+    rng = O.range_from_max(cfg["m"])
+    tab, em, out = str(d / "families.tab"), str(d / "errormodel.txt"), str(d / "report")
+    with open(tab, "w") as f:
+        f.write("Desc\tFamily ID\t" + "\t".join(tree.leaf_names) + "\n")
+        for i, row in enumerate(counts):
+            f.write("NA\tF%06d\t" % i + "\t".join(str(int(x)) for x in row) + "\n")
+    synth.write_error_model_file(em, rng.max)
+    sh = CafeShell(0, os.devnull)
+    for line in ("seed 10", "tree " + cfg["newick"], "load -i %s -p 0.01 -t 1" % tab, "errormodel -model %s -all" % em,
+                 "lambda -s"):
+        sh.dispatch(line)
+    lam_fit = float(sh.params[0])
+    sh.dispatch("seed 10")                 # the null below starts from a known point of the rand() stream
+    sh.dispatch("pvalue -o " + out + ".pv")
+    sh.dispatch("report " + out)
+    sh.close()
+    null = np.array([[float(x) for x in l.split("\t")] for l in open(out + ".pv").read().splitlines()])
+    return dict(tree=tree, counts=counts, cfg=cfg, rng=rng, lam_fit=lam_fit, null=null, report=out + ".cafe",
+                t=O.PyTree(cfg["newick"]))
+
+
+def test_cfg5_fitted_lambda_is_near_the_simulated_one(cfg5_report):
+    r = cfg5_report
+    assert r["null"].shape == (r["rng"].root_max - r["rng"].root_min + 1, 1000)
+    assert abs(r["lam_fit"] - r["cfg"]["lam"]) < 0.2 * r["cfg"]["lam"]
+    assert np.all(np.diff(r["null"], axis=1) >= 0)          # every root size's sample is sorted (:41)
+
+
+def test_cfg5_monte_carlo_null_matches_the_oracle_on_root_sizes(cfg5_report):
+    # the oracle replays the reference's `-t 1` rand() stream for ALL 250 x 1000 simulated families (cheap) and
+    # scores those of a few root sizes (the dense CPU walk is the expensive part)
+    r = cfg5_report
+    t, rng = r["t"], r["rng"]
+    lam = np.full(t.n_nodes, r["lam_fit"])
+    mu = np.full(t.n_nodes, -1.0)
+    mats = O.build_matrices(t, rng, lam, mu, nthreads=os.cpu_count() or 1)
+    try:
+        check = [rng.root_min, rng.root_min + 9, 57, rng.root_max]
+        rows = O.mc_null_rows(t, rng, mats, 1000, 10, check)
+        for s in check:
+            cnt, cm = rows[s]
+            lo = np.full(len(cm), s, np.int32)
+            like = np.sort(O.eval_root_likelihoods(t, mats, cnt, lo, lo, cm, nthreads=os.cpu_count() or 1))
+            got = r["null"][s - rng.root_min]
+            ok = like > 0
+            assert np.array_equal(got == 0, ~ok)
+            assert np.max(np.abs(got[ok] - like[ok]) / like[ok]) < 2e-8      # the file holds 9 significant digits
+    finally:
+        O.free_matrices(mats)
+
+
+def test_cfg5_report_sample_matches_the_oracle(cfg5_report):
+    # Viterbi sizes, family-wide p-value and branch p-values of a sample of the 100 k report rows against the
+    # oracle run on the same null distribution
+    r = cfg5_report
+    t, rng = r["t"], r["rng"]
+    lam = np.full(t.n_nodes, r["lam_fit"])
+    mu = np.full(t.n_nodes, -1.0)
+    rep = O.parse_cafe_report(r["report"])
+    assert len(rep) == len(r["counts"])
+    mats = O.build_matrices(t, rng, lam, mu, nthreads=os.cpu_count() or 1)
+    cd = np.ascontiguousarray(r["null"])
+    # Newick order of the report's sizes -> node ids
+    order = []
+
+    def walk(v):
+        if t.left[v] >= 0:
+            walk(t.left[v])
+            walk(t.right[v])
+        order.append(v)
+
+    walk(t.root)
+    try:
+        rs = np.random.RandomState(5)
+        n_branch = 0
+        for i in rs.choice(len(r["counts"]), 48, replace=False):
+            sizes, maxp, pairs = rep["F%06d" % i]
+            maxp_o, fs_o, bp_o = O.viterbi_and_pvalues(t, mats, r["counts"][i], cd, 1000, 0.01)
+            got = np.zeros(t.n_nodes, np.int64)
+            got[order] = sizes
+            assert np.array_equal(got, fs_o), i
+            assert abs(maxp - maxp_o) <= 2.5e-3, (i, maxp, maxp_o)          # %g text; a tie at 9 digits moves a rank by 1
+            if bp_o is not None and all(x is not None for x in pairs):
+                n_branch += 1
+                flat = np.array([v for pr in pairs for v in pr])
+                assert np.allclose(flat, bp_o, rtol=2e-5, atol=1e-300), i   # %g prints 6 significant digits
+    finally:
+        O.free_matrices(mats)
+
+
+def test_cfg5_null_sharded_by_root_size_recombines_bit_exactly():
+    # the multi-GPU split of the Monte-Carlo null (cafe/conditional_distribution.cpp:88-108: whole root sizes per
+    # worker): blocks of root sizes scored separately equal the single 250,000-row launch bit for bit
+    import torch
+    torch.cuda.init()
+    import cafe_amd
+    from cafe_amd import synth
+    tree, counts, cfg = synth.make_config("cfg5", F=512)
+    rng = cafe_amd.init_family_size(cfg["m"])
+    eng = cafe_amd.Engine(0)
+    tree.apply(eng)
+    eng.set_families(counts, rng)
+    lam, mu = synth.node_rates(tree, cfg)
+    eng.set_exact_matrices(True)
+    eng.reset_birthdeath_cache(lam, mu)
+    mats = {v: eng.get_matrix(v) for v in range(tree.n_nodes) if v != tree.root}
+    rows, lo, cm = synth.simulate_null_rows(tree, mats, rng, 1000, 123)
+    R = rng.root_max - rng.root_min + 1
+    whole = eng.eval_root_likelihoods(rows, lo, lo, cm)
+    assert whole.shape == (R * 1000,) and np.all(np.isfinite(whole)) and np.count_nonzero(whole) > 0.9 * whole.size
+    for world in (2, 3, 8):
+        parts = []
+        base, extra = divmod(R, world)
+        r0 = 0
+        for rank in range(world):
+            r1 = r0 + base + (1 if rank < extra else 0)
+            a, b = r0 * 1000, r1 * 1000
+            parts.append(eng.eval_root_likelihoods(rows[a:b], lo[a:b], lo[a:b], cm[a:b]))
+            r0 = r1
+        assert np.array_equal(np.concatenate(parts), whole)
+    eng.close()
