@@ -96,6 +96,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
+    # the contract is ONE JSON line on stdout: whatever libraries print to file descriptor 1 meanwhile (the host
+    # driver echoes some commands with printf) is sent to stderr, and the line is written to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -341,7 +347,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(newick, counts, rng, prior, cfg, eng, tree)
 
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     eng.close()
     if multi:
         dist.destroy_process_group()
@@ -496,7 +502,7 @@ def cpu_baseline(newick, counts, rng, prior, cfg, eng, tree):
     orng = O.make_range(rng.min, rng.max, rng.root_min, rng.root_max)
     lam, mu = synth.node_rates(tree, cfg)
     err = synth.banded_error_matrix(rng.max) if cfg.get("error_model") else None
-    ekw = dict(errormatrix=err, err_mfs=rng.max) if err is not None else {}
+    ekw = dict(errormatrix=err, err_mfs=rng.max, leaf_has_err=np.ones(t.n_nodes, np.uint8)) if err is not None else {}
     phys, hw = physical_cores()
     try:
         avail = len(os.sched_getaffinity(0))

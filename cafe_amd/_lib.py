@@ -18,6 +18,7 @@ SIGNATURES = {
     "cafehip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "cafehip_destroy": (None, [C.c_void_p]),
     "cafehip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cafehip_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "cafehip_set_tree": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _dp]),
     "cafehip_set_families": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
     "cafehip_set_error_model": (C.c_int, [C.c_void_p, C.c_int, _dp, _u8p]),
@@ -48,6 +49,9 @@ HOST_SIGNATURES = {
     "cafehost_shard_bounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cafehost_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cafehost_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cafehost_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "cafehost_init_comm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "cafehost_exchange_stats": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_long)]),
     "cafehost_set_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cafehost_fetch_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_ulong, C.POINTER(C.c_void_p)]),
     "cafehost_upload": (C.c_int, [C.c_void_p]),

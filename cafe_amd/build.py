@@ -18,7 +18,7 @@ CLI = os.path.join(BINDIR, "cafehip")
 DEPS = ["cafehip.hip", "k2_mfma.hpp", "host_math.hpp", "schedule.hpp", os.path.join("host", "cafe_host.cpp"),
         os.path.join("host", "main.cpp"), os.path.join("..", "..", "include", "cafehip.h"),
         os.path.join("..", "..", "include", "cafehost.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-ldl",
          "-Wno-unused-result"]
 
 

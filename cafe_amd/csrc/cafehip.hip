@@ -81,6 +81,7 @@ struct EvalParams {
     int node_key[kMaxNodes];
     KeyParam keys[kMaxNodes];
     double logprior[kMaxPrior];
+    double prior[kMaxPrior];   // the same prior, not logged (K2's epilogue filters candidates by L * prior)
 };
 
 struct K2Args {
@@ -141,7 +142,10 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
     if (ep_dev && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
         if (threadIdx.x == 0) ep_dev->nkeys = nkeys;
         for (int i = threadIdx.x; i < n_nodes; i += 256) ep_dev->node_key[i] = ep->node_key[i];
-        for (int i = threadIdx.x; i < n_prior; i += 256) ep_dev->logprior[i] = ep->logprior[i];
+        for (int i = threadIdx.x; i < n_prior; i += 256) {
+            ep_dev->logprior[i] = ep->logprior[i];
+            ep_dev->prior[i] = ep->prior[i];
+        }
     }
     const int s0 = blockIdx.y * 16;
     const int c0 = blockIdx.x * 16;
@@ -281,7 +285,10 @@ __global__ __launch_bounds__(256) void k1_build_matrices_rb(const EvalParams* __
     if (ep_dev && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
         if (threadIdx.x == 0) ep_dev->nkeys = nkeys;
         for (int i = threadIdx.x; i < n_nodes; i += 256) ep_dev->node_key[i] = ep->node_key[i];
-        for (int i = threadIdx.x; i < n_prior; i += 256) ep_dev->logprior[i] = ep->logprior[i];
+        for (int i = threadIdx.x; i < n_prior; i += 256) {
+            ep_dev->logprior[i] = ep->logprior[i];
+            ep_dev->prior[i] = ep->prior[i];
+        }
     }
     if (first_zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *first_zero = INT32_MAX;
     const int s0 = blockIdx.y * 16;
@@ -1038,7 +1045,10 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
         if (h->keys[k].mode >= 2 && !h->keys[k].fast_ok) c->all_keys_fast = false;
     if (prior) {
         // compute_posterior adds log(prior[j]) (cafe/lambda.cpp:681); the log is taken on the host
-        for (int j = 0; j < c->R; ++j) h->logprior[j] = std::log(prior[j]);
+        for (int j = 0; j < c->R; ++j) {
+            h->logprior[j] = std::log(prior[j]);
+            h->prior[j] = prior[j];
+        }
     }
     *out_h = h;
     c->cur_params = h;
@@ -1191,8 +1201,7 @@ int launch_mfma_nrt(cafehip_ctx* c, const K2MfmaArgs& a, int nrt_w, int grid, in
 // workgroups share a CU; otherwise they live in global scratch and are fetched back when consumed.
 size_t mfma_lds_bytes_with(const cafehip_ctx* c, int nf, int lds_parks)
 {
-    return (size_t)nf * c->LDv * sizeof(double) * (1 + lds_parks) + (size_t)nf * c->n_leaves * 4 + (size_t)nf * 4 +
-           c->msched.ops.size() * (sizeof(cafehip::MfmaOp) + 4 * sizeof(int));
+    return (size_t)nf * c->LDv * sizeof(double) * (1 + lds_parks) + k2_scratch_bytes(nf, c->n_leaves, (int)c->msched.ops.size());
 }
 
 // Number of park buffers (node vectors waiting for their sibling; slot 0 is the busiest) kept in LDS behind the
@@ -1297,7 +1306,9 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_
 }
 
 // 4x4x4_4b shape: NF = 4 * G * wf (K2Cfg.nft_w carries G).  CAFEHIP_K2CFG4="G,nrtw,wf,wr" overrides.
-constexpr int kMaxGroupTiles = 21;  // G * NRT_W accumulators per wave (register budget: 24 spills to scratch)
+// (G, NRT_W) wave tiles of the 4-family kernel that compile without scratch spills at 2 waves per SIMD (256 registers
+// per lane; checked with tools/k2_regs.py after every kernel change)
+constexpr bool k2_fits4(int G, int nrt_w) { return G * nrt_w <= 15 || (G == 4 && nrt_w == 4) || (G == 3 && nrt_w == 6); }
 bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_cost, std::vector<K2Cand>* all = nullptr)
 {
     const int RT = (std::max(c->C, c->R) + 15) / 16;
@@ -1305,7 +1316,7 @@ bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out
     if (const char* e = getenv("CAFEHIP_K2CFG4")) {
         K2Cfg k;
         if (sscanf(e, "%d,%d,%d,%d", &k.nft_w, &k.nrt_w, &k.wf, &k.wr) == 4 && k.nft_w >= 1 && k.nft_w <= 8 &&
-            k.nrt_w >= 1 && k.nrt_w <= 7 && k.nft_w * k.nrt_w <= kMaxGroupTiles && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 &&
+            k.nrt_w >= 1 && k.nrt_w <= 7 && k2_fits4(k.nft_w, k.nrt_w) && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 &&
             k.wr * k.nrt_w >= RT && mfma_lds_bytes(c, 4 * k.nft_w * k.wf, n_items) <= (size_t)c->lds_limit) {
             *out = k;
             *out_cost = 0;
@@ -1318,7 +1329,7 @@ bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out
         const int nrt_w = (RT + wr - 1) / wr;
         if (nrt_w > 7) continue;
         for (int G = 1; G <= 8; ++G) {
-            if (G * nrt_w > kMaxGroupTiles) continue;
+            if (!k2_fits4(G, nrt_w)) continue;
             for (int wf = 1; wf * wr <= 8 && wf <= 2; wf *= 2) {
                 const int nf = 4 * G * wf;
                 if (mfma_lds_bytes(c, nf, n_items) > (size_t)c->lds_limit) continue;
@@ -1353,7 +1364,7 @@ int launch_mfma4_nrt(cafehip_ctx* c, const K2MfmaArgs& a, int nrt_w, int grid, i
     // only the (G, NRT_W) pairs within the register budget are instantiated
 #define CAFE_M4(N)                                                              \
     case N:                                                                     \
-        if constexpr (G * N <= kMaxGroupTiles)                                  \
+        if constexpr (k2_fits4(G, N))                                           \
             return launch_mfma4_inst<G, N>(c, a, grid, block, lds);             \
         break;
     switch (nrt_w) {
@@ -1787,6 +1798,13 @@ int cafehip_set_stream(cafehip_ctx* c, void* hip_stream)
     // NULL is a real stream in HIP (the legacy default stream, which is also what
     // torch.cuda.current_stream().cuda_stream returns unless a side stream is current)
     c->stream = (hipStream_t)hip_stream;
+    return 0;
+}
+
+int cafehip_get_stream(cafehip_ctx* c, void** hip_stream)
+{
+    if (!c || !hip_stream) return fail("null argument");
+    *hip_stream = (void*)c->stream;
     return 0;
 }
 

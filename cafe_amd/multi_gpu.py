@@ -24,11 +24,21 @@ ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_vo
 class MultiGpuShell(CafeShell):
     """CafeShell whose objective is sharded over the ranks of a torch.distributed group."""
 
-    def __init__(self, torch, dist, device_index, log_path="stdout", device="cuda"):
+    def __init__(self, torch, dist, device_index, log_path="stdout", device="cuda", native=False):
         super().__init__(device_index, log_path)
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device
+        self.native = native
+        if native:
+            # the exchange lives behind the C ABI (cafehost_init_comm): torch.distributed only carries the
+            # communicator id from rank 0 to the others; no callback is registered
+            ident = [self.comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            self.init_comm(self.rank, self.world, ident[0])
+            self._cb = self._ag = None
+            self._wired = True
+            return
         self._check(self._L.cafehost_set_shard(self._h, self.rank, self.world))
         if device == "cuda":
             self._check(self._L.cafehost_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
@@ -94,6 +104,8 @@ class MultiGpuShell(CafeShell):
         self._wired = True
 
     def dispatch(self, line):
+        if self.native:
+            return super().dispatch(line)
         cmd = line.strip().split(" ")[0] if line.strip() else ""
         if cmd in ("load", "tree"):
             self._wired = False
@@ -120,7 +132,8 @@ def main(argv=None):
     else:
         dist.init_process_group(backend=backend)
     rank = dist.get_rank()
-    sh = MultiGpuShell(torch, dist, dev, "stdout" if rank == 0 else os.devnull)
+    sh = MultiGpuShell(torch, dist, dev, "stdout" if rank == 0 else os.devnull,
+                       native=os.environ.get("CAFE_NATIVE_COMM") == "1")
     with open(argv[0]) as f:
         for line in f:
             if sh.dispatch(line) == 1:

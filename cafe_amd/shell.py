@@ -38,6 +38,26 @@ class CafeShell:
     def run_script(self, path):
         return self._check(self._L.cafehost_run_script(self._h, path.encode()))
 
+    # ---- native communicator (include/cafehost.h): RCCL behind the C ABI ---------------------------------
+    COMM_ID_BYTES = 128
+
+    def comm_unique_id(self):
+        """ncclGetUniqueId through the library: bytes for rank 0 to hand to the other ranks."""
+        buf = C.create_string_buffer(self.COMM_ID_BYTES)
+        self._check(self._L.cafehost_comm_unique_id(buf))
+        return buf.raw
+
+    def init_comm(self, rank, world, unique_id):
+        """Join the communicator: from here on every table this session loads is sharded and every objective
+        evaluation ends in one ncclAllGather on the session's stream."""
+        assert len(unique_id) == self.COMM_ID_BYTES
+        self._check(self._L.cafehost_init_comm(self._h, int(rank), int(world), C.c_char_p(unique_id)))
+
+    def exchange_stats(self):
+        sec, calls = C.c_double(), C.c_long()
+        self._check(self._L.cafehost_exchange_stats(self._h, C.byref(sec), C.byref(calls)))
+        return sec.value, calls.value
+
     @property
     def params(self):
         n = self._L.cafehost_num_params(self._h)

@@ -52,6 +52,9 @@ void cafehip_destroy(cafehip_ctx *ctx);
  * void*).  NULL is the HIP legacy default stream -- the handle torch reports for its default
  * stream -- NOT "no stream": until this is called the context uses a private non-blocking stream. */
 int cafehip_set_stream(cafehip_ctx *ctx, void *hip_stream);
+/* The stream the context currently runs on (a hipStream_t as void*), for a caller that wants to enqueue its own
+ * work -- e.g. the collective of the multi-GPU exchange -- behind the context's kernels. */
+int cafehip_get_stream(cafehip_ctx *ctx, void **hip_stream);
 
 /* Tree topology in the reference's nlist numbering (in-order: even ids are
  * leaves, odd ids internal; cafe/cafe_commands.cpp:2028-2051).  parent[root] = -1,

@@ -70,7 +70,8 @@ def test_oracle_spot_check_on_a_sample(problem):
     score, fz, ml, am, mp = p["full"]
     rs = np.random.RandomState(3)
     idx = np.sort(rs.choice(len(p["counts"]), 160, replace=False))
-    ekw = dict(errormatrix=p["err"], err_mfs=p["rng"].max) if p["err"] is not None else {}
+    ekw = (dict(errormatrix=p["err"], err_mfs=p["rng"].max, leaf_has_err=np.ones(p["t"].n_nodes, np.uint8))
+           if p["err"] is not None else {})
     so, fzo, mlo, amo, mpo = O.eval_posterior(p["t"], p["counts"][idx], p["rng"], p["lam"], p["mu"], p["prior"],
                                               nthreads=os.cpu_count() or 1, **ekw)
     assert np.max(np.abs(ml[idx] - mlo) / mlo) < 1e-9
