@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <tuple>
 #include <unordered_map>
 #include <mutex>
 #include <map>
@@ -868,6 +869,10 @@ struct cafehip_ctx {
     // per DEVICE, so the high-water marks live in the context (several contexts of one process may sit on
     // different GPUs)
     std::unordered_map<const void*, size_t> lds_attr;
+    std::map<std::tuple<const void*, int, size_t>, int> k2_occ;   // resident workgroups per CU of a K2 launch shape
+    int k2_grid = 0, k2_park_slots = 0;                          // workgroups / park slots of the last MFMA K2 launch
+    int32_t* d_park_flags = nullptr;                             // park-slot ownership flags (0 = free)
+    int park_flags_cap = 0;
     double* d_PT = nullptr;
     unsigned short* d_vit = nullptr;   // Viterbi argmax tables (global scratch, grow-only)
     size_t vit_cap = 0;
@@ -1170,11 +1175,58 @@ int launch_k2_v1(cafehip_ctx* c, K2Args& a, int n_items)
 
 
 // ---- MFMA launcher -------------------------------------------------------------------
+// Park scratch of a launch (node vectors waiting for their sibling that do not fit LDS): one slot per workgroup that
+// can be RESIDENT (occupancy query x CUs, doubled as margin), claimed by the workgroups at run time
+// (k2_acquire_park_slot), instead of one region per family tile: at the configs[2] shape 2 x 1,280 slots x 2 parks x
+// 33 KB = 169 MB at most instead of 413 MB, and only the slots in use are touched -- they stay in the 256 MB Infinity
+// Cache (round 1: 7.7 GB of HBM traffic per launch).  CAFEHIP_K2SLOTS=0 restores one region per tile.
+int k2_fit_grid(cafehip_ctx* c, const void* fn, K2MfmaArgs& a, int* grid, int block, size_t lds)
+{
+    const bool global_parks = c->msched.n_parks > a.lds_parks;
+    int slots = 0;
+    bool per_tile = false;
+    if (const char* e = getenv("CAFEHIP_K2SLOTS")) per_tile = atoi(e) == 0;
+    if (global_parks && !per_tile) {
+        auto it = c->k2_occ.find({fn, block, lds});
+        if (it == c->k2_occ.end()) {
+            int nb = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, block, lds));
+            it = c->k2_occ.emplace(std::make_tuple(fn, block, lds), std::max(nb, 1)).first;
+        }
+        slots = std::min(*grid, 2 * it->second * std::max(c->n_cu, 1));
+    }
+    const size_t regions = global_parks ? (size_t)(slots > 0 ? slots : *grid) : 1;
+    const size_t park_bytes = regions * a.n_parks * a.NF * a.LDv * sizeof(double);
+    if (park_bytes > c->park_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->d_park);
+        c->d_park = nullptr;
+        c->park_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_park, park_bytes));
+        c->park_cap = park_bytes;
+    }
+    if (slots > c->park_flags_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->d_park_flags);
+        c->d_park_flags = nullptr;
+        HIP_TRY(hipMalloc(&c->d_park_flags, (size_t)slots * sizeof(int32_t)));
+        HIP_TRY(hipMemsetAsync(c->d_park_flags, 0, (size_t)slots * sizeof(int32_t), c->stream));   // all free; every owner releases
+        c->park_flags_cap = slots;
+    }
+    a.park = c->d_park;
+    a.park_flags = c->d_park_flags;
+    a.n_park_slots = slots;
+    c->k2_grid = *grid;
+    c->k2_park_slots = slots;
+    return 0;
+}
+
 constexpr int kMaxTiles16 = 8;      // NFT_W * NRT_W accumulator tiles per wave (16x16x4 shape)
 template <int NFT_W, int NRT_W>
-int launch_mfma_inst(cafehip_ctx* c, const K2MfmaArgs& a, int grid, int block, size_t lds)
+int launch_mfma_inst(cafehip_ctx* c, K2MfmaArgs a, int grid, int block, size_t lds)
 {
     if (grant_lds(c, reinterpret_cast<const void*>(&k2_prune_mfma<NFT_W, NRT_W>), lds, 64 * 1024)) return -1;
+    if (k2_fit_grid(c, reinterpret_cast<const void*>(&k2_prune_mfma<NFT_W, NRT_W>), a, &grid, block, lds)) return -1;
     hipLaunchKernelGGL((k2_prune_mfma<NFT_W, NRT_W>), dim3(grid), dim3(block), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1350,9 +1402,10 @@ bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out
 }
 
 template <int G, int NRT_W>
-int launch_mfma4_inst(cafehip_ctx* c, const K2MfmaArgs& a, int grid, int block, size_t lds)
+int launch_mfma4_inst(cafehip_ctx* c, K2MfmaArgs a, int grid, int block, size_t lds)
 {
     if (grant_lds(c, reinterpret_cast<const void*>(&k2_prune_mfma4<G, NRT_W>), lds, 64 * 1024)) return -1;
+    if (k2_fit_grid(c, reinterpret_cast<const void*>(&k2_prune_mfma4<G, NRT_W>), a, &grid, block, lds)) return -1;
     hipLaunchKernelGGL((k2_prune_mfma4<G, NRT_W>), dim3(grid), dim3(block), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1499,15 +1552,6 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     const int grid = (n_items + nf - 1) / nf;
     const int block = 64 * k.wf * k.wr;
     const size_t lds = mfma_lds_bytes(c, nf, n_items);
-    const size_t park_bytes = (size_t)grid * std::max(c->msched.n_parks, 1) * nf * c->LDv * sizeof(double);
-    if (park_bytes > c->park_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        hipFree(c->d_park);
-        c->d_park = nullptr;
-        c->park_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_park, park_bytes));
-        c->park_cap = park_bytes;
-    }
     K2MfmaArgs a;
     memset(&a, 0, sizeof a);
     a.PT = v1.PT;
@@ -1527,7 +1571,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     a.Wf = k.wf;
     a.Wr = k.wr;
     a.NF = nf;
-    a.park = c->d_park;
+    a.park = nullptr;   // sized and set by k2_fit_grid for the grid actually launched
     a.n_parks = std::max(c->msched.n_parks, 1);
     a.lds_parks = mfma_lds_parks(c, nf, n_items);
     a.err = v1.err;
@@ -1764,6 +1808,7 @@ void cafehip_destroy(cafehip_ctx* c)
     hipFree(c->d_ops);
     hipFree(c->d_mops);
     hipFree(c->d_park);
+    hipFree(c->d_park_flags);
     hipFree(c->d_parent);
     hipFree(c->d_prefix);
     hipFree(c->d_vit_slot);
@@ -2401,12 +2446,12 @@ const char* cafehip_describe(cafehip_ctx* c)
     char buf[512];
     snprintf(buf, sizeof buf,
              "device=%d cus=%d F=%d Fu=%d n_leaves=%d S=%d C=%d R=%d LD=%d KP=%d LDv=%d nkeys=%d "
-             "n_ops=%zu n_slots=%d n_parks=%d k1:%s k2:%s NF=%d block=%d lds=%zu cfg(nftw,nrtw,wf,wr)=%d,%d,%d,%d",
+             "n_ops=%zu n_slots=%d n_parks=%d k1:%s k2:%s NF=%d block=%d lds=%zu cfg(nftw,nrtw,wf,wr)=%d,%d,%d,%d grid=%d park_slots=%d",
              c->device, c->n_cu, c->F, c->Fu, c->n_leaves, c->S, c->C, c->R, c->LD, c->KP, c->LDv,
              c->nkeys, c->sched.ops.size(), c->sched.n_slots, c->msched.n_parks,
              c->k1_product_form ? "product" : "exact",
              c->k2_used_mfma ? (c->k2_shape4 ? "mfma4x4(cfg=G,nrtw,wf,wr)" : "mfma") : "v1", c->k2_nf, c->k2_block, c->k2_lds, c->k2_cfg[0], c->k2_cfg[1],
-             c->k2_cfg[2], c->k2_cfg[3]);
+             c->k2_cfg[2], c->k2_cfg[3], c->k2_grid, c->k2_park_slots);
     c->desc = buf;
     return c->desc.c_str();
 }

@@ -27,6 +27,8 @@ struct K2MfmaArgs {
     const EvalParams* ep;
     const cafehip::MfmaOp* ops;
     int n_ops;
+    int32_t* park_flags;   // [n_park_slots] 0 = free: a workgroup that parks in global memory owns one slot of the
+    int n_park_slots;      // scratch while it runs (slots ~ 2x the resident workgroups, not one per family tile)
     int lds_parks;         // park slots [0, lds_parks) live in LDS behind the node buffer (no global round trip)
     const int32_t* counts;
     int Fu;
@@ -36,7 +38,7 @@ struct K2MfmaArgs {
     int ksteps;            // ceil(C / 4)
     int Wf, Wr;            // wave grid
     int NF;                // families per workgroup = 16 * Wf * NFT_W
-    double* park;          // [grid][n_parks][NF][LDv]
+    double* park;          // [n_park_slots][n_parks][NF][LDv]
     int n_parks;
     // error model
     const double* err;
@@ -176,6 +178,9 @@ __device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const i
 #ifndef CAFE_K2_INTERLEAVE
 #define CAFE_K2_INTERLEAVE 1
 #endif
+#ifndef CAFE_K2_ABLATE
+#define CAFE_K2_ABLATE 0   // debug timing builds ONLY (wrong results): bit 0 = no B-operand loads in the k loop, bit 1 = no A loads
+#endif
 #ifndef CAFE_K2_PRIO
 #define CAFE_K2_PRIO 1   // s_setprio 1 for the waves that carry the extra row tile of an uneven deal
 #endif
@@ -222,8 +227,8 @@ __device__ __forceinline__ void mfma_edge_p(const double* __restrict__ bp, const
 #define CAFE_REGION16(u, k)                                                                                    \
     {                                                                                                          \
         const int kn = min((k) + D - 1, klast);                                                                \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[((u) + D - 1) % D][j] = bp[(size_t)kn * kstride + boff[j]]; \
-        _Pragma("unroll") for (int i = 0; i < NFT_W; ++i) aq[((u) + D - 1) % D][i] = ap[kn * 4 + i * astride];  \
+        if (!(CAFE_K2_ABLATE & 1)) { _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[((u) + D - 1) % D][j] = bp[(size_t)kn * kstride + boff[j]]; } \
+        if (!(CAFE_K2_ABLATE & 2)) { _Pragma("unroll") for (int i = 0; i < NFT_W; ++i) aq[((u) + D - 1) % D][i] = ap[kn * 4 + i * astride]; } \
         _Pragma("unroll") for (int i = 0; i < NFT_W; ++i)                                                      \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                     \
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[(u) % D][i], bq[(u) % D][j], acc[i][j], 0, 0, 0); \
@@ -260,8 +265,8 @@ __device__ __forceinline__ void mfma4_edge_p(const double* __restrict__ bp, cons
 #define CAFE_REGION4(u, k)                                                                                     \
     {                                                                                                          \
         const int kn = min((k) + D - 1, klast);                                                                \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[((u) + D - 1) % D][j] = bp[(size_t)kn * kstride + boff[j]]; \
-        _Pragma("unroll") for (int g = 0; g < G; ++g) aq[((u) + D - 1) % D][g] = ap4[kn * 4 + (size_t)(4 * g) * LDv]; \
+        if (!(CAFE_K2_ABLATE & 1)) { _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[((u) + D - 1) % D][j] = bp[(size_t)kn * kstride + boff[j]]; } \
+        if (!(CAFE_K2_ABLATE & 2)) { _Pragma("unroll") for (int g = 0; g < G; ++g) aq[((u) + D - 1) % D][g] = ap4[kn * 4 + (size_t)(4 * g) * LDv]; } \
         _Pragma("unroll") for (int g = 0; g < G; ++g)                                                          \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                     \
                 acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(aq[(u) % D][g], bq[(u) % D][j], acc[g][j], 0, 0, 0); \
@@ -287,11 +292,42 @@ __device__ __forceinline__ void mfma4_edge_p(const double* __restrict__ bp, cons
 
 // LDS behind the node-vector buffers: the walk's scratch (counts, column limits, step list) and, once the walk is
 // over, the epilogue's scratch (candidate lists + per-family maxima) share it; the launcher sizes it for both.
+// Layout: [step list, matrix offsets, error flags: loaded once per workgroup] then, per family tile, the union of
+// [counts, column limits] (walk) and [candidate lists, per-family maxima] (epilogue).
 __host__ __device__ inline size_t k2_scratch_bytes(int nf, int n_leaves, int n_ops)
 {
-    const size_t walk = (size_t)nf * n_leaves * 4 + (size_t)nf * 4 + (size_t)n_ops * (12 + 2 + 2) * 4;
+    const size_t fixed = (size_t)n_ops * (12 + 2 + 2) * 4;
+    const size_t walk = (size_t)nf * n_leaves * 4 + (size_t)nf * 4 + 8;   // + the park-slot word
     const size_t epi = 8 * 64 * 4 + (size_t)nf * 8 + 16;
-    return walk > epi ? walk : epi;
+    return fixed + (walk > epi ? walk : epi);
+}
+
+// Park scratch in global memory (node vectors waiting for their sibling, when they do not fit LDS): a workgroup owns
+// one SLOT of it while it runs.  Slots are claimed with one atomic compare-and-swap on a flag array, scanning from
+// blockIdx.x % slots (workgroups are dispatched in order, so the first try almost always succeeds) and released at
+// the end of the walk.  With ~2x as many slots as the chip holds workgroups the scratch stays small -- 84 MB at the
+// configs[2] shape instead of 413 MB with one region per family tile -- and lives in the 256 MB Infinity Cache.  No
+// data passes between owners, so exclusivity is all that is needed; a workgroup that finds every slot taken keeps
+// scanning while the owners (resident by construction) finish.  Thread 0 publishes the slot in LDS word `s_slot`
+// ahead of the prologue's barrier.  Returns -1 when the schedule parks nothing in global memory.
+__device__ __forceinline__ int k2_acquire_park_slot(const K2MfmaArgs& a, int* s_slot, int tid)
+{
+    if (a.n_park_slots <= 0) return -1;
+    if (tid == 0) {
+        int s = (int)(blockIdx.x % (unsigned)a.n_park_slots);
+        while (atomicCAS(&a.park_flags[s], 0, 1) != 0) {
+            s = (s + 1 == a.n_park_slots) ? 0 : s + 1;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *s_slot = s;
+    }
+    return 0;
+}
+
+__device__ __forceinline__ void k2_release_park_slot(const K2MfmaArgs& a, const int* s_slot, int tid)
+{
+    // the root step ended with a workgroup barrier behind every read of the parks
+    if (a.n_park_slots > 0 && tid == 0) atomicExch(&a.park_flags[*s_slot], 0);
 }
 
 // A step whose children are both one-hot leaves (cafe/cafe_tree.c:208-209 twice, then :261-266):
@@ -394,13 +430,26 @@ __device__ __forceinline__ bool k2_cherry_step(const K2MfmaArgs& a, const cafehi
 // exp(log + log) treatment; the maximum over those IS the maximum over all.  The candidates of all the families of a
 // wave are collected in an LDS list and evaluated together, one per lane.  Families whose largest product is below
 // 1e-290 (underflow would blur the filter) take the plain loop.
-__device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0, bool batch,
-                                            int wave, int lane, int nwaves)
+template <bool REGS>   // REGS: R <= 256, the lane's prior values live in registers for the whole epilogue
+__device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0, int wave,
+                                                 int lane, int nwaves)
 {
     unsigned* cand = reinterpret_cast<unsigned*>(scratch) + wave * 64;                        // (family << 16) | root index
     unsigned long long* fmaxbits = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(scratch) + 8 * 64);   // [NF]
     const double* prior = a.ep->prior;
     const double* logprior = a.ep->logprior;
+    constexpr int PR = 4;
+    double pr[PR], lpr[PR];
+    if (REGS) {
+        // one global round trip per wave instead of one per family and pass (L2 latency under load is ~1-2 k cycles)
+#pragma unroll
+        for (int q = 0; q < PR; ++q) {
+            const int i = lane + 64 * q;
+            pr[q] = (i < a.R) ? prior[i] : 0.0;
+            lpr[q] = (i < a.R) ? logprior[i] : 0.0;
+        }
+    }
+    const int nq = REGS ? PR : (a.R + 63) / 64;
     int n_cand = 0;
     unsigned long long fastmask = 0;   // bit t: the wave's t-th family took the filtered path (wave-uniform)
 
@@ -421,21 +470,34 @@ __device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* L
         const int u = fam0 + f;
         if (u >= a.Fu) continue;
         const double* L = Lbuf + (size_t)f * a.LDv;
-        if (batch) {
-            const int lo = a.root_lo[u] - a.root_min, hi = a.root_hi[u] - a.root_min;
-            double* o = a.out_root + a.out_off[u];
-            for (int i = lo + lane; i <= hi; i += 64) o[i - lo] = L[i];
-            continue;
-        }
         double best = -INFINITY, qmax = 0.0;
         int bi = INT_MAX;  // INT_MAX = this lane has seen no element yet
-        for (int i = lane; i < a.R; i += 64) {
-            const double v = L[i];
-            if (bi == INT_MAX || v > best) {
-                best = v;
-                bi = i;
+        double vq[PR];     // REGS: the lane's root-vector entries, read once
+#pragma unroll
+        for (int q = 0; q < (REGS ? PR : 1); ++q) vq[q] = 0.0;
+        if (REGS) {
+#pragma unroll
+            for (int q = 0; q < PR; ++q) {
+                const int i = lane + 64 * q;
+                if (i < a.R) {
+                    const double v = L[i];
+                    vq[q] = v;
+                    if (bi == INT_MAX || v > best) {
+                        best = v;
+                        bi = i;
+                    }
+                    qmax = fmax(qmax, v * pr[q]);
+                }
             }
-            qmax = fmax(qmax, v * prior[i]);
+        } else {
+            for (int i = lane; i < a.R; i += 64) {
+                const double v = L[i];
+                if (bi == INT_MAX || v > best) {
+                    best = v;
+                    bi = i;
+                }
+                qmax = fmax(qmax, v * prior[i]);
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -464,25 +526,60 @@ __device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* L
         fastmask |= 1ull << t;
         if (lane == 0) fmaxbits[f] = 0ull;
         const double thr = qmax * (1.0 - 1e-9);
-        for (int i0 = 0; i0 < a.R; i0 += 64) {
-            const int i = i0 + lane;
-            const bool is_c = i < a.R && L[i] * prior[i] >= thr;
-            const unsigned long long m = __ballot(is_c);
-            if (m == 0) continue;
-            const int cnt = __popcll(m);
-            if (n_cand + cnt > 64) flush();
-            if (is_c) cand[n_cand + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)f << 16) | (unsigned)i;
-            n_cand += cnt;
+#pragma unroll
+        for (int q = 0; q < (REGS ? PR : 1); ++q) {
+            // (generic form: q enumerates nothing, the while loop below walks the runs)
+            if (REGS) {
+                const int i = lane + 64 * q;
+                const bool is_c = i < a.R && vq[q] * pr[q] >= thr;
+                const unsigned long long m = __ballot(is_c);
+                if (m != 0) {
+                    const int cnt = __popcll(m);
+                    if (n_cand + cnt > 64) flush();
+                    if (is_c) cand[n_cand + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)f << 16) | (unsigned)i;
+                    n_cand += cnt;
+                }
+            }
+        }
+        if (!REGS) {
+            for (int i0 = 0; i0 < a.R; i0 += 64) {
+                const int i = i0 + lane;
+                const bool is_c = i < a.R && L[i] * prior[i] >= thr;
+                const unsigned long long m = __ballot(is_c);
+                if (m == 0) continue;
+                const int cnt = __popcll(m);
+                if (n_cand + cnt > 64) flush();
+                if (is_c) cand[n_cand + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)f << 16) | (unsigned)i;
+                n_cand += cnt;
+            }
         }
     }
-    if (batch) return;
+    (void)nq;
     if (n_cand) flush();
     // lane t writes the maximum of the wave's t-th family
     {
         const int f = wave + lane * nwaves;
-        if (lane < 64 && f < a.NF && fam0 + f < a.Fu && ((fastmask >> lane) & 1ull))
+        if (f < a.NF && fam0 + f < a.Fu && ((fastmask >> lane) & 1ull))
             a.max_post[fam0 + f] = __longlong_as_double((long long)fmaxbits[f]);
     }
+}
+
+__device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0, bool batch,
+                                            int wave, int lane, int nwaves)
+{
+    if (batch) {
+        for (int f = wave; f < a.NF; f += nwaves) {
+            const int u = fam0 + f;
+            if (u >= a.Fu) continue;
+            const double* L = Lbuf + (size_t)f * a.LDv;
+            const int lo = a.root_lo[u] - a.root_min, hi = a.root_hi[u] - a.root_min;
+            double* o = a.out_root + a.out_off[u];
+            for (int i = lo + lane; i <= hi; i += 64) o[i - lo] = L[i];
+        }
+        return;
+    }
+    if (a.R <= 256) k2_epilogue_impl<true>(a, Lbuf, scratch, fam0, wave, lane, nwaves);
+    else k2_epilogue_impl<false>(a, Lbuf, scratch, fam0, wave, lane, nwaves);
 }
 
 // Column gathers of a one-hot leaf child in the accumulator layout of the 4-family kernel: out[g][j] =
@@ -549,13 +646,13 @@ template <int NFT_W, int NRT_W>
 __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 {
     extern __shared__ double Lbuf[];                          // [NF][LDv]
-    int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv * (1 + a.lds_parks));  // [NF][n_leaves]
-    int* s_colmax = s_cnt + a.NF * a.n_leaves;                // [NF]
     // the walk's step list and each step's matrix index, copied to LDS once: the step loop then never
     // waits on a chain of dependent global loads (step record -> node_key -> matrix base)
-    int* s_ops = s_colmax + a.NF;                             // [n_ops][12]  (cafehip::MfmaOp)
+    int* s_ops = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv * (1 + a.lds_parks));   // [n_ops][12]  (cafehip::MfmaOp)
     int* s_key = s_ops + a.n_ops * 12;                        // [n_ops][2] matrix offsets
     int* s_err = s_key + a.n_ops * 2;                         // [n_ops][2]  1: leaf child that carries the error model
+    int* s_cnt = s_err + a.n_ops * 2;                         // [NF][n_leaves]   (per tile; the epilogue's scratch overlays it)
+    int* s_colmax = s_cnt + a.NF * a.n_leaves;                // [NF]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -568,11 +665,18 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     // half so that the waves carrying the odd extra tile do not pile up on the same SIMDs
     const int wr = (wave / a.Wf + ((blockIdx.x >> 8) & 1) * (a.Wr >> 1)) % a.Wr;
     const int ft0 = wf * NFT_W;
-    const int fam0 = blockIdx.x * a.NF;
     const bool batch = (a.col_max != nullptr);
     const bool fold = (a.PTfold != nullptr) && !batch;
     const size_t park_stride = (size_t)a.NF * a.LDv;
-    double* my_park = a.park + (size_t)blockIdx.x * a.n_parks * park_stride;
+    const int fam0 = blockIdx.x * a.NF;
+    const int my_slot = k2_acquire_park_slot(a, s_colmax + a.NF, tid);   // (the word behind the column limits)
+
+    for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
+    for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
+        const cafehip::MfmaOp& o = a.ops[i >> 1];
+        s_key[i] = a.ep->node_key[o.child[i & 1]] * a.KP * a.LD;   // element offset of the child's matrix (< 2^31)
+        s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
+    }
 
     for (int i = tid; i < a.NF * a.n_leaves; i += blockDim.x) {
         const int f = i / a.n_leaves, j = i - f * a.n_leaves;
@@ -583,16 +687,11 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
         const int u = fam0 + f;
         s_colmax[f] = (batch && u < a.Fu) ? a.col_max[u] : (a.C - 1);
     }
-    for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
-    for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
-        const cafehip::MfmaOp& o = a.ops[i >> 1];
-        s_key[i] = a.ep->node_key[o.child[i & 1]] * a.KP * a.LD;   // element offset of the child's matrix (< 2^31)
-        s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
-    }
     __syncthreads();
     K2_STAMP(1);
+    double* my_park = a.park + (size_t)(my_slot >= 0 ? s_colmax[a.NF] : (int)blockIdx.x) * a.n_parks * park_stride;
 
-    // this lane's families never change: their column limits are read once, not once per step
+    // this lane's families do not change during the walk: their column limits are read once, not once per step
     int cmx[NFT_W][4];
 #pragma unroll
     for (int i = 0; i < NFT_W; ++i)
@@ -769,6 +868,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 
     // ---- root vector (in Lbuf) -> posterior (cafe/lambda.cpp:657-689) or packed root rows ----
     __builtin_amdgcn_s_setprio(0);
+    k2_release_park_slot(a, s_colmax + a.NF, tid);
     k2_epilogue(a, Lbuf, s_cnt, fam0, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
 }
@@ -866,13 +966,13 @@ template <int G, int NRT_W>
 __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 {
     extern __shared__ double Lbuf[];                          // [NF][LDv]
-    int* s_cnt = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv * (1 + a.lds_parks));  // [NF][n_leaves]
-    int* s_colmax = s_cnt + a.NF * a.n_leaves;                // [NF]
     // the walk's step list and each step's matrix index, copied to LDS once: the step loop then never
     // waits on a chain of dependent global loads (step record -> node_key -> matrix base)
-    int* s_ops = s_colmax + a.NF;                             // [n_ops][12]  (cafehip::MfmaOp)
+    int* s_ops = reinterpret_cast<int*>(Lbuf + (size_t)a.NF * a.LDv * (1 + a.lds_parks));   // [n_ops][12]  (cafehip::MfmaOp)
     int* s_key = s_ops + a.n_ops * 12;                        // [n_ops][2] matrix offsets
     int* s_err = s_key + a.n_ops * 2;                         // [n_ops][2]  1: leaf child that carries the error model
+    int* s_cnt = s_err + a.n_ops * 2;                         // [NF][n_leaves]   (per tile; the epilogue's scratch overlays it)
+    int* s_colmax = s_cnt + a.NF * a.n_leaves;                // [NF]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -885,11 +985,18 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     // half so that the waves carrying the odd extra tile do not pile up on the same SIMDs
     const int wr = (wave / a.Wf + ((blockIdx.x >> 8) & 1) * (a.Wr >> 1)) % a.Wr;
     const int fbase = wf * 4 * G;               // first family of this wave inside the workgroup
-    const int fam0 = blockIdx.x * a.NF;
     const bool batch = (a.col_max != nullptr);
     const bool fold = (a.PTfold != nullptr) && !batch;
     const size_t park_stride = (size_t)a.NF * a.LDv;
-    double* my_park = a.park + (size_t)blockIdx.x * a.n_parks * park_stride;
+    const int fam0 = blockIdx.x * a.NF;
+    const int my_slot = k2_acquire_park_slot(a, s_colmax + a.NF, tid);   // (the word behind the column limits)
+
+    for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
+    for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
+        const cafehip::MfmaOp& o = a.ops[i >> 1];
+        s_key[i] = a.ep->node_key[o.child[i & 1]] * a.KP * a.LD;   // element offset of the child's matrix (< 2^31)
+        s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
+    }
 
     for (int i = tid; i < a.NF * a.n_leaves; i += blockDim.x) {
         const int f = i / a.n_leaves, j = i - f * a.n_leaves;
@@ -900,16 +1007,11 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         const int u = fam0 + f;
         s_colmax[f] = (batch && u < a.Fu) ? a.col_max[u] : (a.C - 1);
     }
-    for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
-    for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
-        const cafehip::MfmaOp& o = a.ops[i >> 1];
-        s_key[i] = a.ep->node_key[o.child[i & 1]] * a.KP * a.LD;   // element offset of the child's matrix (< 2^31)
-        s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
-    }
     __syncthreads();
     K2_STAMP(1);
+    double* my_park = a.park + (size_t)(my_slot >= 0 ? s_colmax[a.NF] : (int)blockIdx.x) * a.n_parks * park_stride;
 
-    // this lane's families never change: their column limits are read once, not once per step
+    // this lane's families do not change during the walk: their column limits are read once, not once per step
     int cmx[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) cmx[g] = s_colmax[fbase + 4 * g + lk];
@@ -1095,6 +1197,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     }
 
     __builtin_amdgcn_s_setprio(0);
+    k2_release_park_slot(a, s_colmax + a.NF, tid);
     k2_epilogue(a, Lbuf, s_cnt, fam0, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
 }

@@ -178,7 +178,10 @@ def cfg5_report(tmp_path_factory):
 def test_cfg5_fitted_lambda_is_near_the_simulated_one(cfg5_report):
     r = cfg5_report
     assert r["null"].shape == (r["rng"].root_max - r["rng"].root_min + 1, 1000)
-    assert abs(r["lam_fit"] - r["cfg"]["lam"]) < 0.2 * r["cfg"]["lam"]
+    # (not tight: the reference's Poisson prior fit starts Nelder-Mead at a uniform draw in [0, 1), where the one
+    # forced count of 200 underflows poisspdf to 0 -- the fit stalls near its start, cafe/lambda.cpp:771-838 -- and
+    # the resulting prior pulls the rate up; the restated driver reproduces that behaviour)
+    assert abs(r["lam_fit"] - r["cfg"]["lam"]) < 0.5 * r["cfg"]["lam"]
     assert np.all(np.diff(r["null"], axis=1) >= 0)          # every root size's sample is sorted (:41)
 
 

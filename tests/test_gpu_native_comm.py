@@ -54,9 +54,9 @@ def test_search_through_a_one_rank_rccl_communicator_equals_the_plain_run(test1_
 def test_reload_rewires_the_exchange(test1_table):
     # a second, larger table after a search: the packed buffers are re-sized by `load` itself (the advisor's
     # round-1 finding: stale exchange buffers after a C++-side load)
-    g2, g1 = TR["test2"], TR["test1"]
-    lines = ["seed 10", "load -i %s -p 0.05 -max_size 20" % os.path.join(GOLD, "test2_families.txt"), "tree " + g2["newick"],
-             "lambda -s", "tree " + g1["newick"], "load -i %s -max_size 20" % test1_table, "lambda -s"]
+    g = TR["test1"]
+    lines = ["seed 10", "tree " + g["newick"], "load -i %s -max_size 5" % test1_table, "lambda -s",
+             "load -i %s -max_size 20" % test1_table, "lambda -s"]
     plain, _ = _run(lines, False)
     comm, _ = _run(lines, True)
     assert comm == plain

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""HBM-side traffic of the dominant kernel of every bench workload, for bench.py's roofline.traffic:
+two rocprofv3 passes per workload (FETCH_SIZE and WRITE_SIZE cannot share a pass), each in its own run with
+--kernel-trace only (the PMC guidance of /opt/skills/guides/MI355X_MICROARCH.md).  On gfx950 FETCH_SIZE tallies
+128-byte requests at 64 bytes: it is doubled; WRITE_SIZE is taken as reported.  Writes
+profiles/r02_pmc_traffic.json (keys "<config>:<families per launch>:<k2|mcnull>") and a text summary.
+
+    python tools/collect_pmc.py [out_dir]          (on the GPU box; needs rocprofv3)"""
+import glob
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORK = [("cfg2", 10000, "k2"), ("cfg3", 100000, "k2"), ("cfg4", 62500, "k2"), ("cfg5", 100000, "k2"), ("cfg5", 250000, "mcnull")]
+
+
+def run_pass(counter, cmd, out_dir, tag):
+    d = os.path.join(out_dir, "%s_%s" % (tag, counter))
+    subprocess.call(["rm", "-rf", d])
+    full = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "r", "--"] + cmd
+    subprocess.check_call(full, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    if not dbs:
+        raise RuntimeError("no rocpd database under " + d)
+    db = sqlite3.connect(dbs[0])
+    rows = db.execute("select name, counter_name, counter_value from pmc_events").fetchall()
+    agg = {}
+    for name, cn, v in rows:
+        if cn == counter and "k2_prune" in name:
+            agg.setdefault(name, []).append(v)
+    # the dominant kernel = the instantiation launched most often (the tuner's pick; the timed launches)
+    name = max(agg, key=lambda k: len(agg[k]))
+    vals = agg[name]
+    tail = vals[len(vals) // 2:]          # steady state: the second half of its launches
+    return name, sum(tail) / len(tail), len(vals)
+
+
+def main():
+    out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
+    os.makedirs(out_dir, exist_ok=True)
+    res, lines = {}, []
+    for cfg, F, kind in WORK:
+        cmd = ([sys.executable, "tools/mcnull_one.py", "6"] if kind == "mcnull" else
+               [sys.executable, "tools/ab_one.py", "%s:%d" % (cfg, F)])
+        tag = "%s_%d_%s" % (cfg, F, kind)
+        kname, fetch_kib, n = run_pass("FETCH_SIZE", cmd, out_dir, tag)
+        kname2, write_kib, n2 = run_pass("WRITE_SIZE", cmd, out_dir, tag)
+        traffic = (2.0 * fetch_kib + write_kib) * 1024.0
+        res["%s:%d:%s" % (cfg, F, kind)] = {
+            "kernel": kname, "launches_seen": n, "fetch_kib_raw": fetch_kib, "fetch_kib_x2": 2.0 * fetch_kib,
+            "write_kib": write_kib, "traffic_bytes": traffic,
+            "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate runs), FETCH_SIZE x2 (gfx950), "
+                    "mean over the second half of the kernel's launches",
+        }
+        lines.append("%-22s %-60s launches %4d  FETCH_SIZE %12.1f KiB (x2 = %12.1f)  WRITE_SIZE %12.1f KiB  -> %.3f MB per launch"
+                     % ("%s:%d:%s" % (cfg, F, kind), kname[:60], n, fetch_kib, 2 * fetch_kib, write_kib, traffic / 1e6))
+        print(lines[-1], flush=True)
+    json.dump(res, open(os.path.join(out_dir, "r02_pmc_traffic.json"), "w"), indent=1)
+    open(os.path.join(out_dir, "r02_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()
