@@ -23,6 +23,8 @@ SIGNATURES = {
     "cafehip_set_families": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
     "cafehip_set_error_model": (C.c_int, [C.c_void_p, C.c_int, _dp, _u8p]),
     "cafehip_eval_posterior": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip, _dp, _ip, _dp]),
+    "cafehip_eval_posterior_multi": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _ip]),
+    "cafehip_launch_info": (C.c_int, [C.c_void_p, _ip, _ip]),
     "cafehip_eval_posterior_async": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_void_p, C.c_void_p]),
     "cafehip_num_chunks": (C.c_int, [C.c_void_p]),
     "cafehip_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int)]),
@@ -51,6 +53,7 @@ HOST_SIGNATURES = {
     "cafehost_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cafehost_comm_unique_id": (C.c_int, [C.c_void_p]),
     "cafehost_init_comm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "cafehost_speculation_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "cafehost_exchange_stats": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_long)]),
     "cafehost_set_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cafehost_fetch_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_ulong, C.POINTER(C.c_void_p)]),

@@ -42,6 +42,7 @@ constexpr int kMaxNodes = 256;   // up to 128 taxa
 constexpr int kMaxPrior = 1000;  // FAMILYSIZEMAX, libtree/family.h:8
 constexpr int kMaxLeaves = kMaxNodes / 2;
 constexpr int kParamRing = 8;
+constexpr int kMaxSets = CAFEHIP_MAX_SETS;   // parameter sets evaluated in one pass (cafehip_eval_posterior_multi)
 
 thread_local std::string g_err;
 
@@ -78,8 +79,8 @@ struct KeyParam {
 
 struct EvalParams {
     int nkeys;
-    int pad;
-    int node_key[kMaxNodes];
+    int n_sets;                        // parameter sets of this evaluation (1 unless cafehip_eval_posterior_multi)
+    int node_key[kMaxSets][kMaxNodes]; // set -> node -> matrix
     KeyParam keys[kMaxNodes];
     double logprior[kMaxPrior];
     double prior[kMaxPrior];   // the same prior, not logged (K2's epilogue filters candidates by L * prior)
@@ -141,8 +142,13 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
     // two latencies overlap
     const KeyParam kp_first = ep->keys[min((int)blockIdx.z * keys_per_block, nkeys - 1)];
     if (ep_dev && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-        if (threadIdx.x == 0) ep_dev->nkeys = nkeys;
-        for (int i = threadIdx.x; i < n_nodes; i += 256) ep_dev->node_key[i] = ep->node_key[i];
+        const int n_sets = ep->n_sets;
+        if (threadIdx.x == 0) {
+            ep_dev->nkeys = nkeys;
+            ep_dev->n_sets = n_sets;
+        }
+        for (int i = threadIdx.x; i < n_sets * kMaxNodes; i += 256)
+            if (i % kMaxNodes < n_nodes) (&ep_dev->node_key[0][0])[i] = (&ep->node_key[0][0])[i];
         for (int i = threadIdx.x; i < n_prior; i += 256) {
             ep_dev->logprior[i] = ep->logprior[i];
             ep_dev->prior[i] = ep->prior[i];
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __res
     const int s = s0 + tx;
     const int c = c0 + ty;
     // first kernel of an evaluation: reset the first-zero-family slot K3 will atomicMin into
-    if (first_zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *first_zero = INT32_MAX;
+    if (first_zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)threadIdx.x < ep->n_sets) first_zero[threadIdx.x] = INT32_MAX;
 
     // The table runs of this (s, c) tile do not depend on the key: stage them ONCE and build the tile
     // for keys_per_block keys.  A needs j <= min(s, c) <= min(s0, c0) + 15; B needs i = c - j <= c0 + 15.
@@ -284,14 +290,19 @@ __global__ __launch_bounds__(256) void k1_build_matrices_rb(const EvalParams* __
     extern __shared__ double k1_smem[];
     const KeyParam kp_first = ep->keys[min((int)blockIdx.z * keys_per_block, nkeys - 1)];
     if (ep_dev && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-        if (threadIdx.x == 0) ep_dev->nkeys = nkeys;
-        for (int i = threadIdx.x; i < n_nodes; i += 256) ep_dev->node_key[i] = ep->node_key[i];
+        const int n_sets = ep->n_sets;
+        if (threadIdx.x == 0) {
+            ep_dev->nkeys = nkeys;
+            ep_dev->n_sets = n_sets;
+        }
+        for (int i = threadIdx.x; i < n_sets * kMaxNodes; i += 256)
+            if (i % kMaxNodes < n_nodes) (&ep_dev->node_key[0][0])[i] = (&ep->node_key[0][0])[i];
         for (int i = threadIdx.x; i < n_prior; i += 256) {
             ep_dev->logprior[i] = ep->logprior[i];
             ep_dev->prior[i] = ep->prior[i];
         }
     }
-    if (first_zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *first_zero = INT32_MAX;
+    if (first_zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)threadIdx.x < ep->n_sets) first_zero[threadIdx.x] = INT32_MAX;
     const int s0 = blockIdx.y * 16;
     const int c0 = blockIdx.x * (16 * K1Q);
     const int tx = threadIdx.x & 15;   // row within the tile (fast lane index: PT[c][s] stores are 128-byte runs)
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(1024) void k2_prune_v1(K2Args a)
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             const double* PTc =
-                a.PT + (size_t)a.ep->node_key[op.child[ch]] * a.KP * a.LD + row_lo + r;
+                a.PT + (size_t)a.ep->node_key[0][op.child[ch]] * a.KP * a.LD + row_lo + r;
             const bool errleaf =
                 (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.src[ch]];
             if (op.kind[ch] == 0 && !errleaf) {
@@ -585,26 +596,31 @@ __global__ __launch_bounds__(1024) void k2_prune_v1(K2Args a)
 // counter) publishes the first-zero index and a sequence number the host spins on.
 struct HostResult {
     volatile int32_t done_seq;
-    int32_t first_zero;
-    double chunk_sums[1];  // n_chunks
+    int32_t first_zero[kMaxSets];
+    int32_t pad;
+    double chunk_sums[1];  // [n_sets][n_chunks]
 };
 
 template <bool HOST_OUT>
 __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(const double* __restrict__ max_post_u,
                                                           const double* __restrict__ max_lik_u,
-                                                          const int32_t* __restrict__ fam2u, int F,
+                                                          const int32_t* __restrict__ fam2u, int F, int Fu,
                                                           double* __restrict__ chunk_sums,
                                                           int32_t* __restrict__ first_zero,
                                                           HostResult* host, int32_t* arrive, int32_t seq)
 {
+    // blockIdx.y = parameter set: its per-family values start at set * Fu, its chunk sums at set * gridDim.x
     __shared__ double red[CAFEHIP_CHUNK];
     __shared__ int s_last;
+    const int set = blockIdx.y;
+    max_post_u += (size_t)set * Fu;
+    max_lik_u += (size_t)set * Fu;
     const int i = blockIdx.x * CAFEHIP_CHUNK + threadIdx.x;
     double v = 0.0;
     if (i < F) {
         const int u = fam2u[i];
         v = log(max_post_u[u]);                                   // cafe/lambda.cpp:721
-        if (max_lik_u[u] == 0.0) atomicMin(first_zero, i);        // cafe/lambda.cpp:715-720
+        if (max_lik_u[u] == 0.0) atomicMin(first_zero + set, i);  // cafe/lambda.cpp:715-720
     }
     red[threadIdx.x] = v;
     __syncthreads();
@@ -613,19 +629,20 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(const double* __restri
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
+    const size_t slot = (size_t)set * gridDim.x + blockIdx.x;
     if (!HOST_OUT) {
-        if (threadIdx.x == 0) chunk_sums[blockIdx.x] = red[0];
+        if (threadIdx.x == 0) chunk_sums[slot] = red[0];
         return;
     }
     if (threadIdx.x == 0) {
-        host->chunk_sums[blockIdx.x] = red[0];
+        host->chunk_sums[slot] = red[0];
         __threadfence_system();
-        s_last = (atomicAdd(arrive, 1) == (int)gridDim.x - 1);
+        s_last = (atomicAdd(arrive, 1) == (int)(gridDim.x * gridDim.y) - 1);
     }
     __syncthreads();
     if (s_last && threadIdx.x == 0) {
         __threadfence();
-        host->first_zero = atomicMin(first_zero, INT32_MAX);  // atomic read of the final value
+        for (int q = 0; q < (int)gridDim.y; ++q) host->first_zero[q] = atomicMin(first_zero + q, INT32_MAX);  // atomic read of the final value
         *arrive = 0;
         __threadfence_system();
         host->done_seq = seq;
@@ -713,7 +730,7 @@ __global__ __launch_bounds__(1024) void k4_viterbi(K4Args a)
         int arg[2][NF];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            const double* PTc = a.PT + (size_t)a.ep->node_key[op.child[ch]] * a.KP * a.LD + row_lo + r;
+            const double* PTc = a.PT + (size_t)a.ep->node_key[0][op.child[ch]] * a.KP * a.LD + row_lo + r;
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 y[ch][f] = 0.0;
@@ -855,6 +872,7 @@ struct cafehip_ctx {
     double* d_chunk_sums = nullptr;
     int32_t* d_first_zero = nullptr;
     int n_chunks = 0;
+    int out_sets = 1;             // parameter sets the per-family / per-chunk output buffers hold
     std::vector<int32_t> fam2u;
 
     // tables + matrices
@@ -955,10 +973,11 @@ int grant_lds(cafehip_ctx* c, const void* fn, size_t lds, size_t default_limit)
     return 0;
 }
 
-int ensure_matrix_storage(cafehip_ctx* c)
+int ensure_matrix_storage(cafehip_ctx* c, size_t min_keys = 0)
 {
-    const size_t need_keys = (size_t)std::max(c->n_nodes, 1);
+    const size_t need_keys = std::max((size_t)std::max(c->n_nodes, 1), min_keys);
     if (c->d_PT && c->pt_keys_cap >= need_keys) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
     hipFree(c->d_PT);
     c->d_PT = nullptr;
     const size_t bytes = need_keys * (size_t)c->KP * c->LD * sizeof(double);
@@ -998,10 +1017,11 @@ int launch_error_fold(cafehip_ctx* c)
 // host part of reset_birthdeath_cache: unique keys over non-root nodes
 // (cafe/cafe_tree.c:374-391, 461-483) -> staged EvalParams
 int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_mu,
-                 const double* prior, EvalParams** out_h)
+                 const double* prior, EvalParams** out_h, int n_sets = 1)
 {
     if (c->n_nodes <= 0) return fail("no tree set");
     if (c->M < 0) return fail("no families/ranges set");
+    if (n_sets < 1 || n_sets > kMaxSets) return fail("1..%d parameter sets per evaluation, got %d", kMaxSets, n_sets);
     const int slot = c->ring_pos;
     c->ring_pos = (c->ring_pos + 1) % kParamRing;
     HIP_TRY(hipEventSynchronize(c->h_params_ev[slot]));
@@ -1010,40 +1030,46 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
     int nk = 0;
     std::vector<double> kl, km;
     std::vector<int> kb;
-    for (int i = 0; i < c->n_nodes; ++i) {
-        h->node_key[i] = 0;
-        if (i == c->root) continue;
-        if (!(c->bl[i] > 0))
-            return fail("node %d has branch length %g <= 0: the reference binds no matrix to it "
-                        "(cafe/cafe_tree.c:341-342)", i, c->bl[i]);
-        const int bl = c->bl_int[i];
-        int k = 0;
-        for (; k < nk; ++k)
-            if (kb[k] == bl && kl[k] == node_lambda[i] && km[k] == node_mu[i]) break;
-        if (k == nk) {
-            kb.push_back(bl);
-            kl.push_back(node_lambda[i]);
-            km.push_back(node_mu[i]);
-            const cafehip::KeyScalars ks = cafehip::key_scalars(bl, node_lambda[i], node_mu[i]);
-            h->keys[k].log_alpha = ks.log_alpha;
-            h->keys[k].log_beta = ks.log_beta;
-            h->keys[k].log_coeff = ks.log_coeff;
-            h->keys[k].coeff = ks.coeff;
-            h->keys[k].mode = ks.mode;
-            h->keys[k].bl = bl;
-            h->keys[k].l2a = ks.l2a;
-            h->keys[k].l2b = ks.l2b;
-            h->keys[k].rho_m = ks.rho_m;
-            h->keys[k].rho_e = ks.rho_e;
-            // 2: the register-blocked kernel may run rho^j in plain doubles over 8-term chunks without leaving
-            // the double range (binomial products * rho^8 stay below 2^1000); 1: per-term mantissa/exponent form
-            h->keys[k].fast_ok = !ks.fast_ok ? 0 : ((8.0 * std::abs(ks.rho_e) + c->lnc.log2_max_prod + 8.0 < 1000.0) ? 2 : 1);
-            ++nk;
+    for (int set = 0; set < n_sets; ++set) {
+        const double* nl = node_lambda + (size_t)set * c->n_nodes;
+        const double* nm = node_mu + (size_t)set * c->n_nodes;
+        for (int i = 0; i < c->n_nodes; ++i) {
+            h->node_key[set][i] = 0;
+            if (i == c->root) continue;
+            if (!(c->bl[i] > 0))
+                return fail("node %d has branch length %g <= 0: the reference binds no matrix to it "
+                            "(cafe/cafe_tree.c:341-342)", i, c->bl[i]);
+            const int bl = c->bl_int[i];
+            int k = 0;
+            for (; k < nk; ++k)
+                if (kb[k] == bl && kl[k] == nl[i] && km[k] == nm[i]) break;
+            if (k == nk) {
+                if (nk == kMaxNodes) return fail("more than %d distinct matrices in one evaluation", kMaxNodes);
+                kb.push_back(bl);
+                kl.push_back(nl[i]);
+                km.push_back(nm[i]);
+                const cafehip::KeyScalars ks = cafehip::key_scalars(bl, nl[i], nm[i]);
+                h->keys[k].log_alpha = ks.log_alpha;
+                h->keys[k].log_beta = ks.log_beta;
+                h->keys[k].log_coeff = ks.log_coeff;
+                h->keys[k].coeff = ks.coeff;
+                h->keys[k].mode = ks.mode;
+                h->keys[k].bl = bl;
+                h->keys[k].l2a = ks.l2a;
+                h->keys[k].l2b = ks.l2b;
+                h->keys[k].rho_m = ks.rho_m;
+                h->keys[k].rho_e = ks.rho_e;
+                // 2: the register-blocked kernel may run rho^j in plain doubles over 8-term chunks without leaving
+                // the double range (binomial products * rho^8 stay below 2^1000); 1: per-term mantissa/exponent form
+                h->keys[k].fast_ok = !ks.fast_ok ? 0 : ((8.0 * std::abs(ks.rho_e) + c->lnc.log2_max_prod + 8.0 < 1000.0) ? 2 : 1);
+                ++nk;
+            }
+            if (set == 0) c->node_key[i] = k;
+            h->node_key[set][i] = k;
         }
-        c->node_key[i] = k;
-        h->node_key[i] = k;
     }
     h->nkeys = nk;
+    h->n_sets = n_sets;
     c->nkeys = nk;
     c->all_keys_fast = true;
     for (int k = 0; k < nk; ++k)
@@ -1055,6 +1081,7 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
             h->prior[j] = prior[j];
         }
     }
+    if (ensure_matrix_storage(c, (size_t)nk)) return -1;
     *out_h = h;
     c->cur_params = h;
     c->cur_prior_n = prior ? c->R : 0;
@@ -1193,9 +1220,9 @@ int k2_fit_grid(cafehip_ctx* c, const void* fn, K2MfmaArgs& a, int* grid, int bl
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, block, lds));
             it = c->k2_occ.emplace(std::make_tuple(fn, block, lds), std::max(nb, 1)).first;
         }
-        slots = std::min(*grid, 2 * it->second * std::max(c->n_cu, 1));
+        slots = std::min(*grid * a.n_sets, 2 * it->second * std::max(c->n_cu, 1));
     }
-    const size_t regions = global_parks ? (size_t)(slots > 0 ? slots : *grid) : 1;
+    const size_t regions = global_parks ? (size_t)(slots > 0 ? slots : *grid * a.n_sets) : 1;
     const size_t park_bytes = regions * a.n_parks * a.NF * a.LDv * sizeof(double);
     if (park_bytes > c->park_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1227,7 +1254,7 @@ int launch_mfma_inst(cafehip_ctx* c, K2MfmaArgs a, int grid, int block, size_t l
 {
     if (grant_lds(c, reinterpret_cast<const void*>(&k2_prune_mfma<NFT_W, NRT_W>), lds, 64 * 1024)) return -1;
     if (k2_fit_grid(c, reinterpret_cast<const void*>(&k2_prune_mfma<NFT_W, NRT_W>), a, &grid, block, lds)) return -1;
-    hipLaunchKernelGGL((k2_prune_mfma<NFT_W, NRT_W>), dim3(grid), dim3(block), lds, c->stream, a);
+    hipLaunchKernelGGL((k2_prune_mfma<NFT_W, NRT_W>), dim3(grid, a.n_sets), dim3(block), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1406,7 +1433,7 @@ int launch_mfma4_inst(cafehip_ctx* c, K2MfmaArgs a, int grid, int block, size_t 
 {
     if (grant_lds(c, reinterpret_cast<const void*>(&k2_prune_mfma4<G, NRT_W>), lds, 64 * 1024)) return -1;
     if (k2_fit_grid(c, reinterpret_cast<const void*>(&k2_prune_mfma4<G, NRT_W>), a, &grid, block, lds)) return -1;
-    hipLaunchKernelGGL((k2_prune_mfma4<G, NRT_W>), dim3(grid), dim3(block), lds, c->stream, a);
+    hipLaunchKernelGGL((k2_prune_mfma4<G, NRT_W>), dim3(grid, a.n_sets), dim3(block), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1451,7 +1478,7 @@ std::array<long, 8> tune_key(const cafehip_ctx* c, int n_items)
             (long)c->msched.n_parks, (long)(c->d_err != nullptr)};
 }
 
-int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
+int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1)
 {
     if (n_items <= 0) return 0;
     K2Cfg k16{}, k4{};
@@ -1463,6 +1490,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     const bool have4 = allow4 && choose_mfma4_cfg(c, n_items, &k4, &cost4);
     if (!have16 && !have4) {
         // matrices too large for the MFMA wave grids: the row-per-thread kernel handles them
+        if (n_sets > 1) return fail("several parameter sets per pass need the matrix-core kernel (matrix side too large)");
         c->k2_used_mfma = false;
         K2Args a1 = v1;
         return launch_k2_v1(c, a1, n_items);
@@ -1476,10 +1504,17 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     bool tuning_launch = false;
     {
         const char* te = getenv("CAFEHIP_K2TUNE");
-        const bool enabled = v1.col_max == nullptr && !(te && atoi(te) == 0) && !shape_env && !getenv("CAFEHIP_K2CFG") &&
+        const bool enabled = n_sets == 1 && v1.col_max == nullptr && !(te && atoi(te) == 0) && !shape_env && !getenv("CAFEHIP_K2CFG") &&
                              !getenv("CAFEHIP_K2CFG4");
         auto& t = c->tune;
-        if (!enabled) {
+        if (!enabled && n_sets > 1) {
+            // several parameter sets in one pass: no measurement; the grid a single-set evaluation settled on is
+            // kept if there is one, else the cost model's choice stands
+            if (t.n_items == n_items && t.locked >= 0 && !t.cands.empty()) {
+                use4 = t.cands[t.locked].use4;
+                k = t.cands[t.locked].cfg;
+            }
+        } else if (!enabled) {
             t.n_items = -1;
         } else {
             if (t.n_items != n_items) {  // new table (set_families / set_tree reset n_items to -1)
@@ -1558,6 +1593,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     a.ep = v1.ep;
     a.ops = c->d_mops;
     a.n_ops = (int)c->msched.ops.size();
+    a.n_sets = n_sets;
     a.counts = v1.counts;
     a.Fu = v1.Fu;
     a.n_leaves = v1.n_leaves;
@@ -1640,14 +1676,15 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items)
     return rc;
 }
 
-int launch_k2(cafehip_ctx* c, K2Args& a, int n_items)
+int launch_k2(cafehip_ctx* c, K2Args& a, int n_items, int n_sets = 1)
 {
     const char* e = getenv("CAFEHIP_K2");
     if (e && strcmp(e, "v1") == 0) {
         c->k2_used_mfma = false;
+        if (n_sets > 1) return fail("several parameter sets per pass need the matrix-core kernel");
         return launch_k2_v1(c, a, n_items);
     }
-    return launch_k2_mfma(c, a, n_items);
+    return launch_k2_mfma(c, a, n_items, n_sets);
 }
 
 void fill_common_k2(cafehip_ctx* c, K2Args& a)
@@ -1677,13 +1714,46 @@ int check_ready(cafehip_ctx* c)
     return 0;
 }
 
+int ensure_output_sets(cafehip_ctx* c, int n_sets)
+{
+    if (n_sets <= c->out_sets) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipFree(c->d_max_lik);
+    hipFree(c->d_max_post);
+    hipFree(c->d_argmax);
+    hipFree(c->d_chunk_sums);
+    c->d_max_lik = c->d_max_post = c->d_chunk_sums = nullptr;
+    c->d_argmax = nullptr;
+    c->out_sets = 0;
+    const size_t fu = (size_t)std::max(c->Fu, 1) * n_sets;
+    HIP_TRY(hipMalloc(&c->d_max_lik, fu * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_max_post, fu * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_argmax, fu * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->d_chunk_sums, (size_t)std::max(c->n_chunks, 1) * n_sets * sizeof(double)));
+    const size_t need = (size_t)std::max(c->n_chunks, 1) * n_sets;
+    if (!c->h_result || need > c->h_result_chunks) {
+        hipHostFree(c->h_result);
+        c->h_result = nullptr;
+        const size_t bytes = sizeof(HostResult) + need * sizeof(double);
+        HIP_TRY(hipHostMalloc((void**)&c->h_result, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+        memset((void*)c->h_result, 0, bytes);
+        c->h_result_chunks = need;
+    }
+    c->out_sets = n_sets;
+    return 0;
+}
+
 int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu,
-                const double* prior, double* d_chunk_sums, int32_t* d_first_zero, bool host_out = false)
+                const double* prior, double* d_chunk_sums, int32_t* d_first_zero, bool host_out = false, int n_sets = 1)
 {
     if (check_ready(c)) return -1;
     HIP_TRY(hipSetDevice(c->device));
+    if (n_sets > 1 && ensure_output_sets(c, n_sets)) return -1;
+    if (n_sets > 1 && d_chunk_sums == nullptr) {
+        d_chunk_sums = c->d_chunk_sums;   // (re)allocated above
+    }
     EvalParams* h = nullptr;
-    if (stage_params(c, node_lambda, node_mu, prior, &h)) return -1;
+    if (stage_params(c, node_lambda, node_mu, prior, &h, n_sets)) return -1;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (launch_k1(c, d_first_zero)) return -1;
     if (launch_error_fold(c)) return -1;
@@ -1700,17 +1770,17 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
         a.err_ld = c->err_mfs + 1;
         a.leaf_has_err = c->d_leaf_has_err;
     }
-    if (launch_k2(c, a, c->Fu)) return -1;
+    if (launch_k2(c, a, c->Fu, n_sets)) return -1;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     if (c->n_chunks > 0) {
         if (host_out) {
             ++c->host_seq;
-            hipLaunchKernelGGL(k3_score<true>, dim3(c->n_chunks), dim3(CAFEHIP_CHUNK), 0, c->stream,
-                               c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, d_chunk_sums, d_first_zero,
+            hipLaunchKernelGGL(k3_score<true>, dim3(c->n_chunks, n_sets), dim3(CAFEHIP_CHUNK), 0, c->stream,
+                               c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, c->Fu, d_chunk_sums, d_first_zero,
                                c->h_result, c->d_arrive, c->host_seq);
         } else {
-            hipLaunchKernelGGL(k3_score<false>, dim3(c->n_chunks), dim3(CAFEHIP_CHUNK), 0, c->stream,
-                               c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, d_chunk_sums, d_first_zero,
+            hipLaunchKernelGGL(k3_score<false>, dim3(c->n_chunks, n_sets), dim3(CAFEHIP_CHUNK), 0, c->stream,
+                               c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, c->Fu, d_chunk_sums, d_first_zero,
                                (HostResult*)nullptr, (int32_t*)nullptr, 0);
         }
     }
@@ -1791,7 +1861,7 @@ int cafehip_create(cafehip_ctx** out, int device_id)
         HIP_TRY(hipEventCreateWithFlags(&c->h_params_ev[i], hipEventDisableTiming));
     }
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
-    HIP_TRY(hipMalloc(&c->d_first_zero, sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->d_first_zero, kMaxSets * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&c->d_arrive, sizeof(int32_t)));
     HIP_TRY(hipMemset(c->d_arrive, 0, sizeof(int32_t)));
     HIP_TRY(hipDeviceSynchronize());  // the memset ran on the null stream; later work uses a non-blocking one
@@ -1988,6 +2058,7 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
         memcpy(&ucounts[(size_t)u * n_leaves], counts + (size_t)uniq_rows[u] * n_leaves, sizeof(int32_t) * n_leaves);
 
     free_family_buffers(c);
+    c->out_sets = 1;
     c->F = F;
     c->Fu = Fu;
     c->n_leaves = n_leaves;
@@ -2141,7 +2212,7 @@ int cafehip_eval_posterior(cafehip_ctx* c, const double* node_lambda, const doub
     // fixed-order final sum over chunks (independent of how chunks were produced)
     double s = 0.0;
     for (int i = 0; i < c->n_chunks; ++i) s += c->h_result->chunk_sums[i];
-    const int32_t hfz = c->n_chunks > 0 ? c->h_result->first_zero : INT32_MAX;
+    const int32_t hfz = c->n_chunks > 0 ? c->h_result->first_zero[0] : INT32_MAX;
     const int fz = (hfz >= 0 && hfz < c->F) ? hfz : -1;
     *score = (fz >= 0) ? -INFINITY : s;  // cafe/lambda.cpp:753-760
     if (first_zero_family) *first_zero_family = fz;
@@ -2160,6 +2231,55 @@ int cafehip_eval_posterior(cafehip_ctx* c, const double* node_lambda, const doub
             if (argmax_root) argmax_root[i] = am[u];
         }
     }
+    return 0;
+}
+
+int cafehip_eval_posterior_multi(cafehip_ctx* c, int n_sets, const double* node_lambda, const double* node_mu,
+                                 const double* prior, double* scores, int32_t* first_zero_family)
+{
+    if (!c) return fail("null context");
+    if (!node_lambda || !node_mu || !prior || !scores) return fail("null argument");
+    if (n_sets < 1 || n_sets > kMaxSets) return fail("1..%d parameter sets per call, got %d", kMaxSets, n_sets);
+    if (c->d_err && c->err_mfs < c->range_max)
+        return fail("error model covers sizes 0..%d but range_max is %d", c->err_mfs, c->range_max);
+    if (n_sets == 1) return cafehip_eval_posterior(c, node_lambda, node_mu, prior, scores, first_zero_family, nullptr, nullptr, nullptr);
+    if (eval_device(c, node_lambda, node_mu, prior, nullptr, c->d_first_zero, true, n_sets)) return -1;
+    if (c->n_chunks > 0) {
+        const int32_t want = c->host_seq;
+        unsigned long spins = 0;
+        while (c->h_result->done_seq != want) {
+            if ((++spins & 0x3FFFF) == 0) {
+                hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess) {
+                    if (c->h_result->done_seq != want) HIP_TRY(hipStreamSynchronize(c->stream));
+                    if (c->h_result->done_seq != want) return fail("score kernel finished without publishing its result");
+                    break;
+                }
+                if (q != hipErrorNotReady) return fail("stream error while waiting: %s", hipGetErrorString(q));
+            }
+        }
+    } else {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (collect_kernel_ms(c)) return -1;
+    for (int q = 0; q < n_sets; ++q) {
+        // the same fixed-order sum over this set's chunks as the single-set call: bit-identical scores
+        double sum = 0.0;
+        for (int i = 0; i < c->n_chunks; ++i) sum += c->h_result->chunk_sums[(size_t)q * c->n_chunks + i];
+        const int32_t hfz = c->n_chunks > 0 ? c->h_result->first_zero[q] : INT32_MAX;
+        const int fz = (hfz >= 0 && hfz < c->F) ? hfz : -1;
+        scores[q] = (fz >= 0) ? -INFINITY : sum;
+        if (first_zero_family) first_zero_family[q] = fz;
+    }
+    return 0;
+}
+
+int cafehip_launch_info(cafehip_ctx* c, int* k2_workgroups, int* compute_units)
+{
+    if (!c) return fail("null context");
+    if (k2_workgroups) *k2_workgroups = c->k2_used_mfma ? c->k2_grid : (c->k2_nf > 0 ? (c->Fu + c->k2_nf - 1) / c->k2_nf : 0);
+    if (compute_units) *compute_units = c->n_cu;
     return 0;
 }
 

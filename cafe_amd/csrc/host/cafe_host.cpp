@@ -250,6 +250,12 @@ struct FMinSearch {
     std::vector<double> fv, x_mean, x_r, x_tmp;
     std::vector<int> idx;
     std::function<double(const double*)> eq;
+    // Optional: told which points the NEXT calls of eq() may ask for -- the four candidates of an iteration
+    // (reflection, expansion, the two contractions: all functions of the current simplex,
+    // libcommon/fminsearch.cpp:198-237), the initial simplex, the vertices of a shrink -- so that the owner can
+    // evaluate them in one batched device pass.  eq() is still called in the reference's order with the reference's
+    // accept rules; the hook only changes where the values come from.
+    std::function<void(const std::vector<std::vector<double>>&)> prefetch;
 
     void init(int n)
     {
@@ -322,16 +328,24 @@ struct FMinSearch {
 
     void shrink()
     {  // :238-250
-        for (int i = 1; i < N1; ++i) {
+        for (int i = 1; i < N1; ++i)
             for (int j = 0; j < N; ++j) v[i][j] = v[0][j] + sigma * (v[i][j] - v[0][j]);
-            fv[i] = eq(v[i].data());
-        }
+        if (prefetch) prefetch(std::vector<std::vector<double>>(v.begin() + 1, v.end()));
+        for (int i = 1; i < N1; ++i) fv[i] = eq(v[i].data());
         sort();
     }
 
     int minimize(const double* X0)
     {
         // __fminsearch_min_init :156-187 (note the isinf(previous vertex) rule)
+        if (prefetch) {
+            // the simplex as it comes out when no vertex evaluates to infinity (otherwise some points differ and are
+            // simply evaluated on demand)
+            std::vector<std::vector<double>> pts(N1, std::vector<double>(N));
+            for (int i = 0; i < N1; ++i)
+                for (int j = 0; j < N; ++j) pts[i][j] = ((i - 1) == j) ? (X0[j] ? (1 + delta) * X0[j] : zero_delta) : X0[j];
+            prefetch(pts);
+        }
         for (int i = 0; i < N1; ++i) {
             for (int j = 0; j < N; ++j) {
                 const bool big = (i > 1 && std::isinf(fv[i - 1]));
@@ -352,6 +366,16 @@ struct FMinSearch {
                 x_mean[a] /= N;
             }
             for (int a = 0; a < N; ++a) x_r[a] = x_mean[a] + rho * (x_mean[a] - v[N][a]);
+            if (prefetch) {
+                std::vector<std::vector<double>> pts(4, std::vector<double>(N));
+                for (int a = 0; a < N; ++a) {
+                    pts[0][a] = x_r[a];
+                    pts[1][a] = x_mean[a] + chi * (x_r[a] - x_mean[a]);     // expansion
+                    pts[2][a] = x_mean[a] + psi * (x_mean[a] - v[N][a]);   // inside contraction
+                    pts[3][a] = x_mean[a] + psi * (x_r[a] - x_mean[a]);    // outside contraction
+                }
+                prefetch(pts);
+            }
             const double fv_r = eq(x_r.data());
             if (fv_r < fv[0]) {
                 for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + chi * (x_r[a] - x_mean[a]);
@@ -912,6 +936,59 @@ struct cafehost_session {
         }
     }
 
+    // ---- speculative / batched evaluation ----------------------------------------------
+    // A table that fills less than half the chip leaves most compute units idle during an evaluation, and every
+    // evaluation pays the same launch and walk latency.  The points Nelder-Mead may ask for next are known before
+    // it asks (FMinSearch::prefetch), so they are evaluated TOGETHER (cafehip_eval_posterior_multi: one matrix
+    // launch, one pruning launch with a set dimension) and objective() takes its value from this cache.  The values
+    // are bit-identical to single evaluations, so the trajectory, the fitted parameters, the iteration count and the
+    // log lines are those of the sequential run.  CAFEHOST_SPECULATE=0/1 forces it off/on.
+    struct SpecEntry {
+        std::vector<double> x;
+        double score;
+        int32_t zero;
+    };
+    std::vector<SpecEntry> spec;
+    long spec_launches = 0, spec_points = 0, spec_hits = 0;
+
+    bool speculation_pays()
+    {
+        if (exchange) return false;   // sharded: every evaluation already ends in a collective
+        if (const char* e = getenv("CAFEHOST_SPECULATE")) return atoi(e) != 0;
+        int wg = 0, cu = 0;
+        if (cafehip_launch_info(ctx, &wg, &cu) != 0) return false;
+        return wg > 0 && 2 * wg <= cu;
+    }
+
+    void prefetch_points(const std::vector<std::vector<double>>& pts)
+    {
+        spec.clear();
+        if (pts.size() < 2 || !speculation_pays()) return;
+        std::vector<const std::vector<double>*> use;
+        const int ncheck = has_mu ? num_params : num_lambdas;
+        for (auto& x : pts) {
+            bool ok = true;
+            for (int i = 0; i < ncheck; ++i) ok = ok && !(x[i] < 0);   // objective() never evaluates these
+            for (auto* y : use) ok = ok && (*y != x);
+            if (ok && (int)use.size() < CAFEHIP_MAX_SETS) use.push_back(&x);
+        }
+        if (use.size() < 2) return;
+        const int n_sets = (int)use.size();
+        std::vector<double> nl((size_t)n_sets * tree.n), nm((size_t)n_sets * tree.n), one_l, one_m;
+        for (int q = 0; q < n_sets; ++q) {
+            node_rates(use[q]->data(), one_l, one_m);
+            std::copy(one_l.begin(), one_l.end(), nl.begin() + (size_t)q * tree.n);
+            std::copy(one_m.begin(), one_m.end(), nm.begin() + (size_t)q * tree.n);
+        }
+        std::vector<double> scores(n_sets);
+        std::vector<int32_t> zeros(n_sets);
+        if (cafehip_eval_posterior_multi(ctx, n_sets, nl.data(), nm.data(), prior.data(), scores.data(), zeros.data()) != 0)
+            return;   // e.g. too many distinct matrices for one pass: the points are evaluated on demand
+        ++spec_launches;
+        spec_points += n_sets;
+        for (int q = 0; q < n_sets; ++q) spec.push_back(SpecEntry{*use[q], scores[q], zeros[q] >= 0 ? zeros[q] + shard_lo : -1});
+    }
+
     // reset_birthdeath_cache + get_posterior over the WHOLE table (cafe/cafe_main.c:319-326, cafe/lambda.cpp:691-724):
     // on one GPU one synchronous call; sharded, this rank's partial sums stay on the device and the exchange (native
     // RCCL or the caller's callback) produces the global score.  zero = global index of the first zero-likelihood
@@ -948,7 +1025,16 @@ struct cafehost_session {
             std::vector<double> nl, nm;
             node_rates(x, nl, nm);
             int32_t zero = -1;
-            score = evaluate(nl, nm, prior, zero);
+            bool cached = false;
+            for (auto& e : spec)
+                if ((int)e.x.size() == num_params && std::equal(e.x.begin(), e.x.end(), x)) {
+                    score = e.score;
+                    zero = e.zero;
+                    cached = true;
+                    ++spec_hits;
+                    break;
+                }
+            if (!cached) score = evaluate(nl, nm, prior, zero);
             if (zero >= 0) {  // cafe/lambda.cpp:715-720, 753-760
                 if (!quiet)
                     fprintf(stderr, "WARNING: Calculated posterior probability for family %s = 0\n", fam.ids[zero].c_str());
@@ -992,9 +1078,11 @@ struct cafehost_session {
             pfm.tolx = 1e-6;
             pfm.tolf = 1e-6;
             pfm.eq = [&](const double* x) { return objective(x); };
+            pfm.prefetch = [&](const std::vector<std::vector<double>>& pts) { prefetch_points(pts); };
             std::vector<double> start = params;
             pfm.minimize(start.data());
             params = pfm.v[0];
+            spec.clear();
             search_iters = pfm.iters;
             last_score = pfm.fv[0];
             log("\n");
@@ -1412,6 +1500,20 @@ struct cafehost_session {
                     rem /= size[j];
                 }
                 for (size_t j = 0; j < ranges.size(); ++j) x[j] = ranges[j].step * idx[j] + ranges[j].start;
+                if (e % CAFEHIP_MAX_SETS == 0) {
+                    // the next grid points in one batched pass (small tables): same values, one launch
+                    std::vector<std::vector<double>> pts;
+                    for (long long e2 = e; e2 < total && e2 < e + CAFEHIP_MAX_SETS; ++e2) {
+                        long long rem2 = e2;
+                        std::vector<double> y(ranges.size());
+                        for (int j = (int)ranges.size() - 1; j >= 0; --j) {
+                            y[j] = ranges[j].step * (double)(rem2 % size[j]) + ranges[j].start;
+                            rem2 /= size[j];
+                        }
+                        pts.push_back(y);
+                    }
+                    prefetch_points(pts);
+                }
                 const double v = -objective(x.data());
                 if (fp) {
                     fprintf(fp, "%lf", idx[0] * ranges[0].step + ranges[0].start);
@@ -2497,6 +2599,15 @@ int cafehost_init_comm(cafehost_session* s, int rank, int world, const void* uni
     s->shard_rank = rank;
     s->shard_world = world;
     s->device_families_current = false;   // the next upload shards the table and wires the exchange
+    return 0;
+}
+
+int cafehost_speculation_stats(cafehost_session* s, long* launches, long* points, long* hits)
+{
+    if (!s) return host_fail("null session");
+    if (launches) *launches = s->spec_launches;
+    if (points) *points = s->spec_points;
+    if (hits) *hits = s->spec_hits;
     return 0;
 }
 

@@ -29,6 +29,7 @@ struct K2MfmaArgs {
     int n_ops;
     int32_t* park_flags;   // [n_park_slots] 0 = free: a workgroup that parks in global memory owns one slot of the
     int n_park_slots;      // scratch while it runs (slots ~ 2x the resident workgroups, not one per family tile)
+    int n_sets;            // gridDim.y: parameter sets evaluated in this pass; set s reads node_key[s], writes outputs at s * Fu
     int lds_parks;         // park slots [0, lds_parks) live in LDS behind the node buffer (no global round trip)
     const int32_t* counts;
     int Fu;
@@ -314,7 +315,7 @@ __device__ __forceinline__ int k2_acquire_park_slot(const K2MfmaArgs& a, int* s_
 {
     if (a.n_park_slots <= 0) return -1;
     if (tid == 0) {
-        int s = (int)(blockIdx.x % (unsigned)a.n_park_slots);
+        int s = (int)((blockIdx.y * gridDim.x + blockIdx.x) % (unsigned)a.n_park_slots);
         while (atomicCAS(&a.park_flags[s], 0, 1) != 0) {
             s = (s + 1 == a.n_park_slots) ? 0 : s + 1;
             __builtin_amdgcn_s_sleep(1);
@@ -431,9 +432,12 @@ __device__ __forceinline__ bool k2_cherry_step(const K2MfmaArgs& a, const cafehi
 // wave are collected in an LDS list and evaluated together, one per lane.  Families whose largest product is below
 // 1e-290 (underflow would blur the filter) take the plain loop.
 template <bool REGS>   // REGS: R <= 256, the lane's prior values live in registers for the whole epilogue
-__device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0, int wave,
-                                                 int lane, int nwaves)
+__device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0,
+                                                 size_t out_off, int wave, int lane, int nwaves)
 {
+    double* const max_lik = a.max_lik + out_off;       // this parameter set's block of the outputs
+    double* const max_post = a.max_post + out_off;
+    int32_t* const argmax = a.argmax + out_off;
     unsigned* cand = reinterpret_cast<unsigned*>(scratch) + wave * 64;                        // (family << 16) | root index
     unsigned long long* fmaxbits = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(scratch) + 8 * 64);   // [NF]
     const double* prior = a.ep->prior;
@@ -511,8 +515,8 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
             qmax = fmax(qmax, __shfl_xor(qmax, off));
         }
         if (lane == 0) {
-            a.max_lik[u] = best;
-            a.argmax[u] = bi;
+            max_lik[u] = best;
+            argmax[u] = bi;
         }
         if (!(qmax >= 1e-290) || t >= 64) {
             // plain form: every root size through log and exp
@@ -520,7 +524,7 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
             for (int i = lane; i < a.R; i += 64) bestp = fmax(bestp, exp(log(L[i]) + logprior[i]));
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) bestp = fmax(bestp, __shfl_xor(bestp, off));
-            if (lane == 0) a.max_post[u] = bestp;
+            if (lane == 0) max_post[u] = bestp;
             continue;
         }
         fastmask |= 1ull << t;
@@ -560,12 +564,12 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
     {
         const int f = wave + lane * nwaves;
         if (f < a.NF && fam0 + f < a.Fu && ((fastmask >> lane) & 1ull))
-            a.max_post[fam0 + f] = __longlong_as_double((long long)fmaxbits[f]);
+            max_post[fam0 + f] = __longlong_as_double((long long)fmaxbits[f]);
     }
 }
 
-__device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0, bool batch,
-                                            int wave, int lane, int nwaves)
+__device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0, size_t out_off,
+                                            bool batch, int wave, int lane, int nwaves)
 {
     if (batch) {
         for (int f = wave; f < a.NF; f += nwaves) {
@@ -578,8 +582,8 @@ __device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* L
         }
         return;
     }
-    if (a.R <= 256) k2_epilogue_impl<true>(a, Lbuf, scratch, fam0, wave, lane, nwaves);
-    else k2_epilogue_impl<false>(a, Lbuf, scratch, fam0, wave, lane, nwaves);
+    if (a.R <= 256) k2_epilogue_impl<true>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
+    else k2_epilogue_impl<false>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
 }
 
 // Column gathers of a one-hot leaf child in the accumulator layout of the 4-family kernel: out[g][j] =
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
     for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
         const cafehip::MfmaOp& o = a.ops[i >> 1];
-        s_key[i] = a.ep->node_key[o.child[i & 1]] * a.KP * a.LD;   // element offset of the child's matrix (< 2^31)
+        s_key[i] = a.ep->node_key[blockIdx.y][o.child[i & 1]] * a.KP * a.LD;   // element offset of the child's matrix (< 2^31)
         s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
     }
 
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     }
     __syncthreads();
     K2_STAMP(1);
-    double* my_park = a.park + (size_t)(my_slot >= 0 ? s_colmax[a.NF] : (int)blockIdx.x) * a.n_parks * park_stride;
+    double* my_park = a.park + (size_t)(my_slot >= 0 ? s_colmax[a.NF] : (int)(blockIdx.y * gridDim.x + blockIdx.x)) * a.n_parks * park_stride;
 
     // this lane's families do not change during the walk: their column limits are read once, not once per step
     int cmx[NFT_W][4];
@@ -869,7 +873,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     // ---- root vector (in Lbuf) -> posterior (cafe/lambda.cpp:657-689) or packed root rows ----
     __builtin_amdgcn_s_setprio(0);
     k2_release_park_slot(a, s_colmax + a.NF, tid);
-    k2_epilogue(a, Lbuf, s_cnt, fam0, batch, wave, lane, blockDim.x >> 6);
+    k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
 }
 
@@ -994,7 +998,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
     for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
         const cafehip::MfmaOp& o = a.ops[i >> 1];
-        s_key[i] = a.ep->node_key[o.child[i & 1]] * a.KP * a.LD;   // element offset of the child's matrix (< 2^31)
+        s_key[i] = a.ep->node_key[blockIdx.y][o.child[i & 1]] * a.KP * a.LD;   // element offset of the child's matrix (< 2^31)
         s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
     }
 
@@ -1009,7 +1013,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     }
     __syncthreads();
     K2_STAMP(1);
-    double* my_park = a.park + (size_t)(my_slot >= 0 ? s_colmax[a.NF] : (int)blockIdx.x) * a.n_parks * park_stride;
+    double* my_park = a.park + (size_t)(my_slot >= 0 ? s_colmax[a.NF] : (int)(blockIdx.y * gridDim.x + blockIdx.x)) * a.n_parks * park_stride;
 
     // this lane's families do not change during the walk: their column limits are read once, not once per step
     int cmx[G];
@@ -1198,6 +1202,6 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 
     __builtin_amdgcn_s_setprio(0);
     k2_release_park_slot(a, s_colmax + a.NF, tid);
-    k2_epilogue(a, Lbuf, s_cnt, fam0, batch, wave, lane, blockDim.x >> 6);
+    k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
 }

@@ -123,6 +123,23 @@ class Engine:
                                                   None, None, None))
         return score.value, fz.value
 
+    def get_posterior_multi(self, node_lambdas, node_mus, prior):
+        """Several objective evaluations in one pass: node_lambdas / node_mus are [n_sets, n_nodes].
+        Returns (scores[n_sets], first_zero[n_sets])."""
+        nl = np.ascontiguousarray(node_lambdas, np.float64)
+        nm = np.ascontiguousarray(node_mus, np.float64)
+        pr = np.ascontiguousarray(prior, np.float64)
+        assert nl.ndim == 2 and nl.shape == nm.shape and nl.shape[1] == self.n_nodes
+        scores = np.zeros(nl.shape[0])
+        fz = np.zeros(nl.shape[0], np.int32)
+        _lib.check(self._L.cafehip_eval_posterior_multi(self._h, nl.shape[0], _d(nl), _d(nm), _d(pr), _d(scores), _i(fz)))
+        return scores, fz
+
+    def launch_info(self):
+        wg, cu = C.c_int32(), C.c_int32()
+        _lib.check(self._L.cafehip_launch_info(self._h, C.byref(wg), C.byref(cu)))
+        return wg.value, cu.value
+
     def eval_posterior_async(self, node_lambda, node_mu, prior, d_chunk_sums_ptr, d_first_zero_ptr):
         nl = np.ascontiguousarray(node_lambda, np.float64)
         nm = np.ascontiguousarray(node_mu, np.float64)

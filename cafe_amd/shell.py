@@ -53,6 +53,12 @@ class CafeShell:
         assert len(unique_id) == self.COMM_ID_BYTES
         self._check(self._L.cafehost_init_comm(self._h, int(rank), int(world), C.c_char_p(unique_id)))
 
+    def speculation_stats(self):
+        """(batched passes, points evaluated in them, objective calls served from them)."""
+        a, b, c = C.c_long(), C.c_long(), C.c_long()
+        self._check(self._L.cafehost_speculation_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def exchange_stats(self):
         sec, calls = C.c_double(), C.c_long()
         self._check(self._L.cafehost_exchange_stats(self._h, C.byref(sec), C.byref(calls)))

@@ -35,6 +35,9 @@ extern "C" {
 
 typedef struct cafehip_ctx cafehip_ctx;
 
+/* Parameter sets one pass over the table can evaluate (cafehip_eval_posterior_multi). */
+#define CAFEHIP_MAX_SETS 8
+
 /* Families per partial-sum chunk of the score reduction (fixed so that the
  * summation order does not depend on how families are sharded over GPUs). */
 #define CAFEHIP_CHUNK 256
@@ -100,6 +103,20 @@ int cafehip_set_error_model(cafehip_ctx *ctx, int mfs, const double *errormatrix
 int cafehip_eval_posterior(cafehip_ctx *ctx, const double *node_lambda, const double *node_mu,
                            const double *prior, double *score, int32_t *first_zero_family,
                            double *max_lik, int32_t *argmax_root, double *max_post);
+
+/* n_sets (1..CAFEHIP_MAX_SETS) objective evaluations in ONE pass over the table: set s uses
+ * node_lambda[s * n_nodes ...], node_mu[s * n_nodes ...]; all share the prior.  The matrices of all sets are built by
+ * one launch (identical (branch length, lambda, mu) keys are shared across sets), the pruning launch gains a set
+ * dimension, the score reduction too.  scores[s] / first_zero_family[s] are bit-identical to what
+ * cafehip_eval_posterior returns for set s alone.  What it is for: a table that fills only a fraction of the chip
+ * -- the four candidate vertices of a Nelder-Mead iteration (libcommon/fminsearch.cpp:198-237), the points of a
+ * `lambda -r` grid (cafe/lambda.cpp:192-231), the clusters of the -k model -- cost little more than one evaluation.
+ * Fails (caller falls back to single calls) when the sets need more than 256 distinct matrices or the matrix side
+ * is beyond the matrix-core kernels. */
+int cafehip_eval_posterior_multi(cafehip_ctx *ctx, int n_sets, const double *node_lambda, const double *node_mu,
+                                 const double *prior, double *scores, int32_t *first_zero_family);
+/* Workgroups of the last pruning launch and the device's compute units (how full a single evaluation makes the chip). */
+int cafehip_launch_info(cafehip_ctx *ctx, int *k2_workgroups, int *compute_units);
 
 /* Same evaluation, but nothing is copied back and nothing synchronises: the
  * per-chunk partial sums (cafehip_num_chunks doubles; chunk c covers families

@@ -89,6 +89,13 @@ int cafehost_num_evaluations(cafehost_session *s);                  /* objective
 double cafehost_search_seconds(cafehost_session *s);                /* wall-clock of the last search */
 double cafehost_poisson_lambda(cafehost_session *s);
 
+/* Batched candidate evaluation of the searches: passes launched, points evaluated in them, and how
+ * many objective calls took their value from such a pass.  A table that fills less than half of the chip has the
+ * four candidates of every Nelder-Mead iteration (and the points of a `lambda -r` grid) evaluated together through
+ * cafehip_eval_posterior_multi; trajectories and log lines are those of the sequential run.
+ * CAFEHOST_SPECULATE=0 / 1 forces it off / on. */
+int cafehost_speculation_stats(cafehost_session *s, long *launches, long *points, long *hits);
+
 /* Trace of the last command's objective calls: row i = (params[0..num_params), score).
  * Returns the number of rows copied (<= max_rows). */
 int cafehost_get_trace(cafehost_session *s, double *out, int max_rows);
