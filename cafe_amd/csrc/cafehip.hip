@@ -1387,7 +1387,7 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_
 // 4x4x4_4b shape: NF = 4 * G * wf (K2Cfg.nft_w carries G).  CAFEHIP_K2CFG4="G,nrtw,wf,wr" overrides.
 // (G, NRT_W) wave tiles of the 4-family kernel that compile without scratch spills at 2 waves per SIMD (256 registers
 // per lane; checked with tools/k2_regs.py after every kernel change)
-constexpr bool k2_fits4(int G, int nrt_w) { return G * nrt_w <= 15 || (G == 4 && nrt_w == 4) || (G == 3 && nrt_w == 6); }
+constexpr bool k2_fits4(int G, int nrt_w) { return G * nrt_w <= 21; }   // 24 accumulators spill
 bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_cost, std::vector<K2Cand>* all = nullptr)
 {
     const int RT = (std::max(c->C, c->R) + 15) / 16;
@@ -1558,18 +1558,22 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
                 HIP_TRY(hipEventSynchronize(t.e1));
                 float ms = 0;
                 HIP_TRY(hipEventElapsedTime(&ms, t.e0, t.e1));
-                t.best_ms[t.cur] = std::min(t.best_ms[t.cur], ms);
+                // round 0 runs while the clocks are still ramping up: it only ranks; the decision uses the
+                // measurements of rounds 1 and 2
+                if (t.round == 0) t.best_ms[t.cur] = ms;
+                else if (t.round == 1) t.best_ms[t.cur] = ms;
+                else t.best_ms[t.cur] = std::min(t.best_ms[t.cur], ms);
                 t.pending = false;
-                // next candidate; the second round (round 0 also pays first-launch costs) only re-times the
-                // grids within 12 % of the best
+                // next candidate: round 1 re-times the grids within 12 % of round 0's best, round 2 those within
+                // 5 % of round 1's best
                 const float best = *std::min_element(t.best_ms.begin(), t.best_ms.end());
                 do {
                     if (++t.cur == (int)t.cands.size()) {
                         t.cur = 0;
                         ++t.round;
                     }
-                } while (t.round == 1 && t.best_ms[t.cur] > 1.12f * best);
-                if (t.round >= 2) {
+                } while ((t.round == 1 && t.best_ms[t.cur] > 1.12f * best) || (t.round == 2 && t.best_ms[t.cur] > 1.05f * best));
+                if (t.round >= 3) {
                     t.locked = (int)(std::min_element(t.best_ms.begin(), t.best_ms.end()) - t.best_ms.begin());
                     std::lock_guard<std::mutex> g(g_tuned_mu);
                     g_tuned[tune_key(c, n_items)] = t.cands[t.locked];

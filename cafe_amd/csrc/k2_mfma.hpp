@@ -182,9 +182,6 @@ __device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const i
 #ifndef CAFE_K2_ABLATE
 #define CAFE_K2_ABLATE 0   // debug timing builds ONLY (wrong results): bit 0 = no B-operand loads in the k loop, bit 1 = no A loads
 #endif
-#ifndef CAFE_K2_PRIO
-#define CAFE_K2_PRIO 1   // s_setprio 1 for the waves that carry the extra row tile of an uneven deal
-#endif
 
 // inside a region: one operand load, then its share of the matrix instructions, ... so that the loads issue in
 // the shadow of this wave's own MFMAs instead of ahead of them (sched_group_barrier: 0x20 VMEM read, 0x100 DS
@@ -329,98 +326,6 @@ __device__ __forceinline__ void k2_release_park_slot(const K2MfmaArgs& a, const 
 {
     // the root step ended with a workgroup barrier behind every read of the parks
     if (a.n_park_slots > 0 && tid == 0) atomicExch(&a.park_flags[*s_slot], 0);
-}
-
-// A step whose children are both one-hot leaves (cafe/cafe_tree.c:208-209 twice, then :261-266):
-//     L_v[row] = PT_a[count_a][row] * PT_b[count_b][row]
-// has no product at all.  It is written straight into its destination in the [family][row] layout the next
-// product reads -- every lane of the workgroup takes (family, row) pairs, rows fastest, so the global reads are
-// 512-byte runs per wave and nothing passes through the accumulator layout.  Rows up to the tile-rounded count are
-// written (the matrices are zero padded there), rows beyond a family's column limit are zero (batch mode).
-template <bool GLOBAL_DST>
-__device__ __forceinline__ void k2_fill_cherry(int NF, int n_leaves, int LD, int LDv, const double* Pa, const double* Pb, int lc0,
-                                               int lc1, const int* s_cnt, const int* s_colmax, double* dst, int rows16,
-                                               bool is_root, bool batch, int wave, int lane, int nwaves)
-{
-    for (int kb = 0; kb < rows16; kb += 256) {
-        for (int f0 = wave; f0 < NF; f0 += 2 * nwaves) {
-            // two families x four 64-row runs per pass: all 16 loads of a lane are in flight together
-            double va[2][4], vb[2][4];
-            const int ff[2] = {f0, f0 + nwaves};
-            bool ok[2];
-            int cm[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int f = min(ff[h], NF - 1);
-                const int ca = s_cnt[f * n_leaves + lc0], cb = s_cnt[f * n_leaves + lc1];
-                cm[h] = s_colmax[f];
-                ok[h] = !batch || (ca <= cm[h] && cb <= cm[h]);
-                const double* ra = Pa + (size_t)(ok[h] ? ca : 0) * LD;
-                const double* rb = Pb + (size_t)(ok[h] ? cb : 0) * LD;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = kb + lane + 64 * q;
-                    const bool in = k < rows16;
-                    va[h][q] = in ? ra[k] : 0.0;
-                    vb[h][q] = in ? rb[k] : 0.0;
-                }
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (ff[h] >= NF) continue;
-                double* d = dst + (size_t)ff[h] * LDv;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = kb + lane + 64 * q;
-                    if (k < rows16) {
-                        double v = va[h][q] * vb[h][q];
-                        if (batch && (!ok[h] || (!is_root && k > cm[h]))) v = 0.0;
-                        d[k] = v;
-                    }
-                }
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ void k2_fill_cherry_lds(int NF, int n_leaves, int LD, int LDv, const double* Pa, const double* Pb,
-                                                int lc0, int lc1, const int* s_cnt, const int* s_colmax, double* dst,
-                                                int rows16, bool is_root, bool batch, int wave, int lane, int nwaves)
-{
-    k2_fill_cherry<false>(NF, n_leaves, LD, LDv, Pa, Pb, lc0, lc1, s_cnt, s_colmax, dst, rows16, is_root, batch, wave, lane, nwaves);
-}
-__device__ __forceinline__ void k2_fill_cherry_global(int NF, int n_leaves, int LD, int LDv, const double* Pa, const double* Pb,
-                                                   int lc0, int lc1, const int* s_cnt, const int* s_colmax, double* dst,
-                                                   int rows16, bool is_root, bool batch, int wave, int lane, int nwaves)
-{
-    k2_fill_cherry<true>(NF, n_leaves, LD, LDv, Pa, Pb, lc0, lc1, s_cnt, s_colmax, dst, rows16, is_root, batch, wave, lane, nwaves);
-}
-
-// Runs step `op` if both of its children are one-hot leaves (with the error model folded into their matrices, if
-// any) and returns true; otherwise returns false and touches nothing.
-__device__ __forceinline__ bool k2_cherry_step(const K2MfmaArgs& a, const cafehip::MfmaOp& op, int oi, const int* s_err,
-                                               const int* s_key, const int* s_cnt, const int* s_colmax, double* Lbuf,
-                                               double* my_park, size_t park_stride, int RT, int row_lo, bool fold, bool batch,
-                                               int wave, int lane)
-{
-    if (op.kind[0] != 0 || op.kind[1] != 0) return false;
-    const bool e0 = s_err[oi * 2] != 0, e1 = s_err[oi * 2 + 1] != 0;
-    if ((e0 || e1) && !fold) return false;   // a leaf under an unfolded error model is not one-hot
-    const double* Pa = (e0 ? a.PTfold : a.PT) + s_key[oi * 2] + row_lo;
-    const double* Pb = (e1 ? a.PTfold : a.PT) + s_key[oi * 2 + 1] + row_lo;
-    const int nwaves = blockDim.x >> 6;
-    if (op.dst_park >= a.lds_parks) {
-        k2_fill_cherry_global(a.NF, a.n_leaves, a.LD, a.LDv, Pa, Pb, op.leafcol[0], op.leafcol[1], s_cnt, s_colmax,
-                              my_park + (size_t)op.dst_park * park_stride, RT * 16, op.is_root != 0, batch, wave, lane, nwaves);
-    } else {
-        __syncthreads();   // every wave is done reading the destination buffer
-        K2_STAMP(2 + 6 * oi + 3);
-        double* dst = Lbuf + ((op.dst_park >= 0) ? (size_t)(1 + op.dst_park) * park_stride : 0);
-        k2_fill_cherry_lds(a.NF, a.n_leaves, a.LD, a.LDv, Pa, Pb, op.leafcol[0], op.leafcol[1], s_cnt, s_colmax, dst, RT * 16,
-                           op.is_root != 0, batch, wave, lane, nwaves);
-        __syncthreads();
-    }
-    return true;
 }
 
 // Root vectors (in Lbuf) -> per-family posterior (cafe/lambda.cpp:657-689) or packed root rows (batch mode).
@@ -586,55 +491,6 @@ __device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* L
     else k2_epilogue_impl<false>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
 }
 
-// Column gathers of a one-hot leaf child in the accumulator layout of the 4-family kernel: out[g][j] =
-// PT[count][row tile j].  NT = the wave's live tiles (wave-uniform): in posterior mode the loads are unconditional
-// (no per-load exec-mask branch), in batch mode a count beyond the row's column limit selects zero.
-template <int G, int NRT_W, int NT>
-__device__ __forceinline__ void k2_gather4(double (&out)[G][NRT_W], const double* PTe, int LD, const int* s_cnt, int n_leaves,
-                                           int leafcol, int fbase, int lk, int li, int rt0, const int (&cmx)[G], bool batch)
-{
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int cnt = s_cnt[(fbase + 4 * g + lk) * n_leaves + leafcol];
-        const bool ok = !batch || cnt <= cmx[g];
-        const double* col = PTe + (size_t)(ok ? cnt : 0) * LD + rt0 * 16 + li;
-#pragma unroll
-        for (int j = 0; j < NRT_W; ++j) {
-            if (j < NT) {
-                const double v = col[j * 16];
-                out[g][j] = ok ? v : 0.0;
-            } else {
-                out[g][j] = 0.0;
-            }
-        }
-    }
-}
-
-template <int NFT_W, int NRT_W, int NT>
-__device__ __forceinline__ void k2_gather16(cafe_d4 (&out)[NFT_W][NRT_W], const double* PTe, int LD, const int* s_cnt,
-                                            int n_leaves, int leafcol, int ft0, int lk, int li, int rt0,
-                                            const int (&cmx)[NFT_W][4], bool batch)
-{
-#pragma unroll
-    for (int i = 0; i < NFT_W; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cnt = s_cnt[((ft0 + i) * 16 + lk + 4 * r) * n_leaves + leafcol];
-            const bool ok = !batch || cnt <= cmx[i][r];
-            const double* col = PTe + (size_t)(ok ? cnt : 0) * LD + rt0 * 16 + li;
-#pragma unroll
-            for (int j = 0; j < NRT_W; ++j) {
-                if (j < NT) {
-                    const double v = col[j * 16];
-                    out[i][j][r] = ok ? v : 0.0;
-                } else {
-                    out[i][j][r] = 0.0;
-                }
-            }
-        }
-    }
-}
-
 template <int NFT_W, int NRT_W, int NT>
 __device__ __forceinline__ void k2_edge16(const double* __restrict__ bp, const int (&boff)[NRT_W], size_t kstride,
                                           const double* ap, int astride, int ksteps, cafe_d4 (&acc)[NFT_W][NRT_W])
@@ -711,17 +567,8 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
         const int ntile = rt_base + (wr < rt_rem ? 1 : 0);  // <= NRT_W
         const int rt0 = wr * rt_base + min(wr, rt_rem);
         const bool wave_active = ntile > 0;
-        if (k2_cherry_step(a, op, oi, s_err, s_key, s_cnt, s_colmax, Lbuf, my_park, park_stride, RT, row_lo, fold, batch, wave, lane)) {
-            K2_STAMP(2 + 6 * oi + 4);
-            continue;
-        }
-        // waves dealt the extra row tile of an uneven deal carry the step: they get the matrix pipe first
-#if CAFE_K2_PRIO
-        if (rt_rem != 0 && wr < rt_rem) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-#endif
 
-        cafe_d4 hold[NFT_W][NRT_W];   // declared per step: nothing of it is live across steps (or across a cherry step)
+        cafe_d4 hold[NFT_W][NRT_W];   // declared per step: nothing of it is live across steps
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             const bool has_err = s_err[oi * 2 + ch] != 0;
@@ -754,23 +601,17 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                 }
             } else if (op.kind[ch] == 0 && !errleaf) {
                 // one-hot leaf: factor = PT[count][row]  (cafe/cafe_tree.c:208-209)
-                if (ntile == NRT_W) {
-                    k2_gather16<NFT_W, NRT_W, NRT_W>(fac, PTe, a.LD, s_cnt, a.n_leaves, op.leafcol[ch], ft0, lk, li, rt0, cmx, batch);
-                } else if (NRT_W > 1 && ntile == NRT_W - 1) {
-                    k2_gather16<NFT_W, NRT_W, (NRT_W > 1 ? NRT_W - 1 : 1)>(fac, PTe, a.LD, s_cnt, a.n_leaves, op.leafcol[ch], ft0, lk, li, rt0, cmx, batch);
-                } else {
 #pragma unroll
-                    for (int i = 0; i < NFT_W; ++i) {
+                for (int i = 0; i < NFT_W; ++i) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int f = (ft0 + i) * 16 + lk + 4 * r;
-                            const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
-                            const bool ok = cnt <= cmx[i][r];
-                            // one address per family; the row tiles are constant byte offsets from it
-                            const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = (ft0 + i) * 16 + lk + 4 * r;
+                        const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
+                        const bool ok = cnt <= cmx[i][r];
+                        // one address per family; the row tiles are constant byte offsets from it
+                        const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
-                            for (int j = 0; j < NRT_W; ++j) fac[i][j][r] = (ok && j < ntile) ? col[j * 16] : 0.0;
-                        }
+                        for (int j = 0; j < NRT_W; ++j) fac[i][j][r] = (ok && j < ntile) ? col[j * 16] : 0.0;
                     }
                 }
             } else {
@@ -871,7 +712,6 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     }
 
     // ---- root vector (in Lbuf) -> posterior (cafe/lambda.cpp:657-689) or packed root rows ----
-    __builtin_amdgcn_s_setprio(0);
     k2_release_park_slot(a, s_colmax + a.NF, tid);
     k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
@@ -1029,15 +869,6 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         const int ntile = rt_base + (wr < rt_rem ? 1 : 0);
         const int rt0 = wr * rt_base + min(wr, rt_rem);
         const bool wave_active = ntile > 0;
-        if (k2_cherry_step(a, op, oi, s_err, s_key, s_cnt, s_colmax, Lbuf, my_park, park_stride, RT, row_lo, fold, batch, wave, lane)) {
-            K2_STAMP(2 + 6 * oi + 4);
-            continue;
-        }
-        // waves dealt the extra row tile of an uneven deal carry the step: they get the matrix pipe first
-#if CAFE_K2_PRIO
-        if (rt_rem != 0 && wr < rt_rem) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-#endif
 
         // one-hot leaf child next to a child that needs the matrix cores: issue its column gathers first so
         // that their latency hides under the sibling's product (the Hadamard product commutes exactly)
@@ -1051,26 +882,20 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
             const int leafcol = pre_ch ? op.leafcol[1] : op.leafcol[0];
             const bool pre_folded = fold && s_err[oi * 2 + pre_ch] != 0;
             const double* PTe = (pre_folded ? a.PTfold : a.PT) + s_key[oi * 2 + pre_ch] + row_lo;
-            if (ntile == NRT_W) {
-                k2_gather4<G, NRT_W, NRT_W>(pre, PTe, a.LD, s_cnt, a.n_leaves, leafcol, fbase, lk, li, rt0, cmx, batch);
-            } else if (NRT_W > 1 && ntile == NRT_W - 1) {
-                k2_gather4<G, NRT_W, (NRT_W > 1 ? NRT_W - 1 : 1)>(pre, PTe, a.LD, s_cnt, a.n_leaves, leafcol, fbase, lk, li, rt0, cmx, batch);
-            } else {
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const int f = fbase + 4 * g + lk;
-                    const int cnt = s_cnt[f * a.n_leaves + leafcol];
-                    const bool ok = cnt <= cmx[g];
-                    // one address per family group; the row tiles are constant byte offsets from it
-                    const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
+            for (int g = 0; g < G; ++g) {
+                const int f = fbase + 4 * g + lk;
+                const int cnt = s_cnt[f * a.n_leaves + leafcol];
+                const bool ok = cnt <= cmx[g];
+                // one address per family group; the row tiles are constant byte offsets from it
+                const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
-                    for (int j = 0; j < NRT_W; ++j) pre[g][j] = (ok && j < ntile) ? col[j * 16] : 0.0;
-                }
+                for (int j = 0; j < NRT_W; ++j) pre[g][j] = (ok && j < ntile) ? col[j * 16] : 0.0;
             }
         }
 
         K2_STAMP(2 + 6 * oi + 0);
-        double hold[G][NRT_W];   // declared per step: nothing of it is live across steps (or across a cherry step)
+        double hold[G][NRT_W];   // declared per step: nothing of it is live across steps
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -1101,20 +926,14 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                     }
                 }
             } else if (op.kind[ch] == 0 && !errleaf) {
-                if (ntile == NRT_W) {
-                    k2_gather4<G, NRT_W, NRT_W>(fac, PTe, a.LD, s_cnt, a.n_leaves, op.leafcol[ch], fbase, lk, li, rt0, cmx, batch);
-                } else if (NRT_W > 1 && ntile == NRT_W - 1) {
-                    k2_gather4<G, NRT_W, (NRT_W > 1 ? NRT_W - 1 : 1)>(fac, PTe, a.LD, s_cnt, a.n_leaves, op.leafcol[ch], fbase, lk, li, rt0, cmx, batch);
-                } else {
 #pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        const int f = fbase + 4 * g + lk;
-                        const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
-                        const bool ok = cnt <= cmx[g];
-                        const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
+                for (int g = 0; g < G; ++g) {
+                    const int f = fbase + 4 * g + lk;
+                    const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
+                    const bool ok = cnt <= cmx[g];
+                    const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
-                        for (int j = 0; j < NRT_W; ++j) fac[g][j] = (ok && j < ntile) ? col[j * 16] : 0.0;
-                    }
+                    for (int j = 0; j < NRT_W; ++j) fac[g][j] = (ok && j < ntile) ? col[j * 16] : 0.0;
                 }
             } else {
                 const double* Lsrc = Lbuf;
@@ -1200,7 +1019,6 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         K2_STAMP(2 + 6 * oi + 4);
     }
 
-    __builtin_amdgcn_s_setprio(0);
     k2_release_park_slot(a, s_colmax + a.NF, tid);
     k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);

@@ -97,7 +97,7 @@ int cafehip_set_error_model(cafehip_ctx *ctx, int mfs, const double *errormatrix
  * Optional per-family arrays (NULL to skip): max_lik[F], argmax_root[F]
  * (index into the root range, as pitem->maxlh, cafe/lambda.cpp:673-676),
  * max_post[F].
- * The first ~15 evaluations after a table / tree / error model is set run different launch shapes of the
+ * The first ~20-25 evaluations after a table / tree / error model is set run different launch shapes of the
  * pruning kernel while the library times them and keeps the fastest; every shape returns bit-identical values,
  * so those evaluations are ordinary ones (CAFEHIP_K2TUNE=0 disables the measurement). */
 int cafehip_eval_posterior(cafehip_ctx *ctx, const double *node_lambda, const double *node_mu,
