@@ -650,6 +650,78 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(const double* __restri
 }
 
 
+// ------------------------------------------------------------------------------------
+// K3 of the k-cluster model (cafe_get_clustered_posterior, cafe/cafe_main.c:165-253).  K2 has left the per-family
+// max posterior of every cluster (set) in max_post_u[k * Fu + u].  Per family, clusters ascending as the reference
+// loops them: MAP_k = max_post_k * weight_k (:196), sum (:197), membership p_z[k] = MAP_k / sum (:204),
+// MAP = sum_k p_z[k] * MAP_k (:210-213); the score adds log(MAP) (:241) and the new weights are the mean memberships
+// (:243-245).  One workgroup per chunk of CAFEHIP_CHUNK families in family order, fixed-shape tree sums for the
+// score and for each cluster's membership; MAP == 0 marks the family (:231-240).
+// ------------------------------------------------------------------------------------
+struct ClusterWeights {
+    double w[kMaxSets];
+};
+
+__global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_cluster_score(const double* __restrict__ max_post_u,
+                                                                  const int32_t* __restrict__ fam2u, int F, int Fu, int K,
+                                                                  ClusterWeights cw, double* __restrict__ chunk_sums,
+                                                                  double* __restrict__ memb_sums /* [K][n_chunks] */,
+                                                                  int32_t* __restrict__ first_zero,
+                                                                  double* __restrict__ map_out /* [F] or NULL */,
+                                                                  double* __restrict__ pz_out /* [F][K] or NULL */)
+{
+    __shared__ double red[CAFEHIP_CHUNK];
+    const int i = blockIdx.x * CAFEHIP_CHUNK + threadIdx.x;
+    double pz[kMaxSets];
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < kMaxSets; ++k) pz[k] = 0.0;
+    if (i < F) {
+        const int u = fam2u[i];
+        double mapk[kMaxSets];
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < kMaxSets; ++k) {
+            mapk[k] = 0.0;
+            if (k < K) {
+                mapk[k] = max_post_u[(size_t)k * Fu + u] * cw.w[k];
+                sum += mapk[k];
+            }
+        }
+        double expected = 0.0;
+#pragma unroll
+        for (int k = 0; k < kMaxSets; ++k) {
+            if (k < K) {
+                pz[k] = mapk[k] / sum;
+                expected += pz[k] * mapk[k];
+                if (pz_out) pz_out[(size_t)i * K + k] = pz[k];
+            }
+        }
+        if (map_out) map_out[i] = expected;
+        if (expected == 0.0) atomicMin(first_zero, i);
+        v = log(expected);
+    }
+    // score, then one tree sum per cluster membership
+    for (int q = -1; q < K; ++q) {
+        double x = v;
+#pragma unroll
+        for (int k = 0; k < kMaxSets; ++k)
+            if (q == k) x = pz[k];
+        __syncthreads();
+        red[threadIdx.x] = x;
+        __syncthreads();
+#pragma unroll
+        for (int s = CAFEHIP_CHUNK / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (q < 0) chunk_sums[blockIdx.x] = red[0];
+            else memb_sums[(size_t)q * gridDim.x + blockIdx.x] = red[0];
+        }
+    }
+}
+
 // device words -> pinned host mirror, then a sequence number (cafehip_fetch_small)
 __global__ __launch_bounds__(256) void k_fetch_small(const uint64_t* __restrict__ src, uint64_t* host_dst, size_t n_words,
                                                      volatile int32_t* host_seq, int32_t seq)
@@ -2276,6 +2348,81 @@ int cafehip_eval_posterior_multi(cafehip_ctx* c, int n_sets, const double* node_
         scores[q] = (fz >= 0) ? -INFINITY : sum;
         if (first_zero_family) first_zero_family[q] = fz;
     }
+    return 0;
+}
+
+int cafehip_eval_clustered_posterior(cafehip_ctx* c, int K, const double* node_lambda, const double* node_mu,
+                                     const double* weights, const double* prior, double* score,
+                                     int32_t* first_zero_family, double* membership_sums, double* family_map,
+                                     double* family_membership)
+{
+    if (check_ready(c)) return -1;
+    if (!node_lambda || !node_mu || !weights || !prior || !score || !membership_sums) return fail("null argument");
+    if (K < 1 || K > kMaxSets) return fail("1..%d clusters, got %d", kMaxSets, K);
+    if (c->d_err && c->err_mfs < c->range_max)
+        return fail("error model covers sizes 0..%d but range_max is %d", c->err_mfs, c->range_max);
+    HIP_TRY(hipSetDevice(c->device));
+    if (ensure_output_sets(c, std::max(K, 2))) return -1;
+    EvalParams* h = nullptr;
+    if (stage_params(c, node_lambda, node_mu, prior, &h, K)) return -1;
+    if (launch_k1(c, c->d_first_zero)) return -1;
+    if (launch_error_fold(c)) return -1;
+    K2Args a;
+    fill_common_k2(c, a);
+    a.counts = c->d_counts;
+    a.Fu = c->Fu;
+    a.max_lik = c->d_max_lik;
+    a.argmax = c->d_argmax;
+    a.max_post = c->d_max_post;
+    if (c->d_err) {
+        a.err = c->d_err;
+        a.err_ld = c->err_mfs + 1;
+        a.leaf_has_err = c->d_leaf_has_err;
+    }
+    if (K == 1) {
+        if (launch_k2(c, a, c->Fu, 1)) return -1;
+    } else if (launch_k2(c, a, c->Fu, K)) {
+        return -1;
+    }
+    std::fill(membership_sums, membership_sums + K, 0.0);
+    *score = 0.0;
+    if (first_zero_family) *first_zero_family = -1;
+    if (c->n_chunks == 0) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    ClusterWeights cw;
+    for (int k = 0; k < kMaxSets; ++k) cw.w[k] = k < K ? weights[k] : 0.0;
+    double *d_memb = nullptr, *d_map = nullptr, *d_pz = nullptr;
+    auto cleanup = [&]() { hipFree(d_memb); hipFree(d_map); hipFree(d_pz); };
+#define TRY4(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail("%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    TRY4(hipMalloc(&d_memb, (size_t)K * c->n_chunks * sizeof(double)));
+    if (family_map) TRY4(hipMalloc(&d_map, (size_t)c->F * sizeof(double)));
+    if (family_membership) TRY4(hipMalloc(&d_pz, (size_t)c->F * K * sizeof(double)));
+    hipLaunchKernelGGL(k3_cluster_score, dim3(c->n_chunks), dim3(CAFEHIP_CHUNK), 0, c->stream, c->d_max_post, c->d_fam2u,
+                       c->F, c->Fu, K, cw, c->d_chunk_sums, d_memb, c->d_first_zero, d_map, d_pz);
+    TRY4(hipGetLastError());
+    std::vector<double> sums(c->n_chunks), memb((size_t)K * c->n_chunks);
+    int32_t fz_dev = INT32_MAX;
+    TRY4(hipMemcpyAsync(sums.data(), c->d_chunk_sums, sums.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TRY4(hipMemcpyAsync(memb.data(), d_memb, memb.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TRY4(hipMemcpyAsync(&fz_dev, c->d_first_zero, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (family_map) TRY4(hipMemcpyAsync(family_map, d_map, (size_t)c->F * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (family_membership)
+        TRY4(hipMemcpyAsync(family_membership, d_pz, (size_t)c->F * K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TRY4(hipStreamSynchronize(c->stream));
+#undef TRY4
+    cleanup();
+    double sc = 0.0;
+    for (int i = 0; i < c->n_chunks; ++i) sc += sums[i];
+    for (int k = 0; k < K; ++k) {
+        double m = 0.0;
+        for (int i = 0; i < c->n_chunks; ++i) m += memb[(size_t)k * c->n_chunks + i];
+        membership_sums[k] = m;
+    }
+    const int fz = (fz_dev >= 0 && fz_dev < c->F) ? fz_dev : -1;
+    *score = fz >= 0 ? -INFINITY : sc;
+    if (first_zero_family) *first_zero_family = fz;
     return 0;
 }
 

@@ -778,6 +778,12 @@ struct cafehost_session {
     int search_iters = 0, n_evals = 0;
     double search_seconds = 0;
     std::vector<double> trace;
+    // k-cluster model (`lambda -k`, cafe/lambda.cpp:273-352): K clusters, each with its own rates, mixed by weights
+    int k_clusters = 0;
+    bool fixcluster0 = false;                 // -f: cluster 0 has lambda fixed at 0
+    std::vector<double> k_weights;            // param->k_weights: mean memberships after every evaluation
+    std::vector<double> last_membership_sums; // sum over families of p_z[k] of the LAST evaluation
+    std::vector<double> p_z_membership;       // F x K of the last evaluation (kept for the membership log)
     std::vector<std::vector<double>> cond_dist;  // ConditionalDistribution::matrix, cafe/pvalue.cpp:13
     std::vector<int> root_dist;  // param->root_dist: families per root size (index = size), cafe_commands.cpp:742
     // error model (one model file; ErrorStruct, libtree/family.h:31-38)
@@ -1267,8 +1273,154 @@ struct cafehost_session {
         return out;
     }
 
+    // ---- k-cluster model ---------------------------------------------------------------------------------
+    // Rates of cluster k on every node: initialize_k_bd -> set_birth_death_probabilities4 (cafe/cafe_shell.c:148-177,
+    // 194-213): the K (or, with -f, K - 1) values of the node's lambda class sit next to each other in the
+    // parameter vector; with -f cluster 0 has lambda 0 (an identity matrix: nothing changes along the tree).
+    void cluster_node_rates(const double* x, int k, double* nl, double* nm) const
+    {
+        const int K = k_clusters, fix = fixcluster0 ? 1 : 0;
+        for (int i = 0; i < tree.n; ++i) {
+            int cls = have_lambda_tree ? node_class[i] : 0;
+            if (cls < 0) cls = 0;
+            nl[i] = fix ? (k == 0 ? 0.0 : x[cls * (K - 1) + (k - 1)]) : x[cls * K + k];
+            nm[i] = -1;
+        }
+    }
+
+    // __cafe_cluster_lambda_search (cafe/cafe_main.c:272-308): weights from the parameters
+    // (input_values_copy_weights, libtree/input_values.c:84-94), cafe_get_clustered_posterior on the device in ONE
+    // pass over the table for all K clusters, then the weights become the mean memberships (cafe_main.c:243-245).
+    double cluster_objective(const double* x)
+    {
+        const int K = k_clusters, fix = fixcluster0 ? 1 : 0;
+        const int n_lam = num_lambdas * (K - fix);
+        double score = 0;
+        bool skip = false;
+        for (int i = 0; i < num_params; ++i)
+            if (x[i] < 0) {
+                skip = true;
+                score = std::log(0.0);
+                break;
+            }
+        if (!skip) {
+            k_weights.assign(K, 0.0);
+            double sumofweights = 0;
+            for (int i = 0; i < K - 1; ++i) {
+                k_weights[i] = x[n_lam + i];
+                sumofweights += x[n_lam + i];
+            }
+            k_weights[K - 1] = 1 - sumofweights;
+            std::vector<double> nl((size_t)K * tree.n), nm((size_t)K * tree.n);
+            for (int k = 0; k < K; ++k) cluster_node_rates(x, k, nl.data() + (size_t)k * tree.n, nm.data() + (size_t)k * tree.n);
+            int32_t zero = -1;
+            last_membership_sums.assign(K, 0.0);
+            p_z_membership.assign((size_t)std::max(fam.F(), 1) * K, 0.0);
+            hip_check(cafehip_eval_clustered_posterior(ctx, K, nl.data(), nm.data(), k_weights.data(), prior.data(), &score, &zero,
+                                                       last_membership_sums.data(), nullptr, p_z_membership.data()));
+            if (zero >= 0 && !quiet)
+                fprintf(stderr, "WARNING: Calculated posterior probability for family %s = 0\n", fam.ids[zero].c_str());
+            for (int k = 0; k < K; ++k) k_weights[k] = last_membership_sums[k] / fam.F();
+        }
+        ++n_evals;
+        for (int i = 0; i < num_params; ++i) trace.push_back(x[i]);
+        trace.push_back(score);
+        if (!quiet) {
+            printf("Lambda : %s\n", join_double(x, n_lam).c_str());
+            printf("p : %s\n", join_double(k_weights.data(), K).c_str());
+            printf("Score: %f\n", score);
+            printf(".");
+        }
+        return -score;
+    }
+
+    // cafe_best_lambda_by_fminsearch with k > 0 (cafe/lambda.cpp:525-647)
+    void cluster_search()
+    {
+        if (exchange) throw std::runtime_error("the k-cluster search is not sharded: run it on one rank");
+        const int K = k_clusters, fix = fixcluster0 ? 1 : 0, kfix = K - fix;
+        const int n_lam = num_lambdas * kfix;
+        const int max_runs = 10;
+        std::vector<double> scores;
+        bool converged = false;
+        int runs = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        do {
+            // input_values_randomize, k > 0 branch (cafe/cafe_main.c:129-151)
+            const double mbl = tree.max_branch_length();
+            params.assign(num_params, 0.0);
+            for (int i = 0; i < n_lam; ++i) params[i] = 1.0 / mbl * unifrnd();
+            k_weights.assign(K, 0.0);
+            double sumw = 0;
+            for (int j = 0; j < K; ++j) {
+                k_weights[j] = unifrnd();
+                sumw += k_weights[j];
+            }
+            for (int j = 0; j < K; ++j) k_weights[j] = k_weights[j] / sumw;
+            for (int j = 0; j < K - 1; ++j) params[n_lam + j] = k_weights[j];
+            FMinSearch pfm;
+            pfm.init(num_params);
+            pfm.tolx = 1e-5;
+            pfm.tolf = 1e-5;
+            pfm.eq = [&](const double* x) { return cluster_objective(x); };
+            std::vector<double> start = params;
+            pfm.minimize(start.data());
+            params = pfm.v[0];
+            double current_p = params[n_lam], prev_p;
+            do {   // restart from the mean memberships of the last evaluation until the first weight settles (:571-591)
+                for (int j = 0; j < K - 1; ++j) params[n_lam + j] = last_membership_sums[j] / fam.F();
+                std::vector<double> again = params;
+                pfm.minimize(again.data());
+                params = pfm.v[0];
+                prev_p = current_p;
+                current_p = params[n_lam];
+            } while (current_p - prev_p > pfm.tolx);
+            search_iters = pfm.iters;
+            last_score = pfm.fv[0];
+            log("\n");
+            log("Lambda Search Result: %d\n", pfm.iters);
+            log("Lambda : %s%s\n", fix ? "0," : "", join_double(params.data(), n_lam).c_str());
+            log("p : %s\n", join_double(k_weights.data(), K).c_str());
+            log("p0 : %f\n", params[n_lam]);
+            log("Score: %f\n", pfm.fv[0]);
+            if (runs > 0) {
+                const double minscore = *std::min_element(scores.begin(), scores.end());
+                if (std::fabs(minscore - pfm.fv[0]) < 10 * pfm.tolf) converged = true;
+            }
+            scores.push_back(pfm.fv[0]);
+            ++runs;
+        } while (checkconv && !converged && runs < max_runs);
+        search_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (checkconv) {
+            if (converged)
+                log("score converged in %d runs.\n", runs);
+            else
+                log("score failed to converge in %d runs.\n", max_runs);
+        }
+    }
+
+    // log_cluster_membership, cafe/gene_family.cpp:355-372
+    void log_cluster_membership()
+    {
+        std::ostringstream os;
+        os << "The Number of families : " << fam.F() << "\n";
+        for (int i = 0; i < fam.F(); ++i) {
+            os << "family " << fam.ids[i] << ": ";
+            for (int k = 0; k < k_clusters; ++k) os << " " << p_z_membership[(size_t)i * k_clusters + k];
+            os << "\n";
+        }
+        log("%s", os.str().c_str());
+    }
+
     void finish_command(const std::vector<std::string>& tokens, const char* what)
     {
+        if (k_clusters > 0) {
+            log("DONE: %s Search or setting, for command:\n", what);
+            std::string cmd;
+            for (auto& t : tokens) cmd += t + " ";
+            log("%s\n", cmd.c_str());
+            return;
+        }
         // after lambda/lambdamu the cache is rebuilt for the final parameters and left resident
         // (cafe/lambda.cpp:504-507, cafe/lambdamu.cpp:254-257)
         std::vector<double> nl, nm;
@@ -1441,7 +1593,9 @@ struct cafehost_session {
         num_lambdas = 1;
         bool search_flag = false, score_flag = false, each = false;
         double vlambda = -1;
-        std::vector<double> lambdas;
+        std::vector<double> lambdas, weights_arg;
+        k_clusters = 0;
+        fixcluster0 = false;
         struct LambdaRange { double start, step, end; };
         std::vector<LambdaRange> ranges;
         std::string outfile;
@@ -1453,6 +1607,12 @@ struct cafehost_session {
                 if (a.argv.empty()) throw std::runtime_error("lambda -t needs a lambda tree");
                 set_lambda_tree(a.argv.back());
             } else if (a.opt == "-l") lambdas = doubles_of(a);
+            else if (a.opt == "-p") weights_arg = doubles_of(a);   // k_weights (cafe/lambda.cpp:129-133)
+            else if (a.opt == "-k") {
+                if (!a.argv.empty()) k_clusters = atoi(a.argv[0].c_str());
+                if (k_clusters < 1 || k_clusters > CAFEHIP_MAX_SETS)
+                    throw std::runtime_error("lambda -k: 1.." + std::to_string(CAFEHIP_MAX_SETS) + " clusters");
+            } else if (a.opt == "-f") fixcluster0 = true;
             else if (a.opt == "-v") {
                 // SINGLE_LAMBDA: set_all_lambdas before the command (cafe/lambda.cpp:386-389); a search starts from
                 // random values anyway, so it only matters for the set form
@@ -1468,7 +1628,7 @@ struct cafehost_session {
             } else if (a.opt == "-o") {
                 if (!a.argv.empty()) outfile = a.argv[0];
             } else
-                throw std::runtime_error("lambda " + a.opt + " is outside this build's scope (supported: -s -l -v -t -r -o -e -score -checkconv)");
+                throw std::runtime_error("lambda " + a.opt + " is outside this build's scope (supported: -s -l -v -t -r -o -e -score -checkconv -k -f -p)");
         }
         upload();
         n_evals = 0;
@@ -1526,6 +1686,27 @@ struct cafehost_session {
         }
         set_prior_rfsize_empirical();
         num_params = num_lambdas;
+        if (k_clusters == 0 && !weights_arg.empty()) k_clusters = (int)weights_arg.size();   // -p alone sets k (:129-139)
+        if (k_clusters > 0) {
+            // clustered model: lambda_search / set_parameters, cafe/lambda.cpp:273-352
+            const int fix = fixcluster0 ? 1 : 0;
+            if (k_clusters - fix < 1) throw std::runtime_error("lambda -k -f needs at least two clusters");
+            num_params = num_lambdas * (k_clusters - fix) + (k_clusters - 1);
+            if (search_flag) {
+                cluster_search();
+            } else {
+                if ((int)lambdas.size() != num_lambdas * (k_clusters - fix) || (int)weights_arg.size() != k_clusters)
+                    throw std::runtime_error("ERROR(lambda): Number of parameters not correct: -l needs " +
+                                             std::to_string(num_lambdas * (k_clusters - fix)) + " values and -p " +
+                                             std::to_string(k_clusters));
+                params = lambdas;   // input_values_set_lambdas + input_values_set_k_weights (the first K - 1 weights)
+                params.insert(params.end(), weights_arg.begin(), weights_arg.end() - 1);
+                last_score = cluster_objective(params.data());
+            }
+            if (search_flag) log_cluster_membership();
+            finish_command(tokens, "Lambda");
+            return 0;
+        }
         if (search_flag && each) {
             each_family_search(outfile);
         } else if (search_flag) {

@@ -135,6 +135,26 @@ class Engine:
         _lib.check(self._L.cafehip_eval_posterior_multi(self._h, nl.shape[0], _d(nl), _d(nm), _d(pr), _d(scores), _i(fz)))
         return scores, fz
 
+    def clustered_posterior(self, node_lambdas, node_mus, weights, prior, per_family=False):
+        """cafe_get_clustered_posterior (k-cluster model): node rates [K, n_nodes], weights [K].
+        Returns (score, first_zero, membership_sums[K][, MAP[F], p_z[F, K]])."""
+        nl = np.ascontiguousarray(node_lambdas, np.float64)
+        nm = np.ascontiguousarray(node_mus, np.float64)
+        w = np.ascontiguousarray(weights, np.float64)
+        pr = np.ascontiguousarray(prior, np.float64)
+        K = nl.shape[0]
+        assert nl.shape == nm.shape == (K, self.n_nodes) and w.shape == (K,)
+        score, fz = C.c_double(), C.c_int32(-1)
+        memb = np.zeros(K)
+        fmap = np.zeros(self.F) if per_family else None
+        pz = np.zeros((self.F, K)) if per_family else None
+        _lib.check(self._L.cafehip_eval_clustered_posterior(self._h, K, _d(nl), _d(nm), _d(w), _d(pr), C.byref(score),
+                                                            C.byref(fz), _d(memb), _d(fmap) if per_family else None,
+                                                            _d(pz) if per_family else None))
+        if per_family:
+            return score.value, fz.value, memb, fmap, pz
+        return score.value, fz.value, memb
+
     def launch_info(self):
         wg, cu = C.c_int32(), C.c_int32()
         _lib.check(self._L.cafehip_launch_info(self._h, C.byref(wg), C.byref(cu)))

@@ -115,6 +115,19 @@ int cafehip_eval_posterior(cafehip_ctx *ctx, const double *node_lambda, const do
  * is beyond the matrix-core kernels. */
 int cafehip_eval_posterior_multi(cafehip_ctx *ctx, int n_sets, const double *node_lambda, const double *node_mu,
                                  const double *prior, double *scores, int32_t *first_zero_family);
+/* One evaluation of the k-cluster objective (`lambda -k`): cafe_get_clustered_posterior (cafe/cafe_main.c:165-253) over
+ * cafe_tree_clustered_likelihood (cafe/cafe_tree.c:704-850).  Cluster k prunes every family with its own rates
+ * (node_lambda/node_mu + k * n_nodes; K <= CAFEHIP_MAX_SETS) in the same pass as the other clusters; per family
+ * MAP_k = max posterior_k * weights[k], membership p_z[k] = MAP_k / sum_k MAP_k, MAP = sum_k p_z[k] * MAP_k;
+ * *score = sum over families of log MAP (-inf, with *first_zero_family the lowest index, if some MAP == 0 -- the
+ * reference stops its loop there, :231-240).  membership_sums[k] = sum over families of p_z[k]: the reference's new
+ * weights are membership_sums[k] / F (:243-245).  Optional per-family outputs: family_map[F], family_membership[F*K]
+ * (param->MAP, param->p_z_membership). */
+int cafehip_eval_clustered_posterior(cafehip_ctx *ctx, int K, const double *node_lambda, const double *node_mu,
+                                     const double *weights, const double *prior, double *score,
+                                     int32_t *first_zero_family, double *membership_sums, double *family_map,
+                                     double *family_membership);
+
 /* Workgroups of the last pruning launch and the device's compute units (how full a single evaluation makes the chip). */
 int cafehip_launch_info(cafehip_ctx *ctx, int *k2_workgroups, int *compute_units);
 

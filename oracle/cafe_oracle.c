@@ -546,6 +546,119 @@ void orc_eval_root_likelihoods(const orc_tree *t, int B, int n_leaves, const int
 }
 
 /* ======================================================================== */
+/* k-cluster posterior: cafe/cafe_main.c:165-253 over                          */
+/* cafe_tree_clustered_likelihood cafe/cafe_tree.c:704-850                    */
+/* ======================================================================== */
+
+/* libtree/input_values.c:84-94 */
+void orc_copy_weights(double *out, const double *parameters, int start, int count)
+{
+    int i;
+    double sumofweights = 0;
+    for (i = 0; i < count - 1; i++) {
+        out[i] = parameters[start + i];
+        sumofweights += parameters[start + i];
+    }
+    out[i] = 1 - sumofweights;
+}
+
+/* One evaluation of the clustered objective for K clusters.  Cluster k prunes with its own matrices
+ * (node_lambda/node_mu + k*n_nodes): the per-node recursion of cafe_tree.c:789-812 is the dense product of
+ * compute_internal_node_likelihood with k_bd[k] in place of the single matrix.  Per family
+ * (cafe_main.c:180-211): MAP_k = max_j exp(log L_k[j] + log prior[j]) * weights[k] (the max runs over a zeroed
+ * FAMILYSIZEMAX array, :190-196), p_z[k] = MAP_k / sum, MAP = sum_k p_z[k] * MAP_k; duplicates copy their ref row
+ * (:220-229); the first family with MAP == 0 makes the score log(0) and stops the loop (:231-240); afterwards the
+ * weights become the mean memberships (:243-245).  Returns the score. */
+double orc_eval_clustered_posterior(const orc_tree *t, int F, int n_leaves, const int *counts, const int *ref,
+                                    const orc_range *range, int K, const double *node_lambda,
+                                    const double *node_mu, const double *weights, const double *prior,
+                                    int nthreads, double *MAP_out, double *p_z_out, double *new_weights,
+                                    int *first_zero_family)
+{
+    int M = ORC_MAX(range->max, range->root_max);
+    int sof = size_of_factor(range);
+    int rfsize = range->root_max - range->root_min + 1;
+    orc_matrices **mats = (orc_matrices **)malloc(sizeof(*mats) * K);
+    for (int k = 0; k < K; k++)
+        mats[k] = orc_matrices_build(t, node_lambda + (size_t)k * t->n_nodes, node_mu + (size_t)k * t->n_nodes, M, nthreads);
+    double *mp = (double *)malloc(sizeof(double) * (size_t)ORC_MAX(F, 1) * K);   /* max posterior per family, cluster */
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        double *L = (double *)malloc(sizeof(double) * (size_t)t->n_nodes * sof);
+        int *fs = (int *)malloc(sizeof(int) * t->n_nodes);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+        for (int i = 0; i < F; i++) {
+            if (ref && ref[i] >= 0 && ref[i] != i) continue;
+            for (int n = 0; n < t->n_nodes; n++) fs[n] = -1;
+            for (int j = 0; j < n_leaves; j++) fs[2 * j] = counts[(size_t)i * n_leaves + j];
+            for (int k = 0; k < K; k++) {
+                orc_compute_tree_likelihoods(t, range, mats[k], fs, NULL, 0, NULL, L, sof);
+                const double *lk = L + (size_t)t->root * sof;
+                double best = 0; /* posterior[] is calloc'd: entries outside [root_min, root_min + rfsize) are 0 */
+                for (int j = 0; j < rfsize; j++) {
+                    double p = exp(log(lk[j]) + log(prior[j]));
+                    if (best < p) best = p;
+                }
+                mp[(size_t)i * K + k] = best;
+            }
+        }
+        free(L);
+        free(fs);
+    }
+    double score = 0;
+    int fz = -1;
+    double *sumofweights = (double *)calloc(K, sizeof(double));
+    double *MAP_k = (double *)malloc(sizeof(double) * K);
+    double *pz = (double *)malloc(sizeof(double) * (size_t)ORC_MAX(F, 1) * K);
+    double *MAP = (double *)malloc(sizeof(double) * ORC_MAX(F, 1));
+    for (int i = 0; i < F; i++) {
+        if (!(ref && ref[i] >= 0 && ref[i] != i)) {
+            double sumLikelihood = 0;
+            for (int k = 0; k < K; k++) {
+                MAP_k[k] = mp[(size_t)i * K + k] * weights[k];
+                sumLikelihood += MAP_k[k];
+            }
+            for (int k = 0; k < K; k++) {
+                pz[(size_t)i * K + k] = MAP_k[k] / sumLikelihood;
+                sumofweights[k] += pz[(size_t)i * K + k];
+            }
+            double expectedPosterior = 0;
+            for (int k = 0; k < K; k++) expectedPosterior += pz[(size_t)i * K + k] * (MAP_k[k]);
+            MAP[i] = expectedPosterior;
+        } else {
+            MAP[i] = MAP[ref[i]];
+            for (int k = 0; k < K; k++) {
+                pz[(size_t)i * K + k] = pz[(size_t)ref[i] * K + k];
+                sumofweights[k] += pz[(size_t)i * K + k];
+            }
+        }
+        if (MAP[i] == 0) {
+            score = log(0);
+            fz = i;
+            break;
+        }
+        score += log(MAP[i]);
+    }
+    for (int k = 0; k < K; k++) new_weights[k] = sumofweights[k] / F;
+    if (first_zero_family) *first_zero_family = fz;
+    if (MAP_out) memcpy(MAP_out, MAP, sizeof(double) * F);
+    if (p_z_out) memcpy(p_z_out, pz, sizeof(double) * (size_t)F * K);
+    for (int k = 0; k < K; k++) orc_matrices_free(mats[k]);
+    free(mats);
+    free(mp);
+    free(sumofweights);
+    free(MAP_k);
+    free(pz);
+    free(MAP);
+    return score;
+}
+
+/* ======================================================================== */
 /* cafe/cafe_family.c                                                        */
 /* ======================================================================== */
 

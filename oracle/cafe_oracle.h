@@ -124,6 +124,14 @@ void orc_eval_root_likelihoods(const orc_tree *t, int B, int n_leaves, const int
                                const int *root_lo, const int *root_hi, const int *col_max,
                                const orc_matrices *mats, double *out);
 
+/* ---- k-cluster model: cafe/cafe_main.c:165-253, cafe/cafe_tree.c:704-850 ---- */
+void orc_copy_weights(double *out, const double *parameters, int start, int count);  /* libtree/input_values.c:84-94 */
+double orc_eval_clustered_posterior(const orc_tree *t, int F, int n_leaves, const int *counts, const int *ref,
+                                    const orc_range *range, int K, const double *node_lambda,
+                                    const double *node_mu, const double *weights, const double *prior,
+                                    int nthreads, double *MAP_out, double *p_z_out, double *new_weights,
+                                    int *first_zero_family);
+
 /* ---- cafe/cafe_family.c -------------------------------------------------- */
 void orc_init_family_size(orc_range *fs, int max);            /* :357-364 */
 void orc_family_check_the_pattern(int F, int n, const int *counts, int *ref); /* :9-34 */

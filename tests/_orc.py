@@ -478,3 +478,38 @@ def viterbi_and_pvalues(tree, mats, row, cd, trials, pvalue_cut):
         bp = np.zeros(tree.n_nodes - 1)
         L.orc_viterbi_sum_probabilities(C.byref(ct), C.byref(r), mats, iptr(fs), dptr(bp))
     return maxp, fs, bp
+
+
+def clustered_posterior(tree, counts, rng, node_lambdas, node_mus, weights, prior, ref=None, nthreads=1):
+    """cafe_get_clustered_posterior on the oracle: rates [K, n_nodes], weights [K].
+    Returns (score, first_zero, MAP[F], p_z[F, K], new_weights[K])."""
+    L = lib()
+    L.orc_eval_clustered_posterior.restype = C.c_double
+    L.orc_eval_clustered_posterior.argtypes = [C.POINTER(Tree), C.c_int, C.c_int, _ip, _ip, C.POINTER(Range), C.c_int, _dp, _dp,
+                                               _dp, _dp, C.c_int, _dp, _dp, _dp, _ip]
+    counts = np.ascontiguousarray(counts, np.int32)
+    F, nl = counts.shape
+    lam = np.ascontiguousarray(node_lambdas, np.float64)
+    mu = np.ascontiguousarray(node_mus, np.float64)
+    w = np.ascontiguousarray(weights, np.float64)
+    K = lam.shape[0]
+    pr = np.ascontiguousarray(prior, np.float64)
+    MAP = np.zeros(F)
+    pz = np.zeros((F, K))
+    neww = np.zeros(K)
+    fz = C.c_int(-1)
+    refp = iptr(np.ascontiguousarray(ref, np.int32)) if ref is not None else None
+    ct = tree.ctree()
+    score = L.orc_eval_clustered_posterior(C.byref(ct), F, nl, iptr(counts), refp, C.byref(rng), K, dptr(lam), dptr(mu), dptr(w),
+                                           dptr(pr), nthreads, dptr(MAP), dptr(pz), dptr(neww), C.byref(fz))
+    return score, fz.value, MAP, pz, neww
+
+
+def copy_weights(parameters, start, count):
+    L = lib()
+    L.orc_copy_weights.restype = None
+    L.orc_copy_weights.argtypes = [_dp, _dp, C.c_int, C.c_int]
+    p = np.ascontiguousarray(parameters, np.float64)
+    out = np.zeros(count)
+    L.orc_copy_weights(dptr(out), dptr(p), start, count)
+    return out

@@ -1,0 +1,119 @@
+"""k-cluster model on the GPU (cafehip_eval_clustered_posterior, `lambda -k`) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _orc as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+NEWICK = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+
+
+def _setup(extra_rows=None):
+    import cafe_amd
+    sp, ids, counts = O.load_family_table(os.path.join(GOLD, "example_data.tab"))
+    t = O.PyTree(NEWICK)
+    counts = O.reorder_to_tree(sp, counts, t)
+    if extra_rows is not None:
+        counts = np.vstack([counts, extra_rows(counts)])
+    rng = O.range_from_max(int(counts.max()))
+    prior = O.prior_poisson(1000, rng.root_min, 9.442907)
+    eng = cafe_amd.Engine(0)
+    eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+    eng.set_families(counts, cafe_amd.FamilySizeRange(rng.min, rng.max, rng.root_min, rng.root_max))
+    return eng, t, counts, rng, prior
+
+
+@pytest.mark.parametrize("lams,w", [([0.0017, 0.009], [0.3, 0.7]), ([0.0, 0.004, 0.011], [0.2, 0.5, 0.3]),
+                                    ([0.002], [1.0]), ([0.001, 0.002, 0.003, 0.004, 0.005, 0.006, 0.007, 0.008], [0.125] * 8)])
+def test_clustered_posterior_matches_the_oracle(lams, w):
+    eng, t, counts, rng, prior = _setup(lambda c: c[:5])     # five duplicate rows at the end
+    lam = np.array([np.full(t.n_nodes, x) for x in lams])
+    mu = np.full_like(lam, -1.0)
+    so, fzo, MAPo, pzo, newo = O.clustered_posterior(t, counts, rng, lam, mu, w, prior)
+    s, fz, memb, MAP, pz = eng.clustered_posterior(lam, mu, w, prior, per_family=True)
+    assert fz == fzo == -1
+    assert np.max(np.abs(MAP - MAPo) / MAPo) < 1e-9 and np.max(np.abs(pz - pzo)) < 1e-9
+    assert abs(s - so) <= 1e-11 * abs(so)
+    assert np.allclose(memb / len(counts), newo, rtol=1e-11)
+    eng.close()
+
+
+def test_zero_family_gives_minus_infinity_and_its_index():
+    # a rate with lambda * t >= 1 on a branch zeroes that matrix: every cluster then has max posterior 0
+    eng, t, counts, rng, prior = _setup()
+    lam = np.array([np.full(t.n_nodes, 0.2), np.full(t.n_nodes, 0.3)])
+    mu = np.full_like(lam, -1.0)
+    so, fzo, _, _, _ = O.clustered_posterior(t, counts, rng, lam, mu, [0.5, 0.5], prior)
+    s, fz, memb = eng.clustered_posterior(lam, mu, [0.5, 0.5], prior)
+    assert np.isinf(so) and so < 0 and np.isinf(s) and s < 0 and fz == fzo
+    eng.close()
+
+
+def _shell(lines):
+    from cafe_amd.shell import CafeShell
+    sh = CafeShell(0, os.devnull)
+    for l in lines:
+        sh.dispatch(l)
+    res = (np.array(sh.params), sh.score, sh.iterations, sh.evaluations, sh.trace())
+    sh.close()
+    return res
+
+
+def test_lambda_k_set_form_scores_like_the_oracle():
+    base = ["seed 10", "load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"), "tree " + NEWICK]
+    params, score, it, ev, tr = _shell(base + ["lambda -k 2 -l 0.0017 0.009 -p 0.3 0.7"])
+    assert list(params) == [0.0017, 0.009, 0.3] and ev == 1
+    eng, t, counts, rng, _ = _setup()
+    eng.close()
+    # the driver's prior is the empirical Poisson fit: recover it from a plain lambda command's trace is not needed --
+    # the clustered score under the SAME fitted prior is compared through the one-cluster identity instead
+    p1, s1, _, _, _ = _shell(base + ["lambda -l 0.0017 -score"])
+    pk, sk, _, _, _ = _shell(base + ["lambda -k 1 -l 0.0017 -p 1"])
+    assert abs(sk - s1) <= 1e-10 * abs(s1)          # K = 1, weight 1: the plain posterior (cafe_main.c:196-213)
+    assert np.isfinite(score) and score > 0
+
+
+@pytest.mark.parametrize("command", ["lambda -s -k 2", "lambda -s -k 2 -f", "lambda -s -k 2 -t (((1,1)1,(2,2)2)2,2)"])
+def test_lambda_k_search_objective_calls_match_the_oracle(command):
+    base = ["seed 10", "load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"), "tree " + NEWICK]
+    params, score, it, ev, tr = _shell(base + [command])
+    K, fix = 2, 1 if " -f" in command else 0
+    n_classes = 2 if "-t" in command else 1
+    n_lam = n_classes * (K - fix)
+    assert len(params) == n_lam + K - 1 and ev == len(tr) and ev > 20
+    fin = tr[:, -1][np.isfinite(tr[:, -1])]          # the trace holds +score (sum of log MAP); the search minimises -score
+    assert np.isfinite(score) and abs(score - (-fin).min()) < 1e-6 * abs(score)
+    # the driver fits its own Poisson prior; the oracle gets the same one through the printed lambda_p
+    from cafe_amd.shell import CafeShell
+    sh = CafeShell(0, os.devnull)
+    for l in base + ["lambda -l 0.002"]:
+        sh.dispatch(l)
+    lam_p = sh.poisson_lambda
+    sh.close()
+    sp, ids, counts = O.load_family_table(os.path.join(GOLD, "example_data.tab"))
+    t = O.PyTree(NEWICK)
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    prior = O.prior_poisson(1000, rng.root_min, lam_p)
+    cls = np.zeros(t.n_nodes, int)
+    if n_classes == 2:
+        # (((1,1)1,(2,2)2)2,2): class per node in nlist order, from the lambda tree text
+        lt = O.PyTree("(((a:1,b:1)c:1,(d:1,e:1)f:1)g:1,h:1)")
+        labels = {"a": 0, "b": 0, "c": 0, "d": 1, "e": 1, "f": 1, "g": 1, "h": 1}
+        cls = np.array([labels.get(n, 0) for n in lt.name])
+    rows = [r for r in list(tr[:6]) + list(tr[-6:]) if np.all(r[:-1] >= 0)]
+    assert rows
+    for r in rows:
+        x, got = r[:-1], r[-1]
+        lam = np.zeros((K, t.n_nodes))
+        for k in range(K):
+            for i in range(t.n_nodes):
+                lam[k, i] = (0.0 if k == 0 else x[cls[i] * (K - 1) + k - 1]) if fix else x[cls[i] * K + k]
+        w = O.copy_weights(x, n_lam, K)
+        so, fzo, _, _, _ = O.clustered_posterior(t, counts, rng, lam, np.full_like(lam, -1.0), w, prior)
+        assert abs(got - so) <= 1e-9 * max(1.0, abs(so)), (x, got, so)
