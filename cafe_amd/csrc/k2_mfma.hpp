@@ -10,7 +10,8 @@
 //
 // One workgroup owns NF = 16*NFT families and walks the whole tree for them:
 //   * ONE node-vector buffer Lbuf[NF][LDv] in LDS; results that are not consumed by the
-//     next step are parked in a per-workgroup global scratch region (MfmaSchedule);
+//     next step are parked (MfmaSchedule) in further LDS buffers or in a slot of a global scratch
+//     that the workgroup owns while it runs (k2_acquire_park_slot);
 //   * waves are arranged Wf x Wr: wave (wf, wr) owns family tiles [wf*NFT_W, +NFT_W) and an even
 //     share (<= NRT_W) of the step's row tiles: NFT_W*NRT_W accumulator tiles (4 f64 per lane each);
 //   * leaf children are column gathers PT[count][row] in the D layout; the Hadamard

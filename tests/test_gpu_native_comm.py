@@ -73,6 +73,22 @@ def test_report_through_the_communicator_equals_the_golden_file(tmp_path):
     assert got[:1] + got[2:] == exp[:1] + exp[2:]
 
 
+def test_lhtest_through_the_communicator_equals_the_plain_run(tmp_path):
+    # the advisor's round-1 finding: lhtest loads a new table per file, which left the exchange wired for the
+    # previous one; with the native communicator every `load` re-wires it
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+    sim = tmp_path / "sim"
+    sim.mkdir()
+    base = ["seed 10", "load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"), "tree " + newick, "lambda -s",
+            "genfamily %s/rnd -t 2" % sim]
+    outs = []
+    for comm in (False, True):
+        out = str(tmp_path / ("lh_%d.txt" % comm))
+        _run(base + ["lhtest -d %s -t (((1,1)1,(2,2)2)2,2) -l 0.0107527 -o %s" % (sim, out)], comm)
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and outs[0].count("\n") == 2
+
+
 def test_command_line_front_end_runs_sharded_without_python(tmp_path, test1_table):
     g = TR["test1"]
     script = tmp_path / "run.sh"
