@@ -1142,7 +1142,10 @@ struct cafehost_session {
         lambda_tree = lt;
         have_lambda_tree = true;
         num_lambdas = (int)seen.size();
-        if (!quiet) printf("The number of lambdas is %d\n", num_lambdas);
+        if (!quiet) {
+            printf("The number of lambdas is %d\n", num_lambdas);
+            fflush(stdout);
+        }
         log("Lambda Tree: %s\n", text.c_str());
     }
 
@@ -1330,6 +1333,7 @@ struct cafehost_session {
             printf("p : %s\n", join_double(k_weights.data(), K).c_str());
             printf("Score: %f\n", score);
             printf(".");
+            fflush(stdout);
         }
         return -score;
     }
@@ -2300,6 +2304,7 @@ struct cafehost_session {
                 if (species_index[s_] >= 0) counts[(size_t)i * nl + species_index[s_] / 2] = fam.counts[(size_t)i * ns + s_];
         std::vector<int32_t> sizes((size_t)std::max(F, 1) * n);
         printf("Viterbi\n");
+        fflush(stdout);
         if (F) hip_check(cafehip_viterbi(ctx, F, counts.data(), lo.data(), hi.data(), cm.data(), sizes.data()));
         root_dist.assign(range.root_max - range.root_min + 2, 0);
         for (int i = 0; i < F; ++i) {

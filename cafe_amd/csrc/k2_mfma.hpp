@@ -177,6 +177,9 @@ __device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const i
 #ifndef CAFE_K2_DEPTH
 #define CAFE_K2_DEPTH 3
 #endif
+#ifndef CAFE_K2_DEPTH4   // the 4x4x4 kernel: 2 waves per SIMD at most, so a deeper ring
+#define CAFE_K2_DEPTH4 (CAFE_K2_DEPTH >= 2 ? 4 : CAFE_K2_DEPTH)
+#endif
 #ifndef CAFE_K2_INTERLEAVE
 #define CAFE_K2_INTERLEAVE 1
 #endif
@@ -800,8 +803,8 @@ template <int G, int NRT_W, int NT>
 __device__ __forceinline__ void k2_edge4(const double* __restrict__ bp, const int (&boff)[NRT_W], size_t kstride,
                                          const double* ap4, int LDv, int ksteps, double (&acc)[G][NRT_W])
 {
-#if CAFE_K2_DEPTH >= 2
-    mfma4_edge_p<G, NRT_W, NT, CAFE_K2_DEPTH>(bp, boff, kstride, ap4, LDv, ksteps, acc);
+#if CAFE_K2_DEPTH4 >= 2
+    mfma4_edge_p<G, NRT_W, NT, CAFE_K2_DEPTH4>(bp, boff, kstride, ap4, LDv, ksteps, acc);
 #else
     mfma4_edge<G, NRT_W, NT>(bp, boff, kstride, ap4, LDv, ksteps, acc);
 #endif
