@@ -210,13 +210,13 @@ def main():
         torch.cuda.synchronize()
 
     # engine priming (not part of the W warm-up steps the caller asked for): the first launches after set-up
-    # allocate the scratch buffers, measure the K2 wave grids (~15 evaluations) and run while the GPU is still
-    # leaving its idle power state -- at least 30 evaluations and at least 0.25 s of them
+    # allocate the scratch buffers, measure the K2 wave grids (up to ~30 evaluations) and run while the GPU is still
+    # leaving its idle power state -- at least 40 evaluations and at least 0.25 s of them
     # (with several ranks every step contains a collective, so the count must be the same everywhere: fixed)
     PRIMING = 0
     t_prime = time.perf_counter()
     n_prime_multi = 1000 if F_local <= 20000 else 60
-    while (PRIMING < n_prime_multi) if multi else (PRIMING < 30 or time.perf_counter() - t_prime < 0.25):
+    while (PRIMING < n_prime_multi) if multi else (PRIMING < 40 or time.perf_counter() - t_prime < 0.25):
         one_step(PRIMING)
         PRIMING += 1
     last = None

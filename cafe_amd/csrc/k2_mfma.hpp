@@ -100,192 +100,181 @@ __global__ __launch_bounds__(256) void k1e_fold_error(const double* __restrict__
     PTfold[(size_t)key * KP * LD + (size_t)cnt * LD + s] = v;
 }
 
-// One edge: acc[i][j] += L-tile(i) x PT-tile(j) over all k-steps, operands double-buffered in
-// registers one k-step ahead of the MFMAs.
-template <int NFT_W, int NRT_W, int NT>   // NT <= NRT_W live row tiles (see mfma4_edge)
-__device__ __forceinline__ void mfma_edge(const double* __restrict__ bp, const int (&boff)[NRT_W],
-                                          size_t kstride, const double* ap, int astride, int ksteps,
-                                          cafe_d4 (&acc)[NFT_W][NRT_W])
-{
-    double a0[NFT_W], a1[NFT_W], b0[NT], b1[NT];
-#pragma unroll
-    for (int i = 0; i < NFT_W; ++i) a0[i] = ap[i * astride];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) b0[j] = bp[boff[j]];
-    int ks = 0;
-    for (; ks + 2 < ksteps; ks += 2) {
-        const double* bp1 = bp + (size_t)(ks + 1) * kstride;
-        const double* ap1 = ap + (ks + 1) * 4;
-#pragma unroll
-        for (int i = 0; i < NFT_W; ++i) a1[i] = ap1[i * astride];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b1[j] = bp1[boff[j]];
-#pragma unroll
-        for (int i = 0; i < NFT_W; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
-        const double* bp2 = bp + (size_t)(ks + 2) * kstride;
-        const double* ap2 = ap + (ks + 2) * 4;
-#pragma unroll
-        for (int i = 0; i < NFT_W; ++i) a0[i] = ap2[i * astride];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b0[j] = bp2[boff[j]];
-#pragma unroll
-        for (int i = 0; i < NFT_W; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
-    }
-    // one or two k-steps left: no loads are issued that nobody consumes (they would still have to be waited for
-    // before the result can be stored)
-    if (ks + 2 == ksteps) {
-        const double* bp1 = bp + (size_t)(ks + 1) * kstride;
-        const double* ap1 = ap + (ks + 1) * 4;
-#pragma unroll
-        for (int i = 0; i < NFT_W; ++i) a1[i] = ap1[i * astride];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b1[j] = bp1[boff[j]];
-    }
-#pragma unroll
-    for (int i = 0; i < NFT_W; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
-    if (ks + 2 == ksteps) {
-#pragma unroll
-        for (int i = 0; i < NFT_W; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------
-// Explicitly software-pipelined edge product (CAFE_K2_DEPTH = D >= 2, the default).
-// hipcc schedules the two-stage source loop above (mfma_edge / mfma4_edge) into
+// One edge product: acc[i][j] += node-vector tile(i) x matrix tile(j) over all k-steps, explicitly software-
+// pipelined.  Left to itself hipcc schedules a two-stage source loop into
 //     [3 B loads for k+1] [15 MFMAs of k] [3 B loads for k+2, 5 ds_read2 for k+1 AND k+2] wait lgkmcnt [15 MFMAs of k+1]
-// i.e. the LDS latency of the A operand is exposed once per two k-steps and the B operand has ONE k-step of
-// MFMAs (240 cycles alone, ~400 shared with the SIMD's other wave) to cover an L2 round trip of ~500 cycles
-// (disassembly of k2_prune_mfma4<5,3>, round 2).  Here both operands live in rings of D k-steps: region k
-// (fenced by sched_barrier, so no load can sink below or hoist above it) issues the loads of k-step k + D - 1
-// and the matrix instructions of k-step k, so every operand has D - 1 whole regions to arrive wherever the
-// in-region scheduler puts its load.  Loads past the last k-step are clamped to it (valid addresses, values
-// unused).  Same instructions on the same operands in the same order per accumulator: bit-identical results.
+// i.e. the LDS latency of the node-vector operand is exposed once per two k-steps and the matrix operand has ONE
+// k-step of MFMAs (240 cycles alone, ~400 shared with the SIMD's other wave) to cover an L2 round trip of ~500
+// cycles (disassembly of k2_prune_mfma4<5,3>, round 2).  Here both operands live in rings of D
+// k-steps (D = CAFE_K2_DEPTH16 / CAFE_K2_DEPTH4): region k (fenced by sched_barrier, so no load can sink below or hoist above it) issues the loads of
+// k-step k + D - 1 and the matrix instructions of k-step k, so every operand has D - 1 whole regions to arrive
+// wherever the in-region scheduler puts its load.  Same instructions on the same operands in the same order per
+// accumulator as the plain loop: bit-identical results.
 // ---------------------------------------------------------------------------------------------------
-#ifndef CAFE_K2_DEPTH
-#define CAFE_K2_DEPTH 3
+// Depth: the 16x16x4 kernel's regions are long (64 cycles per matrix instruction, 3-4 waves per SIMD), one region
+// of lookahead covers the L2 round trip and the smaller rings keep a fourth wave resident (cfg 3: 6.63 -> 6.53 ms);
+// the 4x4x4 kernel (16-cycle instructions, 2 waves per SIMD) needs two (cfg 2: 0.180 -> 0.164 ms).
+#ifndef CAFE_K2_DEPTH16
+#define CAFE_K2_DEPTH16 2
 #endif
-#ifndef CAFE_K2_DEPTH4   // the 4x4x4 kernel: 2 waves per SIMD at most, so a deeper ring
-#define CAFE_K2_DEPTH4 (CAFE_K2_DEPTH >= 2 ? 4 : CAFE_K2_DEPTH)
+#ifndef CAFE_K2_DEPTH4
+#define CAFE_K2_DEPTH4 3
 #endif
+static_assert(CAFE_K2_DEPTH16 >= 2 && CAFE_K2_DEPTH4 >= 2, "the operand rings need at least two slots");
 #ifndef CAFE_K2_INTERLEAVE
 #define CAFE_K2_INTERLEAVE 1
-#endif
-#ifndef CAFE_K2_ABLATE
-#define CAFE_K2_ABLATE 0   // debug timing builds ONLY (wrong results): bit 0 = no B-operand loads in the k loop, bit 1 = no A loads
 #endif
 
 // inside a region: one operand load, then its share of the matrix instructions, ... so that the loads issue in
 // the shadow of this wave's own MFMAs instead of ahead of them (sched_group_barrier: 0x20 VMEM read, 0x100 DS
-// read, 0x8 MFMA)
-template <int N_VMEM, int N_DS, int N_MFMA>
+// read, 0x8 MFMA).  DS_FIRST (the 16x16 kernel, depth 2): the node-vector (LDS) reads lead, because every matrix
+// instruction of the NEXT region needs them while a matrix-operand load feeds one column of instructions -- and a
+// read placed after the region's last matrix instruction lets the register allocator fold the two ring slots into
+// one register, i.e. wait for the LDS round trip at the top of every region (disassembly).  The 4x4 kernel (depth
+// 3, two regions of slack either way) measures 4 % faster with the global loads leading (cfg 2: 0.164 vs 0.171 ms).
+template <int N_VMEM, int N_DS, int N_MFMA, bool DS_FIRST>
 __device__ __forceinline__ void k2_region_pattern()
 {
 #if CAFE_K2_INTERLEAVE
     constexpr int n_loads = N_VMEM + N_DS;
     constexpr int q = N_MFMA / n_loads > 0 ? N_MFMA / n_loads : 1;
+    constexpr int n_paired = N_MFMA < n_loads ? N_MFMA : n_loads;   // loads that get a matrix instruction behind them
+    constexpr int n_first = DS_FIRST ? N_DS : N_VMEM;
 #pragma unroll
-    for (int i = 0; i < N_VMEM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x8, q, 0);
+    for (int i = 0; i < n_loads; ++i) {
+        if ((i < n_first) == DS_FIRST) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        if (i < n_paired) __builtin_amdgcn_sched_group_barrier(0x8, q, 0);
     }
-#pragma unroll
-    for (int i = 0; i < N_DS; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x8, q, 0);
-    }
-    if constexpr (N_MFMA - q * n_loads > 0) __builtin_amdgcn_sched_group_barrier(0x8, N_MFMA - q * n_loads, 0);
+    if constexpr (N_MFMA - q * n_paired > 0) __builtin_amdgcn_sched_group_barrier(0x8, N_MFMA - q * n_paired, 0);
 #endif
 }
 
-template <int NFT_W, int NRT_W, int NT, int D>
-__device__ __forceinline__ void mfma_edge_p(const double* __restrict__ bp, const int (&boff)[NRT_W],
-                                            size_t kstride, const double* ap, int astride, int ksteps,
-                                            cafe_d4 (&acc)[NFT_W][NRT_W])
+// The matrix operand's address is split into a WAVE-UNIFORM base (scalar registers: matrix + k-step row block,
+// advanced by one scalar add per region) and per-lane 32-bit byte offsets that do not change during a product
+// (lane's k row and matrix row + the wave's row tiles), i.e. `global_load_dwordx2 v, v_off, s[base:base+1]`;
+// the node-vector operand uses one LDS address per family group, bumped once per D regions, with the k-step as
+// the instruction's immediate offset.  A region is then [NT global loads, G (NFT_W) LDS reads, 2 scalar adds,
+// the matrix instructions]: the 64-bit multiply-adds per load that a `base[k * stride + off]` form costs (10
+// scalar + 9 vector instructions per region, disassembly of round 2's first version) competed with the matrix
+// instructions for the wave's single issue slot per cycle.  The last D - 1 regions have no loads at all.
+// (explicit address spaces: a pointer rebuilt from integers, or carried through the loop in an array, would
+// otherwise degrade every operand load to a flat_load)
+typedef const double __attribute__((address_space(1))) * k2_gptr;
+typedef const char __attribute__((address_space(1))) * k2_gbytes;
+typedef const double __attribute__((address_space(3))) * k2_lptr;
+
+// keeps the 32-bit lane offset a 32-bit value at the load (hoisted out of the loop and widened there, it would
+// cost a 64-bit vector add per load instead of the scalar-base addressing mode)
+__device__ __forceinline__ unsigned k2_opaque(unsigned v)
 {
-    double aq[D][NFT_W], bq[D][NT];
-    const int klast = ksteps - 1;
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d) {
-        const int kk = min(d, klast);
-#pragma unroll
-        for (int i = 0; i < NFT_W; ++i) aq[d][i] = ap[kk * 4 + i * astride];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bq[d][j] = bp[(size_t)kk * kstride + boff[j]];
-    }
-    int k0 = 0;
-#define CAFE_REGION16(u, k)                                                                                    \
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ k2_gbytes k2_uniform(const double* p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (k2_gbytes)(((unsigned long long)hi << 32) | lo);
+}
+
+// The k loop runs D regions per trip with compile-time ring slots.  ksteps - (D - 1) regions carry loads; their
+// count modulo D is absorbed by a partial FIRST trip (phase p: regions p..D-1 only, the rings filled from slot p),
+// so that the loop always ends on a trip boundary and the D - 1 load-free regions that drain the rings have fixed
+// slots.  NT <= NRT_W: the wave's live row tiles; columns NT.. of acc are left untouched (a wave that was dealt one
+// tile fewer than the widest must not burn matrix-pipe cycles on a dummy column: the SIMD's other waves can use them).
+#define CAFE_K2_EDGE_BODY(NA, MFMA_BUILTIN)                                                                    \
+    double aq[D][NA], bq[D][NT];                                                                               \
+    k2_gbytes bk = sb; /* row block of the next k-step to load (wave-uniform) */                               \
+    unsigned vo[NT];                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) vo[j] = k2_opaque(voff[j]);                                 \
+    if (ksteps < D - 1) { /* (matrix side <= 4: not a real table, kept correct) */                             \
+        for (int k = 0; k < ksteps; ++k) {                                                                     \
+            CAFE_K2_LOAD(0, k)                                                                                 \
+            CAFE_K2_MFMA(0)                                                                                    \
+        }                                                                                                      \
+        return;                                                                                                \
+    }                                                                                                          \
+    const int n_main = ksteps - (D - 1);                                                                       \
+    const int full = n_main / D, rem = n_main - full * D;                                                      \
+    const int p = rem ? D - rem : 0;                                                                           \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) pa[i] -= 4 * p;                                             \
+    _Pragma("unroll") for (int pp = 0; pp < D; ++pp)                                                           \
+        if (p == pp) {                                                                                         \
+            _Pragma("unroll") for (int d = 0; d < D - 1; ++d) CAFE_K2_LOAD((pp + d) % D, pp + d)               \
+        }                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    if (p > 0) {                                                                                               \
+        _Pragma("unroll") for (int u = 1; u < D; ++u)                                                          \
+            if (u >= p) CAFE_K2_REGION_L(u)                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) pa[i] += 4 * D;                                         \
+    }                                                                                                          \
+    for (int it = 0; it < full; ++it) {                                                                        \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) vo[j] = k2_opaque(voff[j]);                             \
+        _Pragma("unroll") for (int u = 0; u < D; ++u) CAFE_K2_REGION_L(u)                                      \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) pa[i] += 4 * D;                                         \
+    }                                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < D - 1; ++u) CAFE_K2_REGION_N(u)
+
+#define CAFE_K2_LOAD(slot, koff)                                                                               \
     {                                                                                                          \
-        const int kn = min((k) + D - 1, klast);                                                                \
-        if (!(CAFE_K2_ABLATE & 1)) { _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[((u) + D - 1) % D][j] = bp[(size_t)kn * kstride + boff[j]]; } \
-        if (!(CAFE_K2_ABLATE & 2)) { _Pragma("unroll") for (int i = 0; i < NFT_W; ++i) aq[((u) + D - 1) % D][i] = ap[kn * 4 + i * astride]; } \
-        _Pragma("unroll") for (int i = 0; i < NFT_W; ++i)                                                      \
-            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[(u) % D][i], bq[(u) % D][j], acc[i][j], 0, 0, 0); \
-        k2_region_pattern<NT, NFT_W, NFT_W * NT>();                                                            \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[slot][j] = *(k2_gptr)(bk + vo[j]);                   \
+        bk += kstride_bytes;                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < NA_; ++i) aq[slot][i] = pa[i][(koff) * 4];                       \
+    }
+#define CAFE_K2_REGION_L(u)                                                                                    \
+    {                                                                                                          \
+        CAFE_K2_LOAD(((u) + D - 1) % D, (u) + D - 1)                                                           \
+        CAFE_K2_MFMA((u) % D)                                                                                  \
+        k2_region_pattern<NT, NA_, NA_ * NT, DS_FIRST_>();                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
-    __builtin_amdgcn_sched_barrier(0);
-    for (; k0 + D <= ksteps; k0 += D) {
-#pragma unroll
-        for (int u = 0; u < D; ++u) CAFE_REGION16(u, k0 + u)
+#define CAFE_K2_REGION_N(u)                                                                                    \
+    {                                                                                                          \
+        CAFE_K2_MFMA((u) % D)                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
+
+template <int NFT_W, int NRT_W, int NT, int D>
+__device__ __forceinline__ void mfma_edge_p(k2_gbytes sb, const unsigned (&voff)[NRT_W], unsigned kstride_bytes,
+                                            const double* ap, int astride, int ksteps, cafe_d4 (&acc)[NFT_W][NRT_W])
+{
+    constexpr int NA_ = NFT_W;
+    constexpr bool DS_FIRST_ = true;
+    k2_lptr pa[NFT_W];
 #pragma unroll
-    for (int u = 0; u < D - 1; ++u)
-        if (k0 + u < ksteps) CAFE_REGION16(u, k0 + u)
-#undef CAFE_REGION16
+    for (int i = 0; i < NFT_W; ++i) pa[i] = (k2_lptr)ap + i * astride;
+#define CAFE_K2_MFMA(slot)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NFT_W; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                         \
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[slot][i], bq[slot][j], acc[i][j], 0, 0, 0);
+    CAFE_K2_EDGE_BODY(NFT_W, 16)
+#undef CAFE_K2_MFMA
 }
 
 template <int G, int NRT_W, int NT, int D>
-__device__ __forceinline__ void mfma4_edge_p(const double* __restrict__ bp, const int (&boff)[NRT_W],
-                                             size_t kstride, const double* ap4, int LDv, int ksteps,
-                                             double (&acc)[G][NRT_W])
+__device__ __forceinline__ void mfma4_edge_p(k2_gbytes sb, const unsigned (&voff)[NRT_W], unsigned kstride_bytes,
+                                             const double* ap4, int LDv, int ksteps, double (&acc)[G][NRT_W])
 {
-    double aq[D][G], bq[D][NT];
-    const int klast = ksteps - 1;
+    constexpr int NA_ = G;
+    constexpr bool DS_FIRST_ = false;
+    k2_lptr pa[G];
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) {
-        const int kk = min(d, klast);
-#pragma unroll
-        for (int g = 0; g < G; ++g) aq[d][g] = ap4[kk * 4 + (size_t)(4 * g) * LDv];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bq[d][j] = bp[(size_t)kk * kstride + boff[j]];
-    }
-    int k0 = 0;
-#define CAFE_REGION4(u, k)                                                                                     \
-    {                                                                                                          \
-        const int kn = min((k) + D - 1, klast);                                                                \
-        if (!(CAFE_K2_ABLATE & 1)) { _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[((u) + D - 1) % D][j] = bp[(size_t)kn * kstride + boff[j]]; } \
-        if (!(CAFE_K2_ABLATE & 2)) { _Pragma("unroll") for (int g = 0; g < G; ++g) aq[((u) + D - 1) % D][g] = ap4[kn * 4 + (size_t)(4 * g) * LDv]; } \
-        _Pragma("unroll") for (int g = 0; g < G; ++g)                                                          \
-            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                     \
-                acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(aq[(u) % D][g], bq[(u) % D][j], acc[g][j], 0, 0, 0); \
-        k2_region_pattern<NT, G, G * NT>();                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    for (; k0 + D <= ksteps; k0 += D) {
-#pragma unroll
-        for (int u = 0; u < D; ++u) CAFE_REGION4(u, k0 + u)
-    }
-#pragma unroll
-    for (int u = 0; u < D - 1; ++u)
-        if (k0 + u < ksteps) CAFE_REGION4(u, k0 + u)
-#undef CAFE_REGION4
+    for (int g = 0; g < G; ++g) pa[g] = (k2_lptr)ap4 + (4 * g) * LDv;
+#define CAFE_K2_MFMA(slot)                                                                                     \
+    _Pragma("unroll") for (int g = 0; g < G; ++g)                                                              \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                         \
+            acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(aq[slot][g], bq[slot][j], acc[g][j], 0, 0, 0);
+    CAFE_K2_EDGE_BODY(G, 4)
+#undef CAFE_K2_MFMA
 }
-
+#undef CAFE_K2_EDGE_BODY
+#undef CAFE_K2_LOAD
+#undef CAFE_K2_REGION_L
+#undef CAFE_K2_REGION_N
 
 
 // ---------------------------------------------------------------------------------------------------
@@ -495,17 +484,6 @@ __device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* L
     else k2_epilogue_impl<false>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
 }
 
-template <int NFT_W, int NRT_W, int NT>
-__device__ __forceinline__ void k2_edge16(const double* __restrict__ bp, const int (&boff)[NRT_W], size_t kstride,
-                                          const double* ap, int astride, int ksteps, cafe_d4 (&acc)[NFT_W][NRT_W])
-{
-#if CAFE_K2_DEPTH >= 2
-    mfma_edge_p<NFT_W, NRT_W, NT, CAFE_K2_DEPTH>(bp, boff, kstride, ap, astride, ksteps, acc);
-#else
-    mfma_edge<NFT_W, NRT_W, NT>(bp, boff, kstride, ap, astride, ksteps, acc);
-#endif
-}
-
 template <int NFT_W, int NRT_W>
 __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 {
@@ -643,19 +621,21 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 #pragma unroll
                     for (int j = 0; j < NRT_W; ++j) fac[i][j] = cafe_d4{0.0, 0.0, 0.0, 0.0};
                 if (wave_active) {
-                    int boff[NRT_W];
+                    // matrix operand: uniform base + this lane's (k row, matrix row) and the wave's row tiles
+                    unsigned voff[NRT_W];
 #pragma unroll
-                    for (int j = 0; j < NRT_W; ++j)
-                        boff[j] = ((j < ntile) ? (rt0 + j) : rt0) * 16;  // inactive tiles re-read tile rt0
-                    const double* bp = PTe + (size_t)lk * a.LD + li;
+                    for (int j = 0; j < NRT_W; ++j)   // inactive tiles re-read tile rt0
+                        voff[j] = (unsigned)(lk * a.LD + li + ((j < ntile) ? (rt0 + j) : rt0) * 16) * 8u;
+                    const k2_gbytes sb = k2_uniform(PTe);
                     const double* ap = Lsrc + (size_t)(ft0 * 16 + li) * a.LDv + lk;
+                    const unsigned kstride_bytes = 32u * (unsigned)a.LD;
                     if constexpr (NRT_W > 1) {
                         if (ntile == NRT_W - 1)
-                            k2_edge16<NFT_W, NRT_W, NRT_W - 1>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                            mfma_edge_p<NFT_W, NRT_W, NRT_W - 1, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
                         else
-                            k2_edge16<NFT_W, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                            mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
                     } else {
-                        k2_edge16<NFT_W, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap, 16 * a.LDv, a.ksteps, fac);
+                        mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
                     }
                 }
             }
@@ -736,80 +716,6 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 // Y[fam_base + 4g + (l>>4)][row0 + (l&15)]: the same walk, gathers and stores as k2_prune_mfma with
 // (i, r) flattened to g = 4i + r.
 // ====================================================================================
-// NT <= NRT_W: the wave's live row tiles; columns NT.. of acc are left untouched (a wave that was dealt one tile
-// fewer than the widest must not burn matrix-pipe cycles on a dummy column: the other workgroup's wave on the
-// same SIMD can use them).
-template <int G, int NRT_W, int NT>
-__device__ __forceinline__ void mfma4_edge(const double* __restrict__ bp, const int (&boff)[NRT_W],
-                                           size_t kstride, const double* ap4, int LDv, int ksteps,
-                                           double (&acc)[G][NRT_W])
-{
-    double a0[G], a1[G], b0[NT], b1[NT];
-#pragma unroll
-    for (int g = 0; g < G; ++g) a0[g] = ap4[(size_t)(4 * g) * LDv];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) b0[j] = bp[boff[j]];
-    int ks = 0;
-    for (; ks + 2 < ksteps; ks += 2) {
-        const double* bp1 = bp + (size_t)(ks + 1) * kstride;
-        const double* ap1 = ap4 + (ks + 1) * 4;
-#pragma unroll
-        for (int g = 0; g < G; ++g) a1[g] = ap1[(size_t)(4 * g) * LDv];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b1[j] = bp1[boff[j]];
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[g], b0[j], acc[g][j], 0, 0, 0);
-        const double* bp2 = bp + (size_t)(ks + 2) * kstride;
-        const double* ap2 = ap4 + (ks + 2) * 4;
-#pragma unroll
-        for (int g = 0; g < G; ++g) a0[g] = ap2[(size_t)(4 * g) * LDv];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b0[j] = bp2[boff[j]];
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[g], b1[j], acc[g][j], 0, 0, 0);
-    }
-    // one or two k-steps left: no loads are issued that nobody consumes (they would still have to be waited for
-    // before the result can be stored)
-    if (ks + 2 == ksteps) {
-        const double* bp1 = bp + (size_t)(ks + 1) * kstride;
-        const double* ap1 = ap4 + (ks + 1) * 4;
-#pragma unroll
-        for (int g = 0; g < G; ++g) a1[g] = ap1[(size_t)(4 * g) * LDv];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b1[j] = bp1[boff[j]];
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[g], b0[j], acc[g][j], 0, 0, 0);
-    if (ks + 2 == ksteps) {
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[g][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[g], b1[j], acc[g][j], 0, 0, 0);
-    }
-}
-
-
-template <int G, int NRT_W, int NT>
-__device__ __forceinline__ void k2_edge4(const double* __restrict__ bp, const int (&boff)[NRT_W], size_t kstride,
-                                         const double* ap4, int LDv, int ksteps, double (&acc)[G][NRT_W])
-{
-#if CAFE_K2_DEPTH4 >= 2
-    mfma4_edge_p<G, NRT_W, NT, CAFE_K2_DEPTH4>(bp, boff, kstride, ap4, LDv, ksteps, acc);
-#else
-    mfma4_edge<G, NRT_W, NT>(bp, boff, kstride, ap4, LDv, ksteps, acc);
-#endif
-}
-
 template <int G, int NRT_W>
 __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 {
@@ -962,18 +868,20 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 #pragma unroll
                     for (int j = 0; j < NRT_W; ++j) fac[g][j] = 0.0;
                 if (wave_active) {
-                    int boff[NRT_W];
+                    unsigned voff[NRT_W];
 #pragma unroll
-                    for (int j = 0; j < NRT_W; ++j) boff[j] = ((j < ntile) ? (rt0 + j) : rt0) * 16;
-                    const double* bp = PTe + (size_t)lk * a.LD + li;
+                    for (int j = 0; j < NRT_W; ++j)
+                        voff[j] = (unsigned)(lk * a.LD + li + ((j < ntile) ? (rt0 + j) : rt0) * 16) * 8u;
+                    const k2_gbytes sb = k2_uniform(PTe);
                     const double* ap4 = Lsrc + (size_t)(fbase + (lane & 3)) * a.LDv + lk;
+                    const unsigned kstride_bytes = 32u * (unsigned)a.LD;
                     if constexpr (NRT_W > 1) {
                         if (ntile == NRT_W - 1)
-                            k2_edge4<G, NRT_W, NRT_W - 1>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
+                            mfma4_edge_p<G, NRT_W, NRT_W - 1, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, a.ksteps, fac);
                         else
-                            k2_edge4<G, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
+                            mfma4_edge_p<G, NRT_W, NRT_W, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, a.ksteps, fac);
                     } else {
-                        k2_edge4<G, NRT_W, NRT_W>(bp, boff, (size_t)4 * a.LD, ap4, a.LDv, a.ksteps, fac);
+                        mfma4_edge_p<G, NRT_W, NRT_W, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, a.ksteps, fac);
                     }
                 }
             }

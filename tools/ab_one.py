@@ -46,7 +46,7 @@ def main():
         nl, nm = synth.node_rates(tree, cfg)
         t0 = time.perf_counter()
         n = 0
-        while n < 30 or (time.perf_counter() - t0 < 0.3 and n < 400):
+        while n < 40 or (time.perf_counter() - t0 < 0.3 and n < 400):
             score, fz = eng.get_posterior(nl, nm, prior)
             n += 1
         eng.enable_timing(True)

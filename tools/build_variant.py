@@ -2,7 +2,7 @@
 """Build a variant of libcafehip.so with extra -D flags for A/B runs and debug timelines:
 
     python tools/build_variant.py stamps -DCAFE_K2_STAMPS
-    python tools/build_variant.py d0 -DCAFE_K2_DEPTH=0
+    python tools/build_variant.py d4 -DCAFE_K2_DEPTH4=4
     CAFEHIP_LIB=tools/_variants/d0/libcafehip.so python bench.py ...
 
 Outputs go to tools/_variants/<name>/ (git-ignored, travels to the GPU box with the snapshot)."""
