@@ -329,6 +329,39 @@ __device__ __forceinline__ void k2_release_park_slot(const K2MfmaArgs& a, const 
 // exp(log + log) treatment; the maximum over those IS the maximum over all.  The candidates of all the families of a
 // wave are collected in an LDS list and evaluated together, one per lane.  Families whose largest product is below
 // 1e-290 (underflow would blur the filter) take the plain loop.
+// Wave-wide reductions on the vector ALU's data-parallel primitives (xor 1, xor 2, half-row mirror, row mirror, then
+// one readlane per 16-lane row): ~25 instructions and no LDS traffic, where a __shfl_xor butterfly is 6 dependent
+// ds_bpermute round trips per 32-bit word -- the root scan of one family took 3.4 k cycles with those, 2.2 k with
+// these (cfg 2, s_memtime stamps).  Every lane must be active; every lane receives the result.
+// (The scan stays ONE family at a time: unrolled over 4 families it ran 1.6x slower -- code executed once per
+// workgroup is bound by instruction fetch, not by its dependency chains.)
+__device__ __forceinline__ double k2_wave_max(double v)
+{
+#define CAFE_DPP_MAX(ctrl)                                                                                     \
+    {                                                                                                          \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);              \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);              \
+        v = fmax(v, __hiloint2double(hi, lo));                                                                 \
+    }
+    CAFE_DPP_MAX(0xB1) CAFE_DPP_MAX(0x4E) CAFE_DPP_MAX(0x141) CAFE_DPP_MAX(0x140)
+#undef CAFE_DPP_MAX
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        r[i] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * i + 15), __builtin_amdgcn_readlane(lo, 16 * i + 15));
+    return fmax(fmax(r[0], r[1]), fmax(r[2], r[3]));
+}
+
+__device__ __forceinline__ int k2_wave_min(int v)
+{
+#define CAFE_DPP_MIN(ctrl) v = min(v, __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false));
+    CAFE_DPP_MIN(0xB1) CAFE_DPP_MIN(0x4E) CAFE_DPP_MIN(0x141) CAFE_DPP_MIN(0x140)
+#undef CAFE_DPP_MIN
+    return min(min(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)),
+               min(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
+}
+
 template <bool REGS>   // REGS: R <= 256, the lane's prior values live in registers for the whole epilogue
 __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0,
                                                  size_t out_off, int wave, int lane, int nwaves)
@@ -352,6 +385,10 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
         }
     }
     const int nq = REGS ? PR : (a.R + 63) / 64;
+#ifdef CAFE_K2_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    K2_STAMP(2 + 6 * a.n_ops + 1);
+#endif
     int n_cand = 0;
     unsigned long long fastmask = 0;   // bit t: the wave's t-th family took the filtered path (wave-uniform)
 
@@ -401,16 +438,13 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
                 qmax = fmax(qmax, v * prior[i]);
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ov = __shfl_xor(best, off);
-            const int oi2 = __shfl_xor(bi, off);
-            // first maximum wins (libcommon/mathfunc.c:9-24): larger value, then lower index
-            if (oi2 != INT_MAX && (bi == INT_MAX || ov > best || (ov == best && oi2 < bi))) {
-                best = ov;
-                bi = oi2;
-            }
-            qmax = fmax(qmax, __shfl_xor(qmax, off));
+        // first maximum wins (libcommon/mathfunc.c:9-24): the largest value, then the lowest index holding it (a lane
+        // without elements carries -inf / INT_MAX and never wins)
+        {
+            const double lane_best = best;
+            best = k2_wave_max(lane_best);
+            bi = k2_wave_min(lane_best == best ? bi : INT_MAX);
+            qmax = k2_wave_max(qmax);
         }
         if (lane == 0) {
             max_lik[u] = best;
@@ -420,8 +454,7 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
             // plain form: every root size through log and exp
             double bestp = -INFINITY;
             for (int i = lane; i < a.R; i += 64) bestp = fmax(bestp, exp(log(L[i]) + logprior[i]));
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) bestp = fmax(bestp, __shfl_xor(bestp, off));
+            bestp = k2_wave_max(bestp);
             if (lane == 0) max_post[u] = bestp;
             continue;
         }
@@ -457,7 +490,9 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
         }
     }
     (void)nq;
+    K2_STAMP(2 + 6 * a.n_ops + 2);
     if (n_cand) flush();
+    K2_STAMP(2 + 6 * a.n_ops + 3);
     // lane t writes the maximum of the wave's t-th family
     {
         const int f = wave + lane * nwaves;

@@ -89,6 +89,12 @@ def main():
         prev_end = st[:, :, b + 4].max(axis=1)
     epi = st[:, :, last].max(axis=1) - prev_end
     print("epilogue (posterior): %.0f cycles" % epi.mean())
+    if st[:, :, last + 1].max() > 0:
+        e1 = st[:, :, last + 1].max(axis=1) - prev_end
+        e2 = st[:, :, last + 2].max(axis=1) - prev_end
+        e3 = st[:, :, last + 3].max(axis=1) - prev_end
+        print("   prior in registers %.0f, families scanned %.0f, candidates evaluated %.0f, outputs written %.0f" %
+              (e1.mean(), e2.mean(), e3.mean(), epi.mean()))
     for k, (n, t) in acc.items():
         if n:
             print("%s steps: %d, mean %.0f cycles each, %.0f total (%.1f %% of the workgroup time)" %
