@@ -1580,12 +1580,37 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
         const bool enabled = n_sets == 1 && v1.col_max == nullptr && !(te && atoi(te) == 0) && !shape_env && !getenv("CAFEHIP_K2CFG") &&
                              !getenv("CAFEHIP_K2CFG4");
         auto& t = c->tune;
+        const bool overridden = (te && atoi(te) == 0) || shape_env || getenv("CAFEHIP_K2CFG") || getenv("CAFEHIP_K2CFG4");
         if (!enabled && n_sets > 1) {
             // several parameter sets in one pass: no measurement; the grid a single-set evaluation settled on is
             // kept if there is one, else the cost model's choice stands
             if (t.n_items == n_items && t.locked >= 0 && !t.cands.empty()) {
                 use4 = t.cands[t.locked].use4;
                 k = t.cands[t.locked].cfg;
+            }
+        } else if (!enabled && v1.col_max != nullptr && !overridden) {
+            // batch mode (Monte-Carlo null rows: same tree, same matrices, another row count): one launch cannot be
+            // measured against alternatives; the grid the table's evaluations settled on beats the model's guess
+            // (cfg 5 null, 250 k rows: 21.1 ms with the model's 2,2,1,8, 16.5 ms with the table's 1,4,2,4)
+            if (t.locked >= 0 && !t.cands.empty()) {
+                use4 = t.cands[t.locked].use4;
+                k = t.cands[t.locked].cfg;
+            } else {
+                // ... or on for another table of this shape earlier in the process (nearest row count)
+                std::lock_guard<std::mutex> g(g_tuned_mu);
+                const auto want = tune_key(c, n_items);
+                double best_d = 1e300;
+                for (const auto& kv : g_tuned) {
+                    bool same = kv.first[0] == want[0];
+                    for (int i = 2; i < 8; ++i) same = same && kv.first[i] == want[i];
+                    if (!same) continue;
+                    const double d = fabs(log((double)std::max(kv.first[1], 1L) / (double)n_items));
+                    if (d < best_d) {
+                        best_d = d;
+                        use4 = kv.second.use4;
+                        k = kv.second.cfg;
+                    }
+                }
             }
         } else if (!enabled) {
             t.n_items = -1;
