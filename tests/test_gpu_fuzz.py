@@ -99,3 +99,45 @@ def test_random_shapes(case, kernel):
     assert np.max(np.abs(mpg[nz] - mpo[nz]) / mpo[nz], initial=0) < 1e-9, desc
     ties_ok = amg == amo
     assert np.all(ties_ok | ~nz), desc
+
+
+@pytest.mark.parametrize("shape", ["4", "16"])
+def test_k_loop_phases_and_tiny_matrices(shape):
+    """The products' k loop runs D ring slots per trip, absorbs the remainder in a partial first trip and drains the
+    rings in D - 1 load-free regions (k2_mfma.hpp); matrix sides 4..27 walk every remainder class of both kernels
+    (depth 3 for the 4x4x4 shape, 2 for 16x16x4) and the no-pipeline fallback for a matrix side <= 4."""
+    import cafe_amd
+    t = O.PyTree("((a:7,b:11):5,(c:3,(d:9,e:2):6):4)")
+    rs = np.random.RandomState(4242)
+    os.environ["CAFEHIP_MFMA"] = shape
+    os.environ["CAFEHIP_K2"] = "mfma"
+    try:
+        for mx in list(range(3, 27)):
+            rmax = max(2, mx - 1)
+            F = 37
+            counts = rs.randint(0, mx + 1, size=(F, t.n_leaves)).astype(np.int32)
+            counts[0] = 0
+            counts[1] = mx
+            rng = O.make_range(0, mx, 1, rmax)
+            prior = O.prior_poisson(1000, 1, 2.0)
+            lam = np.full(t.n_nodes, 0.03)
+            mu = np.full(t.n_nodes, 0.02 if mx % 2 else -1.0)
+            eng = cafe_amd.Engine(0)
+            try:
+                eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+                eng.set_families(counts, cafe_amd.FamilySizeRange(0, mx, 1, rmax))
+                sg, fzg, mlg, amg, mpg = eng.get_posterior(lam, mu, prior, per_family=True)
+                desc = eng.describe()
+            finally:
+                eng.close()
+            assert ("k2:mfma4x4" in desc) == (shape == "4"), desc
+            so, fzo, mlo, amo, mpo = O.eval_posterior(t, counts, rng, lam, mu, prior, nthreads=2)
+            assert fzg == fzo, (mx, desc)
+            nz = mlo > 0
+            assert np.array_equal(mlg == 0, mlo == 0), (mx, desc)
+            assert np.max(np.abs(mlg[nz] - mlo[nz]) / mlo[nz], initial=0) < 1e-9, (mx, desc)
+            assert np.max(np.abs(mpg[nz] - mpo[nz]) / mpo[nz], initial=0) < 1e-9, (mx, desc)
+            assert np.all((amg == amo) | ~nz), (mx, desc)
+    finally:
+        os.environ.pop("CAFEHIP_MFMA", None)
+        os.environ.pop("CAFEHIP_K2", None)
