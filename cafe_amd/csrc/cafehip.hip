@@ -933,6 +933,33 @@ struct cafehip_ctx {
     bool k2_used_mfma = false;
     bool k2_shape4 = false;
 
+    // subtree-state compression of the objective path (schedule.hpp, CNode; rebuilt by set_tree / set_families)
+    struct CompressPlan {
+        bool valid = false;
+        cafehip::MfmaSchedule sched;        // walk of the reduced tree (compressed subtrees are leaves)
+        cafehip::MfmaOp* d_ops = nullptr;
+        int n_cols = 0;                     // index columns of the walk: surviving leaves + compressed subtree roots
+        std::vector<int> col_leaf;          // per column: count-table column of the leaf, or -1 (compressed subtree)
+        int32_t* d_counts = nullptr;        // [Fu][n_cols]
+        uint8_t* d_col_has_err = nullptr;   // [n_cols]
+        std::vector<cafehip::CNode> nodes;
+        std::vector<cafehip::CTile> tiles;
+        std::vector<int> level_first;       // tiles of level l: [level_first[l], level_first[l + 1])
+        cafehip::CNode* d_nodes = nullptr;
+        cafehip::CTile* d_tiles = nullptr;
+        int32_t* d_cidx = nullptr;
+        int32_t* d_table_off = nullptr;     // [n_nodes]
+        size_t table_elems = 0;             // per parameter set
+        double* d_tables = nullptr;
+        size_t tables_cap = 0;              // elements
+        long states = 0;                    // sum of D over the compressed nodes
+    } cp;
+    bool walk_compressed = false;           // the MFMA launcher walks the reduced tree (set around one launch)
+    bool last_compressed = false;           // ... and the last objective evaluation did
+    std::vector<int32_t> h_ucounts;         // unique rows, host copy
+    std::vector<uint8_t> h_leaf_has_err;    // by count-table column
+    double issued_walk = 0, issued_tables = 0;   // matrix-instruction flops issued by the last evaluation's pruning
+
     // families
     int F = 0, Fu = 0, n_leaves = 0;
     int range_min = 0, range_max = 0, root_min = 0, root_max = 0;
@@ -1273,6 +1300,269 @@ int launch_k2_v1(cafehip_ctx* c, K2Args& a, int n_items)
 }
 
 
+// ---- subtree-state compression: plan -------------------------------------------------
+const cafehip::MfmaSchedule& walk_sched(const cafehip_ctx* c) { return c->walk_compressed ? c->cp.sched : c->msched; }
+int walk_cols(const cafehip_ctx* c) { return c->walk_compressed ? c->cp.n_cols : c->n_leaves; }
+
+void free_compression(cafehip_ctx* c)
+{
+    auto& p = c->cp;
+    hipFree(p.d_ops);
+    hipFree(p.d_counts);
+    hipFree(p.d_col_has_err);
+    hipFree(p.d_nodes);
+    hipFree(p.d_tiles);
+    hipFree(p.d_cidx);
+    hipFree(p.d_table_off);
+    hipFree(p.d_tables);
+    p = cafehip_ctx::CompressPlan();
+}
+
+int upload_col_has_err(cafehip_ctx* c)
+{
+    auto& p = c->cp;
+    if (!p.valid) return 0;
+    std::vector<uint8_t> v(std::max(p.n_cols, 1), 0);
+    for (int j = 0; j < p.n_cols; ++j)
+        if (p.col_leaf[j] >= 0 && p.col_leaf[j] < (int)c->h_leaf_has_err.size()) v[j] = c->h_leaf_has_err[p.col_leaf[j]];
+    if (!p.d_col_has_err) HIP_TRY(hipMalloc(&p.d_col_has_err, v.size()));
+    HIP_TRY(hipMemcpy(p.d_col_has_err, v.data(), v.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// wave rows / row tiles of k2c_nodes for this matrix side (0: too large, no compression)
+int k2c_wave_rows(const cafehip_ctx* c, int* nrt_w)
+{
+    const int RT = (c->C + 15) / 16;
+    const int wr = RT <= 28 ? 4 : 8;
+    *nrt_w = (RT + wr - 1) / wr;
+    return *nrt_w <= 7 ? wr : 0;
+}
+
+// (Re)build the plan from the tree and the unique rows.  A node is compressed when both children are leaves or
+// compressed and its distinct states number at most CAFEHIP_COMPRESS_THETA (default 0.5) of the unique rows;
+// CAFEHIP_COMPRESS=0 disables.  Tables with fewer than 1024 unique rows are left alone (nothing to win).
+int rebuild_compression(cafehip_ctx* c)
+{
+    free_compression(c);
+    if (const char* e = getenv("CAFEHIP_COMPRESS"))
+        if (atoi(e) == 0) return 0;
+    const int n = c->n_nodes, nl = c->n_leaves, Fu = c->Fu;
+    if (n <= 0 || c->M < 0 || nl != (n + 1) / 2 || Fu < 1024 || (int)c->h_ucounts.size() != Fu * nl) return 0;
+    int nrt_w = 0;
+    if (k2c_wave_rows(c, &nrt_w) == 0) return 0;
+    double theta = 0.5;
+    if (const char* e = getenv("CAFEHIP_COMPRESS_THETA")) theta = std::min(std::max(atof(e), 0.0), 1.0);
+    const size_t limit = (size_t)(theta * Fu);
+    const auto& left = c->left;
+    const auto& right = c->right;
+    auto internal = [&](int v) { return left[v] >= 0; };
+    std::vector<int> post;
+    {
+        std::vector<std::pair<int, int>> st;
+        st.push_back({c->root, 0});
+        while (!st.empty()) {
+            auto& top = st.back();
+            const int v = top.first;
+            if (!internal(v)) { post.push_back(v); st.pop_back(); }
+            else if (top.second == 0) { top.second = 1; st.push_back({left[v], 0}); }
+            else if (top.second == 1) { top.second = 2; st.push_back({right[v], 0}); }
+            else { post.push_back(v); st.pop_back(); }
+        }
+    }
+    std::vector<std::vector<int32_t>> sid(n), idx0(n), idx1(n);
+    std::vector<int> D(n, 0), level(n, 0);
+    std::vector<char> comp(n, 0);
+    for (int v : post) {
+        if (!internal(v)) {
+            sid[v].resize(Fu);
+            for (int u = 0; u < Fu; ++u) sid[v][u] = c->h_ucounts[(size_t)u * nl + v / 2];
+            continue;
+        }
+        const int a = left[v], b = right[v];
+        const bool ok_children = (!internal(a) || comp[a]) && (!internal(b) || comp[b]);
+        if (v != c->root && ok_children) {
+            std::unordered_map<uint64_t, int32_t> ids;
+            ids.reserve(std::min<size_t>(limit + 1, 1u << 20));
+            std::vector<int32_t> mine(Fu);
+            bool fits = true;
+            for (int u = 0; u < Fu; ++u) {
+                const uint64_t key = ((uint64_t)(uint32_t)sid[a][u] << 32) | (uint32_t)sid[b][u];
+                auto it = ids.find(key);
+                if (it == ids.end()) {
+                    if (ids.size() >= limit) { fits = false; break; }
+                    it = ids.emplace(key, (int32_t)ids.size()).first;
+                    idx0[v].push_back(sid[a][u]);
+                    idx1[v].push_back(sid[b][u]);
+                }
+                mine[u] = it->second;
+            }
+            if (fits && !ids.empty()) {
+                comp[v] = 1;
+                D[v] = (int)ids.size();
+                level[v] = 1 + std::max(comp[a] ? level[a] : 0, comp[b] ? level[b] : 0);
+                sid[v].swap(mine);
+            } else {
+                idx0[v].clear();
+                idx1[v].clear();
+            }
+        }
+        // the children's states are needed again only as columns of the walk (kept below for the maximal nodes)
+        if (comp[v]) {
+            std::vector<int32_t>().swap(sid[a]);
+            std::vector<int32_t>().swap(sid[b]);
+        }
+    }
+    std::vector<int> parent(n, -1);
+    for (int v = 0; v < n; ++v)
+        if (internal(v)) { parent[left[v]] = v; parent[right[v]] = v; }
+    int n_comp = 0, n_levels = 0;
+    for (int v = 0; v < n; ++v)
+        if (comp[v]) { ++n_comp; n_levels = std::max(n_levels, level[v]); }
+    if (n_comp == 0) return 0;
+    auto& p = c->cp;
+    // tables
+    std::vector<int32_t> table_off(n, 0);
+    size_t elems = 0, n_idx = 0;
+    for (int v = 0; v < n; ++v)
+        if (comp[v]) {
+            table_off[v] = (int32_t)elems;
+            elems += (size_t)D[v] * c->LD;
+            n_idx += 2 * (size_t)D[v];
+            p.states += D[v];
+        }
+    if (elems >= ((size_t)1 << 31) || n_idx >= ((size_t)1 << 31)) { p = cafehip_ctx::CompressPlan(); return 0; }
+    p.table_elems = elems;
+    // nodes and tiles, level by level
+    std::vector<int32_t> cidx;
+    cidx.reserve(n_idx);
+    p.level_first.assign(1, 0);
+    for (int l = 1; l <= n_levels; ++l) {
+        for (int v = 0; v < n; ++v) {
+            if (!comp[v] || level[v] != l) continue;
+            cafehip::CNode nd{};
+            nd.node = v;
+            nd.D = D[v];
+            const int ch[2] = {left[v], right[v]};
+            for (int k = 0; k < 2; ++k) {
+                nd.child[k] = ch[k];
+                nd.kind[k] = internal(ch[k]) ? 2 : 0;
+                nd.leafcol[k] = internal(ch[k]) ? 0 : ch[k] / 2;
+                nd.tab_off[k] = internal(ch[k]) ? table_off[ch[k]] : 0;
+            }
+            nd.idx_off = (int32_t)cidx.size();
+            cidx.insert(cidx.end(), idx0[v].begin(), idx0[v].end());
+            cidx.insert(cidx.end(), idx1[v].begin(), idx1[v].end());
+            nd.out_off = table_off[v];
+            for (int s0 = 0; s0 < D[v]; s0 += 16) p.tiles.push_back(cafehip::CTile{(int32_t)p.nodes.size(), s0});
+            p.nodes.push_back(nd);
+        }
+        p.level_first.push_back((int)p.tiles.size());
+    }
+    // the reduced tree's leaves and the walk's index table
+    std::vector<char> under(n, 0);   // strictly below a compressed node
+    for (int i = (int)post.size() - 1; i >= 0; --i) {
+        const int v = post[i];   // parents before children in reverse post-order
+        if (parent[v] >= 0 && (comp[parent[v]] || under[parent[v]])) under[v] = 1;
+    }
+    std::vector<int> leafcol_of(n, -1);
+    for (int v = 0; v < n; ++v) {
+        if (under[v]) continue;
+        if (!internal(v) || comp[v]) {
+            leafcol_of[v] = p.n_cols++;
+            p.col_leaf.push_back(internal(v) ? -1 : v / 2);
+        }
+    }
+    std::vector<int32_t> wc((size_t)Fu * p.n_cols);
+    for (int v = 0; v < n; ++v) {
+        const int j = leafcol_of[v];
+        if (j < 0) continue;
+        if (internal(v))
+            for (int u = 0; u < Fu; ++u) wc[(size_t)u * p.n_cols + j] = sid[v][u];
+        else
+            for (int u = 0; u < Fu; ++u) wc[(size_t)u * p.n_cols + j] = c->h_ucounts[(size_t)u * nl + v / 2];
+    }
+    p.sched = cafehip::build_mfma_schedule(n, c->root, left, right, &leafcol_of);
+    HIP_TRY(hipMalloc(&p.d_ops, std::max<size_t>(p.sched.ops.size(), 1) * sizeof(cafehip::MfmaOp)));
+    HIP_TRY(hipMemcpy(p.d_ops, p.sched.ops.data(), p.sched.ops.size() * sizeof(cafehip::MfmaOp), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&p.d_counts, wc.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p.d_counts, wc.data(), wc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&p.d_nodes, p.nodes.size() * sizeof(cafehip::CNode)));
+    HIP_TRY(hipMemcpy(p.d_nodes, p.nodes.data(), p.nodes.size() * sizeof(cafehip::CNode), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&p.d_tiles, p.tiles.size() * sizeof(cafehip::CTile)));
+    HIP_TRY(hipMemcpy(p.d_tiles, p.tiles.data(), p.tiles.size() * sizeof(cafehip::CTile), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&p.d_cidx, std::max<size_t>(cidx.size(), 1) * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p.d_cidx, cidx.data(), cidx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&p.d_table_off, n * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p.d_table_off, table_off.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    p.valid = true;
+    return upload_col_has_err(c);
+}
+
+template <int NRT_W>
+int launch_k2c_inst(cafehip_ctx* c, const K2cArgs& a, int grid, int n_sets, int block, size_t lds)
+{
+    if (grant_lds(c, reinterpret_cast<const void*>(&k2c_nodes<NRT_W>), lds, 64 * 1024)) return -1;
+    hipLaunchKernelGGL(k2c_nodes<NRT_W>, dim3(grid, n_sets), dim3(block), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// factor tables of the compressed subtrees for the matrices just built: one launch per level, children first
+int launch_compressed_levels(cafehip_ctx* c, int n_sets)
+{
+    auto& p = c->cp;
+    c->issued_tables = 0;
+    if (!p.valid) return 0;
+    const size_t need = p.table_elems * (size_t)n_sets;
+    if (need > p.tables_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(p.d_tables);
+        p.d_tables = nullptr;
+        p.tables_cap = 0;
+        HIP_TRY(hipMalloc(&p.d_tables, need * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(p.d_tables, 0, need * sizeof(double), c->stream));   // row padding beyond the tiles stays zero
+        p.tables_cap = need;
+    }
+    int nrt_w = 0;
+    const int wr = k2c_wave_rows(c, &nrt_w);
+    K2cArgs a;
+    memset(&a, 0, sizeof a);
+    a.PT = c->d_PT;
+    a.PTfold = (c->d_err && c->fold_current) ? c->d_PTfold : nullptr;
+    a.ep = c->d_params;
+    a.nodes = p.d_nodes;
+    a.cidx = p.d_cidx;
+    a.leaf_has_err = c->d_leaf_has_err;
+    a.tables = p.d_tables;
+    a.table_set_stride = p.table_elems;
+    a.C = c->C;
+    a.LD = c->LD;
+    a.KP = c->KP;
+    a.LDv = c->LDv;
+    a.ksteps = (c->C + 3) / 4;
+    const size_t lds = (size_t)16 * c->LDv * sizeof(double);
+    for (size_t l = 0; l + 1 < p.level_first.size(); ++l) {
+        const int first = p.level_first[l], n_tiles = p.level_first[l + 1] - first;
+        if (n_tiles <= 0) continue;
+        a.tiles = p.d_tiles + first;
+        int rc = -1;
+        switch (nrt_w) {
+            case 1: rc = launch_k2c_inst<1>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
+            case 2: rc = launch_k2c_inst<2>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
+            case 3: rc = launch_k2c_inst<3>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
+            case 4: rc = launch_k2c_inst<4>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
+            case 5: rc = launch_k2c_inst<5>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
+            case 6: rc = launch_k2c_inst<6>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
+            case 7: rc = launch_k2c_inst<7>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
+        }
+        if (rc) return rc;
+    }
+    const double kpad = 4.0 * ((c->C + 3) / 4), rows = 16.0 * ((c->C + 15) / 16);
+    c->issued_tables = 2.0 * kpad * rows * 16.0 * (double)p.tiles.size() * n_sets;
+    return 0;
+}
+
 // ---- MFMA launcher -------------------------------------------------------------------
 // Park scratch of a launch (node vectors waiting for their sibling that do not fit LDS): one slot per workgroup that
 // can be RESIDENT (occupancy query x CUs, doubled as margin), claimed by the workgroups at run time
@@ -1281,7 +1571,7 @@ int launch_k2_v1(cafehip_ctx* c, K2Args& a, int n_items)
 // Cache (round 1: 7.7 GB of HBM traffic per launch).  CAFEHIP_K2SLOTS=0 restores one region per tile.
 int k2_fit_grid(cafehip_ctx* c, const void* fn, K2MfmaArgs& a, int* grid, int block, size_t lds)
 {
-    const bool global_parks = c->msched.n_parks > a.lds_parks;
+    const bool global_parks = walk_sched(c).n_parks > a.lds_parks;
     int slots = 0;
     bool per_tile = false;
     if (const char* e = getenv("CAFEHIP_K2SLOTS")) per_tile = atoi(e) == 0;
@@ -1352,7 +1642,7 @@ int launch_mfma_nrt(cafehip_ctx* c, const K2MfmaArgs& a, int nrt_w, int grid, in
 // workgroups share a CU; otherwise they live in global scratch and are fetched back when consumed.
 size_t mfma_lds_bytes_with(const cafehip_ctx* c, int nf, int lds_parks)
 {
-    return (size_t)nf * c->LDv * sizeof(double) * (1 + lds_parks) + k2_scratch_bytes(nf, c->n_leaves, (int)c->msched.ops.size());
+    return (size_t)nf * c->LDv * sizeof(double) * (1 + lds_parks) + k2_scratch_bytes(nf, walk_cols(c), (int)walk_sched(c).ops.size());
 }
 
 // Number of park buffers (node vectors waiting for their sibling; slot 0 is the busiest) kept in LDS behind the
@@ -1363,15 +1653,16 @@ size_t mfma_lds_bytes_with(const cafehip_ctx* c, int nf, int lds_parks)
 // CAFEHIP_LDSPARK=<n> overrides (0 = none).
 int mfma_lds_parks(const cafehip_ctx* c, int nf, int n_items)
 {
-    if (c->msched.n_parks <= 0) return 0;
-    if (const char* e = getenv("CAFEHIP_LDSPARK")) return std::min(std::max(atoi(e), 0), c->msched.n_parks);
+    const int n_parks = walk_sched(c).n_parks;
+    if (n_parks <= 0) return 0;
+    if (const char* e = getenv("CAFEHIP_LDSPARK")) return std::min(std::max(atoi(e), 0), n_parks);
     const size_t cu_lds = 160 * 1024;
     const int grid = (n_items + nf - 1) / nf;
     const int wanted = std::max(1, (grid + c->n_cu - 1) / std::max(c->n_cu, 1));
     const int resident0 = (int)(cu_lds / std::max<size_t>(mfma_lds_bytes_with(c, nf, 0), 1));
     const int keep = std::max(1, std::min(wanted, resident0));
     int n = 0;
-    while (n < c->msched.n_parks && (int)(cu_lds / mfma_lds_bytes_with(c, nf, n + 1)) >= keep &&
+    while (n < n_parks && (int)(cu_lds / mfma_lds_bytes_with(c, nf, n + 1)) >= keep &&
            mfma_lds_bytes_with(c, nf, n + 1) <= (size_t)c->lds_limit)
         ++n;
     return n;
@@ -1547,8 +1838,8 @@ std::mutex g_tuned_mu;
 std::map<std::array<long, 8>, K2Cand> g_tuned;
 std::array<long, 8> tune_key(const cafehip_ctx* c, int n_items)
 {
-    return {(long)c->device, (long)n_items, (long)c->C, (long)c->R, (long)c->n_leaves, (long)c->msched.ops.size(),
-            (long)c->msched.n_parks, (long)(c->d_err != nullptr)};
+    return {(long)c->device, (long)n_items, (long)c->C, (long)c->R, (long)walk_cols(c), (long)walk_sched(c).ops.size(),
+            (long)walk_sched(c).n_parks, (long)(c->d_err != nullptr)};
 }
 
 int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1)
@@ -1564,6 +1855,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     if (!have16 && !have4) {
         // matrices too large for the MFMA wave grids: the row-per-thread kernel handles them
         if (n_sets > 1) return fail("several parameter sets per pass need the matrix-core kernel (matrix side too large)");
+        if (c->walk_compressed) return fail("internal: compressed walk without a matrix-core wave grid");
         c->k2_used_mfma = false;
         K2Args a1 = v1;
         return launch_k2_v1(c, a1, n_items);
@@ -1592,7 +1884,11 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
             // batch mode (Monte-Carlo null rows: same tree, same matrices, another row count): one launch cannot be
             // measured against alternatives; the grid the table's evaluations settled on beats the model's guess
             // (cfg 5 null, 250 k rows: 21.1 ms with the model's 2,2,1,8, 16.5 ms with the table's 1,4,2,4)
-            if (t.locked >= 0 && !t.cands.empty()) {
+            auto fits = [&](const K2Cand& cd) {
+                const int nf_c = cd.use4 ? 4 * cd.cfg.nft_w * cd.cfg.wf : 16 * cd.cfg.nft_w * cd.cfg.wf;
+                return mfma_lds_bytes(c, nf_c, n_items) <= (size_t)c->lds_limit;   // (the table's walk may have been a reduced one)
+            };
+            if (t.locked >= 0 && !t.cands.empty() && fits(t.cands[t.locked])) {
                 use4 = t.cands[t.locked].use4;
                 k = t.cands[t.locked].cfg;
             } else {
@@ -1603,7 +1899,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
                 for (const auto& kv : g_tuned) {
                     bool same = kv.first[0] == want[0];
                     for (int i = 2; i < 8; ++i) same = same && kv.first[i] == want[i];
-                    if (!same) continue;
+                    if (!same || !fits(kv.second)) continue;
                     const double d = fabs(log((double)std::max(kv.first[1], 1L) / (double)n_items));
                     if (d < best_d) {
                         best_d = d;
@@ -1700,12 +1996,17 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     memset(&a, 0, sizeof a);
     a.PT = v1.PT;
     a.ep = v1.ep;
-    a.ops = c->d_mops;
-    a.n_ops = (int)c->msched.ops.size();
+    a.ops = c->walk_compressed ? c->cp.d_ops : c->d_mops;
+    a.n_ops = (int)walk_sched(c).ops.size();
     a.n_sets = n_sets;
-    a.counts = v1.counts;
+    a.counts = c->walk_compressed ? c->cp.d_counts : v1.counts;
     a.Fu = v1.Fu;
-    a.n_leaves = v1.n_leaves;
+    a.n_leaves = walk_cols(c);
+    if (c->walk_compressed) {
+        a.tables = c->cp.d_tables;
+        a.table_off = c->cp.d_table_off;
+        a.table_set_stride = c->cp.table_elems;
+    }
     a.C = v1.C;
     a.R = v1.R;
     a.root_min = v1.root_min;
@@ -1717,11 +2018,11 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     a.Wr = k.wr;
     a.NF = nf;
     a.park = nullptr;   // sized and set by k2_fit_grid for the grid actually launched
-    a.n_parks = std::max(c->msched.n_parks, 1);
+    a.n_parks = std::max(walk_sched(c).n_parks, 1);
     a.lds_parks = mfma_lds_parks(c, nf, n_items);
     a.err = v1.err;
     a.err_ld = v1.err_ld;
-    a.leaf_has_err = v1.leaf_has_err;
+    a.leaf_has_err = (c->walk_compressed && v1.leaf_has_err) ? c->cp.d_col_has_err : v1.leaf_has_err;
     a.err_banded = (v1.err != nullptr) ? c->err_banded : 0;
     a.err_dlo = c->err_dlo;
     a.err_dhi = c->err_dhi;
@@ -1743,6 +2044,17 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     c->k2_lds = lds;
     c->k2_used_mfma = true;
     c->k2_shape4 = use4;
+    {
+        // matrix-instruction flops this launch issues: one product per internal child, roundup16(rows) x roundup4(C)
+        // per family slot (tile padding included)
+        const double kpad = 4.0 * a.ksteps;
+        double per_slot = 0;
+        for (const auto& op : walk_sched(c).ops) {
+            const double rows = 16.0 * (((op.is_root ? c->R : c->C) + 15) / 16);
+            per_slot += 2.0 * kpad * rows * ((op.kind[0] == 1) + (op.kind[1] == 1));
+        }
+        c->issued_walk = per_slot * (double)nf * grid * n_sets;
+    }
 #ifdef CAFE_K2_STAMPS
     const char* stamps_file = getenv("CAFEHIP_STAMPS_FILE");
     const size_t stamps_n = (size_t)grid * 8 * K2_STAMP_SLOTS;
@@ -1781,7 +2093,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
         if (FILE* f = fopen(stamps_file, "wb")) {
             const long long hdr[8] = {grid, block / 64, K2_STAMP_SLOTS, a.n_ops, nf, use4 ? 4 : 16, k.wf, k.wr};
             fwrite(hdr, sizeof hdr, 1, f);
-            fwrite(c->msched.ops.data(), sizeof(cafehip::MfmaOp), c->msched.ops.size(), f);
+            fwrite(walk_sched(c).ops.data(), sizeof(cafehip::MfmaOp), walk_sched(c).ops.size(), f);
             fwrite(h.data(), sizeof(unsigned long long), stamps_n, f);
             fclose(f);
         }
@@ -1884,7 +2196,19 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
         a.err_ld = c->err_mfs + 1;
         a.leaf_has_err = c->d_leaf_has_err;
     }
-    if (launch_k2(c, a, c->Fu, n_sets)) return -1;
+    {
+        // the objective path walks the reduced tree when the table compresses (matrix-core kernels; an error model
+        // only in its folded form, so that every leaf stays a column gather)
+        const char* k2e = getenv("CAFEHIP_K2");
+        const bool use_c = c->cp.valid && !(k2e && strcmp(k2e, "v1") == 0) && (!c->d_err || c->fold_current);
+        c->issued_tables = 0;
+        if (use_c && launch_compressed_levels(c, n_sets)) return -1;
+        c->walk_compressed = use_c;
+        const int rc = launch_k2(c, a, c->Fu, n_sets);
+        c->walk_compressed = false;
+        if (rc) return -1;
+        c->last_compressed = use_c && c->k2_used_mfma;
+    }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     if (c->n_chunks > 0) {
         if (host_out) {
@@ -1989,6 +2313,7 @@ void cafehip_destroy(cafehip_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     free_family_buffers(c);
+    free_compression(c);
     hipFree(c->d_ops);
     hipFree(c->d_mops);
     hipFree(c->d_park);
@@ -2112,6 +2437,7 @@ int cafehip_set_tree(cafehip_ctx* c, int n_nodes, const int32_t* parent, const i
     }
     c->have_matrices = false;
     if (c->M >= 0 && ensure_matrix_storage(c)) return -1;
+    if (c->M >= 0 && rebuild_compression(c)) return -1;
     return 0;
 }
 
@@ -2172,6 +2498,8 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
         memcpy(&ucounts[(size_t)u * n_leaves], counts + (size_t)uniq_rows[u] * n_leaves, sizeof(int32_t) * n_leaves);
 
     free_family_buffers(c);
+    c->h_ucounts = ucounts;
+    if (Fu == 0) c->h_ucounts.clear();
     c->out_sets = 1;
     c->F = F;
     c->Fu = Fu;
@@ -2234,6 +2562,7 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
         c->have_matrices = false;
     }
     if (c->n_nodes > 0 && ensure_matrix_storage(c)) return -1;
+    if (rebuild_compression(c)) return -1;
     return 0;
 }
 
@@ -2249,7 +2578,8 @@ int cafehip_set_error_model(cafehip_ctx* c, int mfs, const double* errormatrix,
     c->d_err = nullptr;
     c->d_leaf_has_err = nullptr;
     c->err_mfs = -1;
-    if (!errormatrix) return 0;
+    c->h_leaf_has_err.clear();
+    if (!errormatrix) return upload_col_has_err(c);
     if (c->n_nodes <= 0) return fail("set the tree before the error model");
     if (mfs < 0) return fail("bad error-model size %d", mfs);
     const size_t n = (size_t)(mfs + 1) * (mfs + 1);
@@ -2274,8 +2604,9 @@ int cafehip_set_error_model(cafehip_ctx* c, int mfs, const double* errormatrix,
     for (int i = 0; i < c->n_nodes; i += 2) by_col[i / 2] = leaf_has_model ? leaf_has_model[i] : 1;
     HIP_TRY(hipMalloc(&c->d_leaf_has_err, by_col.size()));
     HIP_TRY(hipMemcpy(c->d_leaf_has_err, by_col.data(), by_col.size(), hipMemcpyHostToDevice));
+    c->h_leaf_has_err = by_col;
     c->err_mfs = mfs;
-    return 0;
+    return upload_col_has_err(c);
 }
 
 int cafehip_num_chunks(cafehip_ctx* c) { return c ? c->n_chunks : fail("null context"); }
@@ -2469,6 +2800,14 @@ int cafehip_launch_info(cafehip_ctx* c, int* k2_workgroups, int* compute_units)
     if (!c) return fail("null context");
     if (k2_workgroups) *k2_workgroups = c->k2_used_mfma ? c->k2_grid : (c->k2_nf > 0 ? (c->Fu + c->k2_nf - 1) / c->k2_nf : 0);
     if (compute_units) *compute_units = c->n_cu;
+    return 0;
+}
+
+int cafehip_last_issued_flops(cafehip_ctx* c, double* walk, double* tables)
+{
+    if (!c) return fail("null context");
+    if (walk) *walk = c->issued_walk;
+    if (tables) *tables = c->last_compressed ? c->issued_tables : 0.0;
     return 0;
 }
 
@@ -2762,6 +3101,11 @@ const char* cafehip_describe(cafehip_ctx* c)
              c->k2_used_mfma ? (c->k2_shape4 ? "mfma4x4(cfg=G,nrtw,wf,wr)" : "mfma") : "v1", c->k2_nf, c->k2_block, c->k2_lds, c->k2_cfg[0], c->k2_cfg[1],
              c->k2_cfg[2], c->k2_cfg[3], c->k2_grid, c->k2_park_slots);
     c->desc = buf;
+    if (c->cp.valid) {
+        snprintf(buf, sizeof buf, " compressed(nodes=%zu levels=%zu states=%ld walk_steps=%zu walk_cols=%d used=%d)", c->cp.nodes.size(),
+                 c->cp.level_first.size() - 1, c->cp.states, c->cp.sched.ops.size(), c->cp.n_cols, (int)c->last_compressed);
+        c->desc += buf;
+    }
     return c->desc.c_str();
 }
 

@@ -59,6 +59,11 @@ struct K2MfmaArgs {
     double* max_lik;
     int32_t* argmax;
     double* max_post;
+    // compressed subtrees (schedule.hpp, CNode): factor tables [set][node table][state][LD], rows gathered like
+    // matrix columns by a child of kind 2; table_off[node] = element offset of the node's table
+    const double* tables;
+    const int32_t* table_off;
+    size_t table_set_stride;
     // debug builds (-DCAFE_K2_STAMPS): s_memtime stamps [workgroup][wave][K2_STAMP_SLOTS], else NULL and unused
     unsigned long long* stamps;
 };
@@ -551,7 +556,8 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
     for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
         const cafehip::MfmaOp& o = a.ops[i >> 1];
-        s_key[i] = a.ep->node_key[blockIdx.y][o.child[i & 1]] * a.KP * a.LD;   // element offset of the child's matrix (< 2^31)
+        // element offset (< 2^31) of the child's matrix, or of its factor table when it is a compressed subtree
+        s_key[i] = (o.kind[i & 1] == 2) ? a.table_off[o.child[i & 1]] : a.ep->node_key[blockIdx.y][o.child[i & 1]] * a.KP * a.LD;
         s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
     }
 
@@ -591,7 +597,9 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
             const bool has_err = s_err[oi * 2 + ch] != 0;
             const bool folded = has_err && fold;   // gathers on the folded matrix, like a one-hot leaf
             const bool errleaf = has_err && !fold;
-            const double* PTe = (folded ? a.PTfold : a.PT) + s_key[oi * 2 + ch] + row_lo;
+            const bool from_table = op.kind[ch] == 2;   // compressed subtree: the factor is a row of its table
+            const double* PTe = (from_table ? a.tables + (size_t)blockIdx.y * a.table_set_stride : (folded ? a.PTfold : a.PT)) +
+                                s_key[oi * 2 + ch] + row_lo;
             cafe_d4 fac[NFT_W][NRT_W];
             if (errleaf && a.err_banded) {
                 // banded error model (as read from a model file, cafe/error_model.cpp:162-189): the leaf
@@ -616,15 +624,15 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                         }
                     }
                 }
-            } else if (op.kind[ch] == 0 && !errleaf) {
-                // one-hot leaf: factor = PT[count][row]  (cafe/cafe_tree.c:208-209)
+            } else if (op.kind[ch] != 1 && !errleaf) {
+                // one-hot leaf: factor = PT[count][row]  (cafe/cafe_tree.c:208-209); compressed subtree: table[state][row]
 #pragma unroll
                 for (int i = 0; i < NFT_W; ++i) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int f = (ft0 + i) * 16 + lk + 4 * r;
                         const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
-                        const bool ok = cnt <= cmx[i][r];
+                        const bool ok = from_table || cnt <= cmx[i][r];
                         // one address per family; the row tiles are constant byte offsets from it
                         const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
@@ -783,7 +791,8 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
     for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
         const cafehip::MfmaOp& o = a.ops[i >> 1];
-        s_key[i] = a.ep->node_key[blockIdx.y][o.child[i & 1]] * a.KP * a.LD;   // element offset of the child's matrix (< 2^31)
+        // element offset (< 2^31) of the child's matrix, or of its factor table when it is a compressed subtree
+        s_key[i] = (o.kind[i & 1] == 2) ? a.table_off[o.child[i & 1]] : a.ep->node_key[blockIdx.y][o.child[i & 1]] * a.KP * a.LD;
         s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
     }
 
@@ -820,18 +829,20 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         bool simple[2];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch)
-            simple[ch] = (op.kind[ch] == 0) && (fold || !s_err[oi * 2 + ch]);
+            simple[ch] = (op.kind[ch] != 1) && (fold || !s_err[oi * 2 + ch]);
         const int pre_ch = (simple[1] && !simple[0]) ? 1 : ((simple[0] && !simple[1]) ? 0 : -1);
         double pre[G][NRT_W];
         if (pre_ch >= 0) {
             const int leafcol = pre_ch ? op.leafcol[1] : op.leafcol[0];
             const bool pre_folded = fold && s_err[oi * 2 + pre_ch] != 0;
-            const double* PTe = (pre_folded ? a.PTfold : a.PT) + s_key[oi * 2 + pre_ch] + row_lo;
+            const bool pre_table = (pre_ch ? op.kind[1] : op.kind[0]) == 2;
+            const double* PTe = (pre_table ? a.tables + (size_t)blockIdx.y * a.table_set_stride : (pre_folded ? a.PTfold : a.PT)) +
+                                s_key[oi * 2 + pre_ch] + row_lo;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int f = fbase + 4 * g + lk;
                 const int cnt = s_cnt[f * a.n_leaves + leafcol];
-                const bool ok = cnt <= cmx[g];
+                const bool ok = pre_table || cnt <= cmx[g];
                 // one address per family group; the row tiles are constant byte offsets from it
                 const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
@@ -852,7 +863,9 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
             const bool has_err = s_err[oi * 2 + ch] != 0;
             const bool folded = has_err && fold;
             const bool errleaf = has_err && !fold;
-            const double* PTe = (folded ? a.PTfold : a.PT) + s_key[oi * 2 + ch] + row_lo;
+            const bool from_table = op.kind[ch] == 2;
+            const double* PTe = (from_table ? a.tables + (size_t)blockIdx.y * a.table_set_stride : (folded ? a.PTfold : a.PT)) +
+                                s_key[oi * 2 + ch] + row_lo;
             double fac[G][NRT_W];
             if (errleaf && a.err_banded) {
 #pragma unroll
@@ -870,12 +883,12 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                         fac[g][j] = v;
                     }
                 }
-            } else if (op.kind[ch] == 0 && !errleaf) {
+            } else if (op.kind[ch] != 1 && !errleaf) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const int f = fbase + 4 * g + lk;
                     const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
-                    const bool ok = cnt <= cmx[g];
+                    const bool ok = from_table || cnt <= cmx[g];
                     const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
                     for (int j = 0; j < NRT_W; ++j) fac[g][j] = (ok && j < ntile) ? col[j * 16] : 0.0;
@@ -969,4 +982,98 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     k2_release_park_slot(a, s_colmax + a.NF, tid);
     k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
+}
+
+
+// ====================================================================================
+// k2c_nodes -- factor tables of compressed subtrees (schedule.hpp, CNode), one launch per level.
+// A workgroup owns 16 states of one node: it forms their node vectors in LDS, L[state][k] = F_a[k] * F_b[k] with
+// F_x a matrix column (leaf child: PT[count], folded with the error model where the leaf carries one) or a row of
+// the child's table, multiplies them by the node's own edge matrix with the walk's edge product (same k order, same
+// instruction: the table rows are bit-identical to the factors the uncompressed walk forms in registers) and stores
+// rows [0, C) of the result as table[state][row]; the consumer adds the root offset exactly as for a leaf column.
+// 16x16x4 shape, one 16-state tile, Wr = blockDim.x / 64 wave rows of NRT_W row tiles.
+// ====================================================================================
+struct K2cArgs {
+    const double* PT;
+    const double* PTfold;             // or NULL
+    const EvalParams* ep;
+    const cafehip::CNode* nodes;
+    const cafehip::CTile* tiles;      // this level's tiles
+    const int32_t* cidx;              // child indices of every compressed node's states
+    const uint8_t* leaf_has_err;      // by count-table column, or NULL
+    double* tables;
+    size_t table_set_stride;
+    int C, LD, KP, LDv, ksteps;
+};
+
+template <int NRT_W>
+__global__ __launch_bounds__(512) void k2c_nodes(K2cArgs a)
+{
+    extern __shared__ double Lbuf[];   // [16][LDv]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const cafehip::CTile tile = a.tiles[blockIdx.x];
+    const cafehip::CNode nd = a.nodes[tile.cnode];
+    const int set = blockIdx.y;
+    double* const tab = a.tables + (size_t)set * a.table_set_stride;
+    {
+        const int per_state = blockDim.x >> 4;
+        const int f = tid / per_state, l = tid - f * per_state;
+        const int s = tile.state0 + f;
+        bool live = s < nd.D;
+        const double* col[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int idx = live ? a.cidx[nd.idx_off + ch * nd.D + s] : 0;
+            const double* base;
+            if (nd.kind[ch] == 0) {
+                const bool folded = a.PTfold != nullptr && a.leaf_has_err[nd.leafcol[ch]];
+                base = (folded ? a.PTfold : a.PT) + (size_t)a.ep->node_key[set][nd.child[ch]] * a.KP * a.LD;
+                live = live && idx <= a.C - 1;   // a count beyond the column range: no such column (cafe/cafe_tree.c:208-209)
+            } else {
+                base = tab + nd.tab_off[ch];
+            }
+            col[ch] = base + (size_t)idx * a.LD;
+        }
+        double* L = Lbuf + (size_t)f * a.LDv;
+        for (int k = l; k < a.LDv; k += per_state) L[k] = (live && k < a.C) ? col[0][k] * col[1][k] : 0.0;
+    }
+    __syncthreads();
+    const int Wr = blockDim.x >> 6;
+    const int RT = (a.C + 15) >> 4;
+    const int rt_base = RT / Wr, rt_rem = RT - rt_base * Wr;
+    const int ntile = rt_base + (wave < rt_rem ? 1 : 0);
+    const int rt0 = wave * rt_base + min(wave, rt_rem);
+    cafe_d4 fac[1][NRT_W];
+#pragma unroll
+    for (int j = 0; j < NRT_W; ++j) fac[0][j] = cafe_d4{0.0, 0.0, 0.0, 0.0};
+    if (ntile > 0) {
+        unsigned voff[NRT_W];
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j) voff[j] = (unsigned)(lk * a.LD + li + ((j < ntile) ? (rt0 + j) : rt0) * 16) * 8u;
+        const k2_gbytes sb = k2_uniform(a.PT + (size_t)a.ep->node_key[set][nd.node] * a.KP * a.LD);
+        const double* ap = Lbuf + (size_t)li * a.LDv + lk;
+        const unsigned kstride_bytes = 32u * (unsigned)a.LD;
+        if constexpr (NRT_W > 1) {
+            if (ntile == NRT_W - 1)
+                mfma_edge_p<1, NRT_W, NRT_W - 1, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+            else
+                mfma_edge_p<1, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+        } else {
+            mfma_edge_p<1, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+        }
+    }
+    double* const out = tab + nd.out_off;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int s = tile.state0 + lk + 4 * r;
+        if (s >= nd.D) continue;
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j) {
+            if (j < ntile) {
+                const int row = (rt0 + j) * 16 + li;
+                out[(size_t)s * a.LD + row] = (row < a.C) ? fac[0][j][r] : 0.0;
+            }
+        }
+    }
 }

@@ -152,8 +152,9 @@ struct MfmaOp {
     int32_t node;
     int32_t is_root;
     int32_t child[2];     // child node ids, in processing order
-    int32_t kind[2];      // 0 = leaf (column gather), 1 = internal (vector in LDS or parked)
-    int32_t leafcol[2];   // count-table column for leaves
+    int32_t kind[2];      // 0 = leaf (column gather), 1 = internal (vector in LDS or parked),
+                          // 2 = compressed subtree (row gather from its factor table, see CNode)
+    int32_t leafcol[2];   // count-table column for leaves / state-id column for compressed subtrees
     int32_t src_park[2];  // internal child: -1 = vector is in the LDS buffer, else park index
     int32_t dst_park;     // -1 = keep the result in the LDS buffer, else park index
     int32_t pad;
@@ -164,10 +165,17 @@ struct MfmaSchedule {
     int n_parks = 0;
 };
 
-inline MfmaSchedule build_mfma_schedule(int n_nodes, int root, const std::vector<int>& left,
-                                        const std::vector<int>& right)
+// `leafcol_of` (optional): the walk of a REDUCED tree -- a node v with leafcol_of[v] >= 0 is a leaf of the walk
+// whatever its children: an original leaf (kind 0) or the root of a compressed subtree (kind 2), its index column
+// in the walk's count table being leafcol_of[v].  Without it the leaves are the tree's (column = node id / 2).
+inline MfmaSchedule build_mfma_schedule(int n_nodes, int root, const std::vector<int>& left_in,
+                                        const std::vector<int>& right_in, const std::vector<int>* leafcol_of = nullptr)
 {
     MfmaSchedule sch;
+    std::vector<int> left = left_in, right = right_in;
+    if (leafcol_of)
+        for (int v = 0; v < n_nodes; ++v)
+            if ((*leafcol_of)[v] >= 0) left[v] = right[v] = -1;
     // parks needed by each subtree
     std::vector<int> need(n_nodes, 0);
     std::vector<int> post;
@@ -253,8 +261,8 @@ inline MfmaSchedule build_mfma_schedule(int n_nodes, int root, const std::vector
             op.src_park[c] = -1;
             op.leafcol[c] = 0;
             if (!internal(ch[c])) {
-                op.kind[c] = 0;
-                op.leafcol[c] = ch[c] / 2;
+                op.kind[c] = (left_in[ch[c]] < 0) ? 0 : 2;
+                op.leafcol[c] = leafcol_of ? (*leafcol_of)[ch[c]] : ch[c] / 2;
             } else {
                 op.kind[c] = 1;
                 if (ch[c] != in_lds) {
@@ -284,5 +292,31 @@ inline MfmaSchedule build_mfma_schedule(int n_nodes, int root, const std::vector
     sch.n_parks = next_park;
     return sch;
 }
+
+
+// ---------------------------------------------------------------------------------
+// Subtree-state compression.  The vector of an internal node depends on the family only through the counts at the
+// leaves below it; families that agree there share the vector, and its product with the node's edge matrix.  A
+// COMPRESSED node v has D_v distinct states (tuples of its children's states; a leaf's state is its count) among
+// the table's unique rows, few enough that the factor M_v . L_v is built once per state into a table
+// [D_v][LD] (k2c_nodes, one launch per level, children before parents) and the family walk gathers row
+// state_v(family) from it exactly as it gathers a matrix column for a one-hot leaf.  Same products on the same
+// operands in the same order: bit-identical to the uncompressed walk.
+// ---------------------------------------------------------------------------------
+struct CNode {
+    int32_t node;        // tree node (the table holds the factor along ITS branch)
+    int32_t D;           // distinct states
+    int32_t child[2];
+    int32_t kind[2];     // 0 = leaf (index = count), 2 = compressed child (index = the child's state)
+    int32_t leafcol[2];  // leaf: column of the count table (error-model flag)
+    int32_t tab_off[2];  // compressed child: element offset of its table
+    int32_t idx_off;     // index array: child 0 at [idx_off, idx_off + D), child 1 at [idx_off + D, idx_off + 2 D)
+    int32_t out_off;     // element offset of this node's table
+};
+
+struct CTile {
+    int32_t cnode;       // index into the CNode array
+    int32_t state0;      // first state of the tile
+};
 
 }  // namespace cafehip

@@ -160,6 +160,12 @@ class Engine:
         _lib.check(self._L.cafehip_launch_info(self._h, C.byref(wg), C.byref(cu)))
         return wg.value, cu.value
 
+    def last_issued_flops(self):
+        """(walk, tables): matrix-instruction flops issued by the last objective evaluation's pruning."""
+        w, t = C.c_double(), C.c_double()
+        _lib.check(self._L.cafehip_last_issued_flops(self._h, C.byref(w), C.byref(t)))
+        return w.value, t.value
+
     def eval_posterior_async(self, node_lambda, node_mu, prior, d_chunk_sums_ptr, d_first_zero_ptr):
         nl = np.ascontiguousarray(node_lambda, np.float64)
         nm = np.ascontiguousarray(node_mu, np.float64)

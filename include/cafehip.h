@@ -131,6 +131,13 @@ int cafehip_eval_clustered_posterior(cafehip_ctx *ctx, int K, const double *node
 /* Workgroups of the last pruning launch and the device's compute units (how full a single evaluation makes the chip). */
 int cafehip_launch_info(cafehip_ctx *ctx, int *k2_workgroups, int *compute_units);
 
+/* Matrix-instruction flops issued by the pruning of the last objective evaluation (tile padding included), for
+ * roofline accounting: `walk` = the family walk (one product per internal child edge of the walked tree and family
+ * slot), `tables` = the factor tables of compressed subtrees (families that agree on the counts below a node share
+ * its vector; the library builds the product with the node's edge matrix once per distinct state -- bit-identical
+ * values, less work; CAFEHIP_COMPRESS=0 disables).  No reference counterpart. */
+int cafehip_last_issued_flops(cafehip_ctx *ctx, double *walk, double *tables);
+
 /* Same evaluation, but nothing is copied back and nothing synchronises: the
  * per-chunk partial sums (cafehip_num_chunks doubles; chunk c covers families
  * [c*CAFEHIP_CHUNK, (c+1)*CAFEHIP_CHUNK)) and the first-zero index (INT32_MAX if

@@ -1,0 +1,104 @@
+"""Subtree-state compression of the objective path (cafe_amd/csrc/schedule.hpp, CNode): families that agree on the
+counts below a node share its vector, so the product with the node's edge matrix is built once per distinct state
+and the family walk gathers it.  The values must be BIT-identical to the uncompressed walk (same products, same
+order), with and without a folded error model, for one and several parameter sets."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _orc as O
+
+pytestmark = pytest.mark.gpu
+
+NEWICK = "(((a:6,b:6):5,(c:4,(d:2,e:2):2):7):9,((f:3,g:3):8,h:11):9)"
+
+
+def _table(F, n, seed, top=9):
+    rs = np.random.RandomState(seed)
+    counts = rs.poisson(2.2, size=(F, n)).clip(0, top).astype(np.int32)
+    counts[0] = 0
+    counts[1] = top
+    return counts
+
+
+def _run(compress, counts, t, rng_tuple, lam, mu, prior, err=None, sets=None):
+    import cafe_amd
+    os.environ["CAFEHIP_COMPRESS"] = "1" if compress else "0"
+    try:
+        eng = cafe_amd.Engine(0)
+        try:
+            eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+            eng.set_families(counts, cafe_amd.FamilySizeRange(*rng_tuple))
+            if err is not None:
+                eng.set_error_model(err)
+            if sets is None:
+                out = eng.get_posterior(lam, mu, prior, per_family=True)
+            else:
+                out = eng.get_posterior_multi(sets[0], sets[1], prior)
+            return out, eng.describe(), eng.last_issued_flops()
+        finally:
+            eng.close()
+    finally:
+        os.environ.pop("CAFEHIP_COMPRESS", None)
+
+
+@pytest.mark.parametrize("model", ["lambda", "lambdamu"])
+@pytest.mark.parametrize("with_error", [False, True])
+def test_compressed_walk_is_bit_identical_and_matches_the_oracle(model, with_error):
+    t = O.PyTree(NEWICK)
+    F = 6000
+    counts = _table(F, t.n_leaves, 11)
+    rng_tuple = (0, 40, 1, 30)
+    rng = O.make_range(*rng_tuple)
+    prior = O.prior_poisson(1000, 1, 2.0)
+    lam = np.full(t.n_nodes, 0.02)
+    mu = np.full(t.n_nodes, 0.013 if model == "lambdamu" else -1.0)
+    err = None
+    if with_error:
+        from cafe_amd import synth
+        err = synth.banded_error_matrix(rng_tuple[1])
+    (s1, fz1, ml1, am1, mp1), d1, (w1, tb1) = _run(True, counts, t, rng_tuple, lam, mu, prior, err)
+    (s0, fz0, ml0, am0, mp0), d0, (w0, tb0) = _run(False, counts, t, rng_tuple, lam, mu, prior, err)
+    assert "compressed(" in d1 and "used=1" in d1, d1
+    assert "compressed(" not in d0
+    assert tb1 > 0 and tb0 == 0 and w1 + tb1 < w0, (w1, tb1, w0)      # less matrix work, same values:
+    assert s1 == s0 and fz1 == fz0
+    assert np.array_equal(ml1, ml0) and np.array_equal(mp1, mp0) and np.array_equal(am1, am0)
+    if not with_error:
+        so, fzo, mlo, amo, mpo = O.eval_posterior(t, counts, rng, lam, mu, prior, nthreads=os.cpu_count() or 1)
+        nz = mlo > 0
+        assert np.max(np.abs(ml1[nz] - mlo[nz]) / mlo[nz]) < 1e-9
+        assert np.max(np.abs(mp1[nz] - mpo[nz]) / mpo[nz]) < 1e-9
+        assert abs(s1 - so) <= 1e-9 * abs(so)
+
+
+def test_compressed_walk_with_several_parameter_sets():
+    t = O.PyTree(NEWICK)
+    counts = _table(5000, t.n_leaves, 12)
+    rng_tuple = (0, 40, 1, 30)
+    prior = O.prior_poisson(1000, 1, 2.0)
+    K = 3
+    lams = np.stack([np.full(t.n_nodes, 0.01 * (k + 1)) for k in range(K)])
+    mus = np.full((K, t.n_nodes), -1.0)
+    out1, d1, _ = _run(True, counts, t, rng_tuple, None, None, prior, sets=(lams, mus))
+    out0, d0, _ = _run(False, counts, t, rng_tuple, None, None, prior, sets=(lams, mus))
+    assert "used=1" in d1, d1
+    for x, y in zip(out1, out0):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_small_tables_and_incompressible_tables_are_left_alone():
+    import cafe_amd
+    t = O.PyTree(NEWICK)
+    eng = cafe_amd.Engine(0)
+    try:
+        eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+        eng.set_families(_table(300, t.n_leaves, 13), cafe_amd.FamilySizeRange(0, 40, 1, 30))
+        assert "compressed(" not in eng.describe()
+        rs = np.random.RandomState(5)
+        wide = rs.randint(0, 200, size=(3000, t.n_leaves)).astype(np.int32)     # every pair of counts distinct
+        eng.set_families(wide, cafe_amd.FamilySizeRange(0, 260, 1, 250))
+        assert "compressed(" not in eng.describe()
+    finally:
+        eng.close()
