@@ -933,7 +933,7 @@ struct cafehip_ctx {
     bool k2_used_mfma = false;
     bool k2_shape4 = false;
 
-    // subtree-state compression of the objective path (schedule.hpp, CNode; rebuilt by set_tree / set_families)
+    // subtree-state compression of the objective path (schedule.hpp, CTile; rebuilt by set_tree / set_families)
     struct CompressPlan {
         bool valid = false;
         cafehip::MfmaSchedule sched;        // walk of the reduced tree (compressed subtrees are leaves)
@@ -942,12 +942,11 @@ struct cafehip_ctx {
         std::vector<int> col_leaf;          // per column: count-table column of the leaf, or -1 (compressed subtree)
         int32_t* d_counts = nullptr;        // [Fu][n_cols]
         uint8_t* d_col_has_err = nullptr;   // [n_cols]
-        std::vector<cafehip::CNode> nodes;
+        int n_nodes = 0;                    // compressed nodes
         std::vector<cafehip::CTile> tiles;
         std::vector<int> level_first;       // tiles of level l: [level_first[l], level_first[l + 1])
-        cafehip::CNode* d_nodes = nullptr;
+        std::vector<int> level_nft;         // ... of 16 * level_nft[l] states each
         cafehip::CTile* d_tiles = nullptr;
-        int32_t* d_cidx = nullptr;
         int32_t* d_table_off = nullptr;     // [n_nodes]
         size_t table_elems = 0;             // per parameter set
         double* d_tables = nullptr;
@@ -1310,9 +1309,7 @@ void free_compression(cafehip_ctx* c)
     hipFree(p.d_ops);
     hipFree(p.d_counts);
     hipFree(p.d_col_has_err);
-    hipFree(p.d_nodes);
     hipFree(p.d_tiles);
-    hipFree(p.d_cidx);
     hipFree(p.d_table_off);
     hipFree(p.d_tables);
     p = cafehip_ctx::CompressPlan();
@@ -1330,13 +1327,14 @@ int upload_col_has_err(cafehip_ctx* c)
     return 0;
 }
 
-// wave rows / row tiles of k2c_nodes for this matrix side (0: too large, no compression)
+// wave rows / row tiles per wave of k2c_nodes for this matrix side: one wave per row tile up to 16 waves
+// (0: matrix too large, no compression)
 int k2c_wave_rows(const cafehip_ctx* c, int* nrt_w)
 {
     const int RT = (c->C + 15) / 16;
-    const int wr = RT <= 28 ? 4 : 8;
+    const int wr = std::min(RT, 16);
     *nrt_w = (RT + wr - 1) / wr;
-    return *nrt_w <= 7 ? wr : 0;
+    return *nrt_w <= 2 ? wr : 0;   // (matrix sides up to 512; beyond, the plain walk)
 }
 
 // (Re)build the plan from the tree and the unique rows.  A node is compressed when both children are leaves or
@@ -1433,31 +1431,37 @@ int rebuild_compression(cafehip_ctx* c)
         }
     if (elems >= ((size_t)1 << 31) || n_idx >= ((size_t)1 << 31)) { p = cafehip_ctx::CompressPlan(); return 0; }
     p.table_elems = elems;
-    // nodes and tiles, level by level
-    std::vector<int32_t> cidx;
-    cidx.reserve(n_idx);
+    // tiles, level by level (children's tables are complete before a level starts)
     p.level_first.assign(1, 0);
+    p.level_nft.clear();
     for (int l = 1; l <= n_levels; ++l) {
+            // 16 states per tile: 32- and 64-state tiles (a half / a quarter of the workgroups and of the matrix re-reads)
+        // measured 4-8 % slower at every bench shape -- fewer, longer workgroups fill the chip worse
+        const int nft = 1;
+        const int ts = 16 * nft;
         for (int v = 0; v < n; ++v) {
             if (!comp[v] || level[v] != l) continue;
-            cafehip::CNode nd{};
-            nd.node = v;
-            nd.D = D[v];
+            ++p.n_nodes;
             const int ch[2] = {left[v], right[v]};
-            for (int k = 0; k < 2; ++k) {
-                nd.child[k] = ch[k];
-                nd.kind[k] = internal(ch[k]) ? 2 : 0;
-                nd.leafcol[k] = internal(ch[k]) ? 0 : ch[k] / 2;
-                nd.tab_off[k] = internal(ch[k]) ? table_off[ch[k]] : 0;
+            for (int s0 = 0; s0 < D[v]; s0 += ts) {
+                cafehip::CTile t{};
+                t.node = v;
+                t.state0 = s0;
+                t.n_live = std::min(ts, D[v] - s0);
+                t.out_off = table_off[v];
+                for (int k = 0; k < 2; ++k) {
+                    t.child[k] = ch[k];
+                    t.kind[k] = internal(ch[k]) ? 2 : 0;
+                    t.leafcol[k] = internal(ch[k]) ? 0 : ch[k] / 2;
+                    t.tab_off[k] = internal(ch[k]) ? table_off[ch[k]] : 0;
+                    const auto& ix = k ? idx1[v] : idx0[v];
+                    for (int f = 0; f < t.n_live; ++f) t.idx[k][f] = ix[s0 + f];
+                }
+                p.tiles.push_back(t);
             }
-            nd.idx_off = (int32_t)cidx.size();
-            cidx.insert(cidx.end(), idx0[v].begin(), idx0[v].end());
-            cidx.insert(cidx.end(), idx1[v].begin(), idx1[v].end());
-            nd.out_off = table_off[v];
-            for (int s0 = 0; s0 < D[v]; s0 += 16) p.tiles.push_back(cafehip::CTile{(int32_t)p.nodes.size(), s0});
-            p.nodes.push_back(nd);
         }
         p.level_first.push_back((int)p.tiles.size());
+        p.level_nft.push_back(nft);
     }
     // the reduced tree's leaves and the walk's index table
     std::vector<char> under(n, 0);   // strictly below a compressed node
@@ -1487,23 +1491,20 @@ int rebuild_compression(cafehip_ctx* c)
     HIP_TRY(hipMemcpy(p.d_ops, p.sched.ops.data(), p.sched.ops.size() * sizeof(cafehip::MfmaOp), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&p.d_counts, wc.size() * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(p.d_counts, wc.data(), wc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&p.d_nodes, p.nodes.size() * sizeof(cafehip::CNode)));
-    HIP_TRY(hipMemcpy(p.d_nodes, p.nodes.data(), p.nodes.size() * sizeof(cafehip::CNode), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&p.d_tiles, p.tiles.size() * sizeof(cafehip::CTile)));
     HIP_TRY(hipMemcpy(p.d_tiles, p.tiles.data(), p.tiles.size() * sizeof(cafehip::CTile), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&p.d_cidx, std::max<size_t>(cidx.size(), 1) * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(p.d_cidx, cidx.data(), cidx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&p.d_table_off, n * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(p.d_table_off, table_off.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
     p.valid = true;
     return upload_col_has_err(c);
 }
 
-template <int NRT_W>
-int launch_k2c_inst(cafehip_ctx* c, const K2cArgs& a, int grid, int n_sets, int block, size_t lds)
+template <int NFT_W, int NRT_W>
+int launch_k2c_inst(cafehip_ctx* c, const K2cArgs& a, int grid, int n_sets, int block)
 {
-    if (grant_lds(c, reinterpret_cast<const void*>(&k2c_nodes<NRT_W>), lds, 64 * 1024)) return -1;
-    hipLaunchKernelGGL(k2c_nodes<NRT_W>, dim3(grid, n_sets), dim3(block), lds, c->stream, a);
+    const size_t lds = (size_t)16 * NFT_W * c->LDv * sizeof(double);
+    if (grant_lds(c, reinterpret_cast<const void*>(&k2c_nodes<NFT_W, NRT_W>), lds, 64 * 1024)) return -1;
+    hipLaunchKernelGGL((k2c_nodes<NFT_W, NRT_W>), dim3(grid, n_sets), dim3(block), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1531,8 +1532,6 @@ int launch_compressed_levels(cafehip_ctx* c, int n_sets)
     a.PT = c->d_PT;
     a.PTfold = (c->d_err && c->fold_current) ? c->d_PTfold : nullptr;
     a.ep = c->d_params;
-    a.nodes = p.d_nodes;
-    a.cidx = p.d_cidx;
     a.leaf_has_err = c->d_leaf_has_err;
     a.tables = p.d_tables;
     a.table_set_stride = p.table_elems;
@@ -1541,25 +1540,21 @@ int launch_compressed_levels(cafehip_ctx* c, int n_sets)
     a.KP = c->KP;
     a.LDv = c->LDv;
     a.ksteps = (c->C + 3) / 4;
-    const size_t lds = (size_t)16 * c->LDv * sizeof(double);
+    double slots = 0;   // 16-state tiles issued (padding of the last tile of a node included)
     for (size_t l = 0; l + 1 < p.level_first.size(); ++l) {
         const int first = p.level_first[l], n_tiles = p.level_first[l + 1] - first;
         if (n_tiles <= 0) continue;
         a.tiles = p.d_tiles + first;
+        const int nft = p.level_nft[l];
+        slots += (double)n_tiles * nft;
         int rc = -1;
-        switch (nrt_w) {
-            case 1: rc = launch_k2c_inst<1>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
-            case 2: rc = launch_k2c_inst<2>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
-            case 3: rc = launch_k2c_inst<3>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
-            case 4: rc = launch_k2c_inst<4>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
-            case 5: rc = launch_k2c_inst<5>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
-            case 6: rc = launch_k2c_inst<6>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
-            case 7: rc = launch_k2c_inst<7>(c, a, n_tiles, n_sets, 64 * wr, lds); break;
-        }
-        if (rc) return rc;
+#define CAFE_K2C(NFT, NRT) if (nft == NFT && nrt_w == NRT) rc = launch_k2c_inst<NFT, NRT>(c, a, n_tiles, n_sets, 64 * wr);
+        CAFE_K2C(1, 1) CAFE_K2C(1, 2)
+#undef CAFE_K2C
+        if (rc) return rc < 0 ? rc : fail("internal: no k2c_nodes<%d,%d>", nft, nrt_w);
     }
     const double kpad = 4.0 * ((c->C + 3) / 4), rows = 16.0 * ((c->C + 15) / 16);
-    c->issued_tables = 2.0 * kpad * rows * 16.0 * (double)p.tiles.size() * n_sets;
+    c->issued_tables = 2.0 * kpad * rows * 16.0 * slots * n_sets;
     return 0;
 }
 
@@ -3102,7 +3097,7 @@ const char* cafehip_describe(cafehip_ctx* c)
              c->k2_cfg[2], c->k2_cfg[3], c->k2_grid, c->k2_park_slots);
     c->desc = buf;
     if (c->cp.valid) {
-        snprintf(buf, sizeof buf, " compressed(nodes=%zu levels=%zu states=%ld walk_steps=%zu walk_cols=%d used=%d)", c->cp.nodes.size(),
+        snprintf(buf, sizeof buf, " compressed(nodes=%d levels=%zu states=%ld walk_steps=%zu walk_cols=%d used=%d)", c->cp.n_nodes,
                  c->cp.level_first.size() - 1, c->cp.states, c->cp.sched.ops.size(), c->cp.n_cols, (int)c->last_compressed);
         c->desc += buf;
     }

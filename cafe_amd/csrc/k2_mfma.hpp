@@ -59,7 +59,7 @@ struct K2MfmaArgs {
     double* max_lik;
     int32_t* argmax;
     double* max_post;
-    // compressed subtrees (schedule.hpp, CNode): factor tables [set][node table][state][LD], rows gathered like
+    // compressed subtrees (schedule.hpp, CTile): factor tables [set][node table][state][LD], rows gathered like
     // matrix columns by a child of kind 2; table_off[node] = element offset of the node's table
     const double* tables;
     const int32_t* table_off;
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 
 
 // ====================================================================================
-// k2c_nodes -- factor tables of compressed subtrees (schedule.hpp, CNode), one launch per level.
+// k2c_nodes -- factor tables of compressed subtrees (schedule.hpp, CTile), one launch per level.
 // A workgroup owns 16 states of one node: it forms their node vectors in LDS, L[state][k] = F_a[k] * F_b[k] with
 // F_x a matrix column (leaf child: PT[count], folded with the error model where the leaf carries one) or a row of
 // the child's table, multiplies them by the node's own edge matrix with the walk's edge product (same k order, same
@@ -998,45 +998,54 @@ struct K2cArgs {
     const double* PT;
     const double* PTfold;             // or NULL
     const EvalParams* ep;
-    const cafehip::CNode* nodes;
     const cafehip::CTile* tiles;      // this level's tiles
-    const int32_t* cidx;              // child indices of every compressed node's states
     const uint8_t* leaf_has_err;      // by count-table column, or NULL
     double* tables;
     size_t table_set_stride;
     int C, LD, KP, LDv, ksteps;
 };
 
-template <int NRT_W>
-__global__ __launch_bounds__(512) void k2c_nodes(K2cArgs a)
+// A level is a few hundred workgroups: one or two waves per SIMD, nothing to switch to while an operand is in flight,
+// so the rings are deep and a tile's rows are spread over as many waves as it has row tiles (up to 16).  A tile holds
+// 16 * NFT_W states; the launcher uses NFT_W = 1 (larger tiles measured slower).
+#ifndef CAFE_K2C_DEPTH
+#define CAFE_K2C_DEPTH 6
+#endif
+template <int NFT_W, int NRT_W>
+__global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
 {
-    extern __shared__ double Lbuf[];   // [16][LDv]
+    extern __shared__ double Lbuf[];   // [16 * NFT_W][LDv]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
-    const cafehip::CTile tile = a.tiles[blockIdx.x];
-    const cafehip::CNode nd = a.nodes[tile.cnode];
+    const cafehip::CTile& t = a.tiles[blockIdx.x];
     const int set = blockIdx.y;
     double* const tab = a.tables + (size_t)set * a.table_set_stride;
+    const int node = t.node, n_live = t.n_live;
     {
-        const int per_state = blockDim.x >> 4;
-        const int f = tid / per_state, l = tid - f * per_state;
-        const int s = tile.state0 + f;
-        bool live = s < nd.D;
-        const double* col[2];
+        // L[state][k] = F_a[k] * F_b[k]
+        const double* base[2];
+        bool leaf[2];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            const int idx = live ? a.cidx[nd.idx_off + ch * nd.D + s] : 0;
-            const double* base;
-            if (nd.kind[ch] == 0) {
-                const bool folded = a.PTfold != nullptr && a.leaf_has_err[nd.leafcol[ch]];
-                base = (folded ? a.PTfold : a.PT) + (size_t)a.ep->node_key[set][nd.child[ch]] * a.KP * a.LD;
-                live = live && idx <= a.C - 1;   // a count beyond the column range: no such column (cafe/cafe_tree.c:208-209)
+            leaf[ch] = t.kind[ch] == 0;
+            if (leaf[ch]) {
+                const bool folded = a.PTfold != nullptr && a.leaf_has_err[t.leafcol[ch]];
+                base[ch] = (folded ? a.PTfold : a.PT) + (size_t)a.ep->node_key[set][t.child[ch]] * a.KP * a.LD;
             } else {
-                base = tab + nd.tab_off[ch];
+                base[ch] = tab + t.tab_off[ch];
             }
-            col[ch] = base + (size_t)idx * a.LD;
         }
-        double* L = Lbuf + (size_t)f * a.LDv;
-        for (int k = l; k < a.LDv; k += per_state) L[k] = (live && k < a.C) ? col[0][k] * col[1][k] : 0.0;
+        // blockDim / states threads per state (all threads busy; contiguous runs of both columns)
+        const int per_state = blockDim.x / (16 * NFT_W);
+        const int f = tid / per_state, l = tid - f * per_state;
+        if (f < 16 * NFT_W) {
+            const int i0 = t.idx[0][f], i1 = t.idx[1][f];
+            // a count beyond the column range: no such column (cafe/cafe_tree.c:208-209)
+            const bool live = f < n_live && !(leaf[0] && i0 > a.C - 1) && !(leaf[1] && i1 > a.C - 1);
+            const double* c0 = base[0] + (size_t)(live ? i0 : 0) * a.LD;
+            const double* c1 = base[1] + (size_t)(live ? i1 : 0) * a.LD;
+            double* L = Lbuf + (size_t)f * a.LDv;
+            for (int k = l; k < a.LDv; k += per_state) L[k] = (live && k < a.C) ? c0[k] * c1[k] : 0.0;
+        }
     }
     __syncthreads();
     const int Wr = blockDim.x >> 6;
@@ -1044,35 +1053,40 @@ __global__ __launch_bounds__(512) void k2c_nodes(K2cArgs a)
     const int rt_base = RT / Wr, rt_rem = RT - rt_base * Wr;
     const int ntile = rt_base + (wave < rt_rem ? 1 : 0);
     const int rt0 = wave * rt_base + min(wave, rt_rem);
-    cafe_d4 fac[1][NRT_W];
+    cafe_d4 fac[NFT_W][NRT_W];
 #pragma unroll
-    for (int j = 0; j < NRT_W; ++j) fac[0][j] = cafe_d4{0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < NFT_W; ++i)
+#pragma unroll
+        for (int j = 0; j < NRT_W; ++j) fac[i][j] = cafe_d4{0.0, 0.0, 0.0, 0.0};
     if (ntile > 0) {
         unsigned voff[NRT_W];
 #pragma unroll
         for (int j = 0; j < NRT_W; ++j) voff[j] = (unsigned)(lk * a.LD + li + ((j < ntile) ? (rt0 + j) : rt0) * 16) * 8u;
-        const k2_gbytes sb = k2_uniform(a.PT + (size_t)a.ep->node_key[set][nd.node] * a.KP * a.LD);
+        const k2_gbytes sb = k2_uniform(a.PT + (size_t)a.ep->node_key[set][node] * a.KP * a.LD);
         const double* ap = Lbuf + (size_t)li * a.LDv + lk;
         const unsigned kstride_bytes = 32u * (unsigned)a.LD;
         if constexpr (NRT_W > 1) {
             if (ntile == NRT_W - 1)
-                mfma_edge_p<1, NRT_W, NRT_W - 1, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+                mfma_edge_p<NFT_W, NRT_W, NRT_W - 1, CAFE_K2C_DEPTH>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
             else
-                mfma_edge_p<1, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+                mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2C_DEPTH>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
         } else {
-            mfma_edge_p<1, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+            mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2C_DEPTH>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
         }
     }
-    double* const out = tab + nd.out_off;
+    double* const out = tab + t.out_off + (size_t)t.state0 * a.LD;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int s = tile.state0 + lk + 4 * r;
-        if (s >= nd.D) continue;
+    for (int i = 0; i < NFT_W; ++i) {
 #pragma unroll
-        for (int j = 0; j < NRT_W; ++j) {
-            if (j < ntile) {
-                const int row = (rt0 + j) * 16 + li;
-                out[(size_t)s * a.LD + row] = (row < a.C) ? fac[0][j][r] : 0.0;
+        for (int r = 0; r < 4; ++r) {
+            const int f = i * 16 + lk + 4 * r;
+            if (f >= n_live) continue;
+#pragma unroll
+            for (int j = 0; j < NRT_W; ++j) {
+                if (j < ntile) {
+                    const int row = (rt0 + j) * 16 + li;
+                    out[(size_t)f * a.LD + row] = (row < a.C) ? fac[i][j][r] : 0.0;
+                }
             }
         }
     }

@@ -299,24 +299,24 @@ inline MfmaSchedule build_mfma_schedule(int n_nodes, int root, const std::vector
 // leaves below it; families that agree there share the vector, and its product with the node's edge matrix.  A
 // COMPRESSED node v has D_v distinct states (tuples of its children's states; a leaf's state is its count) among
 // the table's unique rows, few enough that the factor M_v . L_v is built once per state into a table
-// [D_v][LD] (k2c_nodes, one launch per level, children before parents) and the family walk gathers row
+// [D_v][LD] (k2c_nodes: tiles of 16 states, one launch per level, children before parents) and the family walk gathers row
 // state_v(family) from it exactly as it gathers a matrix column for a one-hot leaf.  Same products on the same
 // operands in the same order: bit-identical to the uncompressed walk.
 // ---------------------------------------------------------------------------------
-struct CNode {
-    int32_t node;        // tree node (the table holds the factor along ITS branch)
-    int32_t D;           // distinct states
-    int32_t child[2];
-    int32_t kind[2];     // 0 = leaf (index = count), 2 = compressed child (index = the child's state)
-    int32_t leafcol[2];  // leaf: column of the count table (error-model flag)
-    int32_t tab_off[2];  // compressed child: element offset of its table
-    int32_t idx_off;     // index array: child 0 at [idx_off, idx_off + D), child 1 at [idx_off + D, idx_off + 2 D)
-    int32_t out_off;     // element offset of this node's table
-};
-
+// One workgroup's work in k2c_nodes, self-contained (one load instead of a tile -> node -> index chain of dependent
+// global round trips: a level is latency-bound): up to kCTileStates states of one compressed node.
+constexpr int kCTileStates = 64;
 struct CTile {
-    int32_t cnode;       // index into the CNode array
+    int32_t node;        // tree node whose edge matrix multiplies the vectors
     int32_t state0;      // first state of the tile
+    int32_t n_live;      // states in the tile (1 .. 16 * NFT_W of the level's launch)
+    int32_t out_off;     // element offset of the node's table
+    int32_t child[2];
+    int32_t kind[2];     // 0 = leaf, 2 = compressed child
+    int32_t leafcol[2];
+    int32_t tab_off[2];
+    int32_t pad[4];
+    int32_t idx[2][kCTileStates];  // per state of the tile: the children's counts / states
 };
 
 }  // namespace cafehip
