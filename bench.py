@@ -287,25 +287,42 @@ def main():
         grid = (F_local + nf - 1) // nf
         n_el = algorithmic_elements_per_family(tree.n_leaves, R, C)
         issued, useful = issued_mfma_flops_per_family(tree, R, C)
-        # every workgroup issues the matrix instructions of NF family slots, filled or not
-        issued_launch = issued * grid * nf
+        # every workgroup issues the matrix instructions of NF family slots, filled or not.  The library reports
+        # what the last evaluation issued: the family walk (of the REDUCED tree when the table compresses) and the
+        # factor tables of the compressed subtrees (cafehip_last_issued_flops); without compression the walk figure
+        # must equal the tree formula above
+        walk_fl, table_fl = eng.last_issued_flops()
+        compressed = table_fl > 0
+        if not compressed and abs(walk_fl - issued * grid * nf) > 1e-9 * walk_fl:
+            raise SystemExit("issued-flop accounting: library %.6g vs tree formula %.6g" % (walk_fl, issued * grid * nf))
+        issued_launch = walk_fl + table_fl
         achieved = issued_launch / (k2_ms * 1e-3) / 1e12
         frac = achieved / FP64_PEAK_TFLOPS
         if not frac <= 1.0:
             raise SystemExit("roofline fraction %.3f > 1: the flop accounting is wrong" % frac)
         out["roofline"] = {
             "bound": "mfma",
-            "kernel": "k2_prune_mfma4 (v_mfma_f64_4x4x4_4b)" if "mfma4x4" in desc else "k2_prune_mfma (v_mfma_f64_16x16x4)",
-            "kernel_does": "pruning of all families + posterior in one launch",
+            "kernel": ("k2_prune_mfma4 (v_mfma_f64_4x4x4_4b)" if "mfma4x4" in desc else "k2_prune_mfma (v_mfma_f64_16x16x4)") +
+                      (" + k2c_nodes (v_mfma_f64_16x16x4), the factor tables of compressed subtrees" if compressed else ""),
+            "kernel_does": "pruning of all families + posterior" + (": one k2c_nodes launch per compression level, then the "
+                           "walk of the reduced tree; the timed interval and the flops cover all of them" if compressed else " in one launch"),
             "achieved": achieved,
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": frac,
-            "flops_counted": "matrix-instruction flops ISSUED per launch, tile padding included: products on internal "
-                             "child edges only (one-hot leaf edges are column gathers), roundup16(rows) x roundup4(C) "
-                             "per product, NF family slots per workgroup x %d workgroups" % grid,
+            "flops_counted": "matrix-instruction flops ISSUED per evaluation, tile padding included: products on internal "
+                             "child edges only (one-hot leaf edges and compressed subtrees are gathers), roundup16(rows) x "
+                             "roundup4(C) per product, NF family slots per workgroup x %d workgroups%s" % (
+                                 grid, "; plus one product per 16-state tile of every compressed node" if compressed else ""),
             "issued_flops_per_launch": issued_launch,
+            "issued_flops_walk": walk_fl,
+            "issued_flops_tables": table_fl,
+            "uncompressed_walk_would_issue": issued * grid * nf,
+            "work_saved_by_subtree_state_compression": 1.0 - issued_launch / (issued * grid * nf),
             "useful_flops_per_launch": useful * F_local,
+            "useful_flops_note": "exact rows x C for every internal edge and family, i.e. what an uncompressed walk without "
+                                 "tile padding executes; with compression fewer are executed, so the two rates below are "
+                                 "NOT utilisations",
             "useful_TFLOP/s": useful * F_local / (k2_ms * 1e-3) / 1e12,
             "useful_frac": useful * F_local / (k2_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
             "families_per_launch": F_local,

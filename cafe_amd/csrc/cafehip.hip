@@ -1436,7 +1436,7 @@ int rebuild_compression(cafehip_ctx* c)
     p.level_nft.clear();
     for (int l = 1; l <= n_levels; ++l) {
             // 16 states per tile: 32- and 64-state tiles (a half / a quarter of the workgroups and of the matrix re-reads)
-        // measured 4-8 % slower at every bench shape -- fewer, longer workgroups fill the chip worse
+        // measured 2-30 % slower at every bench shape -- fewer, longer workgroups fill the chip worse
         const int nft = 1;
         const int ts = 16 * nft;
         for (int v = 0; v < n; ++v) {

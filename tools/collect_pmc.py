@@ -27,15 +27,26 @@ def run_pass(counter, cmd, out_dir, tag):
         raise RuntimeError("no rocpd database under " + d)
     db = sqlite3.connect(dbs[0])
     rows = db.execute("select name, counter_name, counter_value from pmc_events").fetchall()
-    agg = {}
+    agg, tables = {}, []
     for name, cn, v in rows:
-        if cn == counter and "k2_prune" in name:
+        if cn != counter:
+            continue
+        if "k2_prune" in name:
             agg.setdefault(name, []).append(v)
+        elif "k2c_nodes" in name:
+            tables.append(v)
     # the dominant kernel = the instantiation launched most often (the tuner's pick; the timed launches)
     name = max(agg, key=lambda k: len(agg[k]))
     vals = agg[name]
     tail = vals[len(vals) // 2:]          # steady state: the second half of its launches
-    return name, sum(tail) / len(tail), len(vals)
+    per_launch = sum(tail) / len(tail)
+    # the factor tables of compressed subtrees (k2c_nodes, one launch per level before EVERY walk launch of whatever
+    # instantiation): their mean per evaluation is added to the walk's
+    n_walks = sum(len(v) for v in agg.values())
+    per_eval_tables = sum(tables) / n_walks if tables and n_walks else 0.0
+    if per_eval_tables:
+        name += " + k2c_nodes"
+    return name, per_launch + per_eval_tables, len(vals)
 
 
 def main():
@@ -53,7 +64,7 @@ def main():
             "kernel": kname, "launches_seen": n, "fetch_kib_raw": fetch_kib, "fetch_kib_x2": 2.0 * fetch_kib,
             "write_kib": write_kib, "traffic_bytes": traffic,
             "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate runs), FETCH_SIZE x2 (gfx950), "
-                    "mean over the second half of the kernel's launches",
+                    "mean over the second half of the kernel's launches (+ the k2c_nodes launches of one evaluation where the table compresses)",
         }
         lines.append("%-22s %-60s launches %4d  FETCH_SIZE %12.1f KiB (x2 = %12.1f)  WRITE_SIZE %12.1f KiB  -> %.3f MB per launch"
                      % ("%s:%d:%s" % (cfg, F, kind), kname[:60], n, fetch_kib, 2 * fetch_kib, write_kib, traffic / 1e6))
