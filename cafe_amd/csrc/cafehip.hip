@@ -1338,7 +1338,8 @@ int k2c_wave_rows(const cafehip_ctx* c, int* nrt_w)
 }
 
 // (Re)build the plan from the tree and the unique rows.  A node is compressed when both children are leaves or
-// compressed and its distinct states number at most CAFEHIP_COMPRESS_THETA (default 0.5) of the unique rows;
+// compressed and its distinct states number at most CAFEHIP_COMPRESS_THETA (default 0.5, 0.7 for matrix sides >= 200) of
+// the unique rows;
 // CAFEHIP_COMPRESS=0 disables.  Tables with fewer than 1024 unique rows are left alone (nothing to win).
 int rebuild_compression(cafehip_ctx* c)
 {
@@ -1349,7 +1350,10 @@ int rebuild_compression(cafehip_ctx* c)
     if (n <= 0 || c->M < 0 || nl != (n + 1) / 2 || Fu < 1024 || (int)c->h_ucounts.size() != Fu * nl) return 0;
     int nrt_w = 0;
     if (k2c_wave_rows(c, &nrt_w) == 0) return 0;
-    double theta = 0.5;
+    // a table product costs more per state than a walk product per family (16-state tiles re-read the matrix: x1.5
+    // at a 151-wide matrix, x1.2 at 251) and every level is a launch: measured optimum 0.5 / 0.7 (sweep of 0.2..0.9
+    // at the bench shapes)
+    double theta = c->C < 200 ? 0.5 : 0.7;
     if (const char* e = getenv("CAFEHIP_COMPRESS_THETA")) theta = std::min(std::max(atof(e), 0.0), 1.0);
     const size_t limit = (size_t)(theta * Fu);
     const auto& left = c->left;
