@@ -192,7 +192,7 @@ def main():
         if not multi:
             score, fz = eng.get_posterior(nl, nm, prior)
             if timed:
-                kernel_ms.append(eng.last_kernel_ms())
+                kernel_ms.append(list(eng.last_kernel_ms()) + [eng.last_tables_ms()])
             return score
         eng.eval_posterior_async(nl, nm, prior, p_chunks, p_fz)
         # the one exchange step: a single RCCL all_gather of (chunk sums, first-zero index) per rank
@@ -201,7 +201,7 @@ def main():
         exchange_s[0] += time.perf_counter() - t_x
         exchange_s[1] += 1
         if timed:
-            kernel_ms.append(eng.last_kernel_ms())  # the exchange has synchronised the stream
+            kernel_ms.append(list(eng.last_kernel_ms()) + [eng.last_tables_ms()])  # the exchange has synchronised the stream
         return score
 
     def barrier():
@@ -280,8 +280,10 @@ def main():
         out["exchange_ms_per_step"] = exchange_ms
 
     if rank == 0 and kernel_ms:
-        km = np.array(kernel_ms)  # columns: K1 matrix build, K2 pruning+posterior, K3 score
+        km = np.array(kernel_ms)  # columns: K1 matrix build, K2 pruning+posterior (tables + walk), K3 score, tables alone
         k2_ms = float(km[:, 1].mean())
+        tables_ms = float(km[:, 3].mean())
+        walk_ms = k2_ms - tables_ms
         desc = eng.describe()
         nf = int(re.search(r"NF=(\d+)", desc).group(1))
         grid = (F_local + nf - 1) // nf
@@ -295,42 +297,55 @@ def main():
         compressed = table_fl > 0
         if not compressed and abs(walk_fl - issued * grid * nf) > 1e-9 * walk_fl:
             raise SystemExit("issued-flop accounting: library %.6g vs tree formula %.6g" % (walk_fl, issued * grid * nf))
-        issued_launch = walk_fl + table_fl
-        achieved = issued_launch / (k2_ms * 1e-3) / 1e12
+        achieved = walk_fl / (walk_ms * 1e-3) / 1e12
         frac = achieved / FP64_PEAK_TFLOPS
-        if not frac <= 1.0:
-            raise SystemExit("roofline fraction %.3f > 1: the flop accounting is wrong" % frac)
+        total_frac = (walk_fl + table_fl) / (k2_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+        if not (frac <= 1.0 and total_frac <= 1.0):
+            raise SystemExit("roofline fraction %.3f / %.3f > 1: the flop accounting is wrong" % (frac, total_frac))
         out["roofline"] = {
             "bound": "mfma",
-            "kernel": ("k2_prune_mfma4 (v_mfma_f64_4x4x4_4b)" if "mfma4x4" in desc else "k2_prune_mfma (v_mfma_f64_16x16x4)") +
-                      (" + k2c_nodes (v_mfma_f64_16x16x4), the factor tables of compressed subtrees" if compressed else ""),
-            "kernel_does": "pruning of all families + posterior" + (": one k2c_nodes launch per compression level, then the "
-                           "walk of the reduced tree; the timed interval and the flops cover all of them" if compressed else " in one launch"),
+            "kernel": "k2_prune_mfma4 (v_mfma_f64_4x4x4_4b)" if "mfma4x4" in desc else "k2_prune_mfma (v_mfma_f64_16x16x4)",
+            "kernel_does": "the family walk: pruning of all families + posterior in one launch" +
+                           (" over the REDUCED tree (compressed subtrees are row gathers from factor tables built by "
+                            "the k2c_nodes launches just before it: see factor_tables / pruning_total)" if compressed else ""),
             "achieved": achieved,
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": frac,
-            "flops_counted": "matrix-instruction flops ISSUED per evaluation, tile padding included: products on internal "
+            "flops_counted": "matrix-instruction flops ISSUED by the launch, tile padding included: products on internal "
                              "child edges only (one-hot leaf edges and compressed subtrees are gathers), roundup16(rows) x "
-                             "roundup4(C) per product, NF family slots per workgroup x %d workgroups%s" % (
-                                 grid, "; plus one product per 16-state tile of every compressed node" if compressed else ""),
-            "issued_flops_per_launch": issued_launch,
-            "issued_flops_walk": walk_fl,
-            "issued_flops_tables": table_fl,
-            "uncompressed_walk_would_issue": issued * grid * nf,
-            "work_saved_by_subtree_state_compression": 1.0 - issued_launch / (issued * grid * nf),
+                             "roundup4(C) per product, NF family slots per workgroup x %d workgroups" % grid,
+            "issued_flops_per_launch": walk_fl,
+            "avg_launch_ms": walk_ms,
+            "launch_samples": len(kernel_ms),
+            "launch_samples_in_timed_region": samples_in_region,
+            "min_launch_ms": float((km[:, 1] - km[:, 3]).min()),
+            "max_launch_ms": float((km[:, 1] - km[:, 3]).max()),
+            "families_per_launch": F_local,
+            "factor_tables": None if not compressed else {
+                "kernel": "k2c_nodes (v_mfma_f64_16x16x4): one launch per compression level, 16 states per workgroup",
+                "launches_per_evaluation": int(re.search(r"levels=(\d+)", desc).group(1)),
+                "states": int(re.search(r"states=(\d+)", desc).group(1)),
+                "ms_per_evaluation": tables_ms,
+                "issued_flops": table_fl,
+                "achieved_TFLOP/s": table_fl / (tables_ms * 1e-3) / 1e12,
+                "frac": table_fl / (tables_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            },
+            "pruning_total": {
+                "what": "all pruning launches of one evaluation (factor tables + walk), HIP events around them",
+                "ms": k2_ms,
+                "issued_flops": walk_fl + table_fl,
+                "achieved_TFLOP/s": (walk_fl + table_fl) / (k2_ms * 1e-3) / 1e12,
+                "frac": total_frac,
+                "uncompressed_walk_would_issue": issued * grid * nf,
+                "work_saved_by_subtree_state_compression": 1.0 - (walk_fl + table_fl) / (issued * grid * nf),
+            },
             "useful_flops_per_launch": useful * F_local,
             "useful_flops_note": "exact rows x C for every internal edge and family, i.e. what an uncompressed walk without "
                                  "tile padding executes; with compression fewer are executed, so the two rates below are "
                                  "NOT utilisations",
             "useful_TFLOP/s": useful * F_local / (k2_ms * 1e-3) / 1e12,
             "useful_frac": useful * F_local / (k2_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-            "families_per_launch": F_local,
-            "avg_launch_ms": k2_ms,
-            "launch_samples": len(kernel_ms),
-            "launch_samples_in_timed_region": samples_in_region,
-            "min_launch_ms": float(km[:, 1].min()),
-            "max_launch_ms": float(km[:, 1].max()),
         }
         out["roofline"].update(pmc_traffic(args.config, F_local))
         # SURVEY.md 8(d)'s reference-faithful accounting (a dense product on EVERY child edge, as the CPU path
@@ -377,6 +392,7 @@ def pmc_traffic(config, families, kernel="k2"):
     try:
         rec = json.load(open(TRAFFIC_FILE))["%s:%d:%s" % (config, families, kernel)]
         return {"traffic": rec["traffic_bytes"], "traffic_unit": "bytes per launch, HBM side: 2 x FETCH_SIZE + WRITE_SIZE",
+                "factor_tables_traffic": rec.get("tables_traffic_bytes"),
                 "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) + " (" + rec.get("note", "") + ")",
                 "traffic_minimal_bytes": rec.get("minimal_bytes")}
     except Exception:

@@ -27,6 +27,7 @@ SIGNATURES = {
     "cafehip_eval_clustered_posterior": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp]),
     "cafehip_launch_info": (C.c_int, [C.c_void_p, _ip, _ip]),
     "cafehip_last_issued_flops": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "cafehip_last_tables_ms": (C.c_int, [C.c_void_p, _dp]),
     "cafehip_eval_posterior_async": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_void_p, C.c_void_p]),
     "cafehip_num_chunks": (C.c_int, [C.c_void_p]),
     "cafehip_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int)]),

@@ -1027,6 +1027,9 @@ struct cafehip_ctx {
     bool timing = false, timing_pending = false;
     hipEvent_t ev[4] = {};
     double last_ms[3] = {0, 0, 0};
+    double last_tables_ms = 0;          // part of last_ms[1]: the k2c_nodes launches (compressed subtrees)
+    hipEvent_t ev_mid = nullptr;
+    bool ev_mid_used = false;
     double last_batch_ms = 0;   // pruning launch of the last cafehip_eval_root_likelihoods call
     int k2_nf = 0, k2_block = 0;
     size_t k2_lds = 0;
@@ -2202,6 +2205,12 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
         const bool use_c = c->cp.valid && !(k2e && strcmp(k2e, "v1") == 0) && (!c->d_err || c->fold_current);
         c->issued_tables = 0;
         if (use_c && launch_compressed_levels(c, n_sets)) return -1;
+        c->ev_mid_used = false;
+        if (use_c && c->timing) {
+            if (!c->ev_mid) HIP_TRY(hipEventCreate(&c->ev_mid));
+            HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
+            c->ev_mid_used = true;
+        }
         c->walk_compressed = use_c;
         const int rc = launch_k2(c, a, c->Fu, n_sets);
         c->walk_compressed = false;
@@ -2238,6 +2247,12 @@ int collect_kernel_ms(cafehip_ctx* c)
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
         c->last_ms[i] = ms;
+    }
+    c->last_tables_ms = 0;
+    if (c->ev_mid_used) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev_mid));
+        c->last_tables_ms = ms;
     }
     c->timing_pending = false;
     return 0;
@@ -2337,6 +2352,7 @@ void cafehip_destroy(cafehip_ctx* c)
         hipEventDestroy(c->h_params_ev[i]);
     }
     for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
+    if (c->ev_mid) hipEventDestroy(c->ev_mid);
     hipHostFree(c->h_result);
     hipFree(c->d_arrive);
     hipStreamDestroy(c->own_stream);
@@ -3077,6 +3093,14 @@ int cafehip_last_kernel_ms(cafehip_ctx* c, double ms[3])
     if (!c) return fail("null context");
     if (collect_kernel_ms(c)) return -1;  // the asynchronous entry point leaves the events pending
     for (int i = 0; i < 3; ++i) ms[i] = c->last_ms[i];
+    return 0;
+}
+
+int cafehip_last_tables_ms(cafehip_ctx* c, double* ms)
+{
+    if (!c || !ms) return fail("null argument");
+    if (collect_kernel_ms(c)) return -1;
+    *ms = c->last_tables_ms;
     return 0;
 }
 

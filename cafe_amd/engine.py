@@ -160,6 +160,12 @@ class Engine:
         _lib.check(self._L.cafehip_launch_info(self._h, C.byref(wg), C.byref(cu)))
         return wg.value, cu.value
 
+    def last_tables_ms(self):
+        """With timing on: the part of last_kernel_ms()[1] spent in the k2c_nodes launches (compressed subtrees)."""
+        v = C.c_double()
+        _lib.check(self._L.cafehip_last_tables_ms(self._h, C.byref(v)))
+        return v.value
+
     def last_issued_flops(self):
         """(walk, tables): matrix-instruction flops issued by the last objective evaluation's pruning."""
         w, t = C.c_double(), C.c_double()

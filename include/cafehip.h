@@ -202,6 +202,9 @@ int cafehip_fetch_small(cafehip_ctx *ctx, const void *d_src, size_t nbytes, cons
  * ms[2] = score reduction.  Enabled by cafehip_enable_timing(ctx, 1). */
 int cafehip_enable_timing(cafehip_ctx *ctx, int on);
 int cafehip_last_kernel_ms(cafehip_ctx *ctx, double ms[3]);
+/* The part of ms[1] spent building the factor tables of compressed subtrees (the k2c_nodes launches that precede the
+ * family walk; 0 when the table does not compress): ms[1] - this = the walk launch alone. */
+int cafehip_last_tables_ms(cafehip_ctx *ctx, double *ms);
 /* With timing enabled: duration of the pruning launch of the last cafehip_eval_root_likelihoods call (HIP
  * events on the context's stream; the copies either side of it are not included). */
 int cafehip_last_batch_ms(cafehip_ctx *ctx, double *ms);

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORK = [("cfg2", 10000, "k2"), ("cfg3", 100000, "k2"), ("cfg4", 62500, "k2"), ("cfg5", 100000, "k2"), ("cfg5", 250000, "mcnull")]
 
 
-def run_pass(counter, cmd, out_dir, tag):
+def run_pass(counter, cmd, out_dir, tag, largest=0):
     d = os.path.join(out_dir, "%s_%s" % (tag, counter))
     subprocess.call(["rm", "-rf", d])
     full = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "r", "--"] + cmd
@@ -38,15 +38,19 @@ def run_pass(counter, cmd, out_dir, tag):
     # the dominant kernel = the instantiation launched most often (the tuner's pick; the timed launches)
     name = max(agg, key=lambda k: len(agg[k]))
     vals = agg[name]
+    if largest:
+        # the Monte-Carlo-null run: the table's own evaluations (45, to settle the wave grid) use the same
+        # instantiation; the `largest` null launches (250 k uncompressed rows each) are the ones with the most traffic
+        allv = sorted(v for vs in agg.values() for v in vs)
+        tail = allv[-largest:]
+        return "batch-mode launch (largest %d of %d k2_prune launches)" % (largest, len(allv)), sum(tail) / len(tail), largest, 0.0
     tail = vals[len(vals) // 2:]          # steady state: the second half of its launches
     per_launch = sum(tail) / len(tail)
     # the factor tables of compressed subtrees (k2c_nodes, one launch per level before EVERY walk launch of whatever
     # instantiation): their mean per evaluation is added to the walk's
     n_walks = sum(len(v) for v in agg.values())
     per_eval_tables = sum(tables) / n_walks if tables and n_walks else 0.0
-    if per_eval_tables:
-        name += " + k2c_nodes"
-    return name, per_launch + per_eval_tables, len(vals)
+    return name, per_launch, len(vals), per_eval_tables
 
 
 def main():
@@ -57,17 +61,22 @@ def main():
         cmd = ([sys.executable, "tools/mcnull_one.py", "6"] if kind == "mcnull" else
                [sys.executable, "tools/ab_one.py", "%s:%d" % (cfg, F)])
         tag = "%s_%d_%s" % (cfg, F, kind)
-        kname, fetch_kib, n = run_pass("FETCH_SIZE", cmd, out_dir, tag)
-        kname2, write_kib, n2 = run_pass("WRITE_SIZE", cmd, out_dir, tag)
+        kname, fetch_kib, n, t_fetch = run_pass("FETCH_SIZE", cmd, out_dir, tag, 6 if kind == "mcnull" else 0)
+        kname2, write_kib, n2, t_write = run_pass("WRITE_SIZE", cmd, out_dir, tag, 6 if kind == "mcnull" else 0)
         traffic = (2.0 * fetch_kib + write_kib) * 1024.0
+        tables = (2.0 * t_fetch + t_write) * 1024.0
         res["%s:%d:%s" % (cfg, F, kind)] = {
             "kernel": kname, "launches_seen": n, "fetch_kib_raw": fetch_kib, "fetch_kib_x2": 2.0 * fetch_kib,
             "write_kib": write_kib, "traffic_bytes": traffic,
+            "tables_traffic_bytes": tables, "tables_fetch_kib_raw": t_fetch, "tables_write_kib": t_write,
             "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate runs), FETCH_SIZE x2 (gfx950), "
-                    "mean over the second half of the kernel's launches (+ the k2c_nodes launches of one evaluation where the table compresses)",
+                    "mean over the second half of the kernel's launches; tables_* = the k2c_nodes launches of one "
+                    "evaluation (factor tables of compressed subtrees), 0 where the table does not compress",
         }
         lines.append("%-22s %-60s launches %4d  FETCH_SIZE %12.1f KiB (x2 = %12.1f)  WRITE_SIZE %12.1f KiB  -> %.3f MB per launch"
-                     % ("%s:%d:%s" % (cfg, F, kind), kname[:60], n, fetch_kib, 2 * fetch_kib, write_kib, traffic / 1e6))
+                     "   + k2c_nodes per evaluation: FETCH %.1f KiB (x2) WRITE %.1f KiB -> %.3f MB"
+                     % ("%s:%d:%s" % (cfg, F, kind), kname[:60], n, fetch_kib, 2 * fetch_kib, write_kib, traffic / 1e6,
+                        t_fetch, t_write, tables / 1e6))
         print(lines[-1], flush=True)
     json.dump(res, open(os.path.join(out_dir, "r02_pmc_traffic.json"), "w"), indent=1)
     open(os.path.join(out_dir, "r02_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
