@@ -110,6 +110,14 @@ class Engine:
         R = self.range.root_max - self.range.root_min + 1
         if len(nl) != self.n_nodes or len(nm) != self.n_nodes or len(pr) < R:
             raise ValueError("node_lambda/node_mu need n_nodes entries and prior >= R entries")
+        if not per_family:
+            # the objective path of a search / of bench.py: raw addresses and reused result cells (building three
+            # ctypes pointer objects per call costs more than the launches' own CPU time at small tables)
+            fast = self._fast_eval()
+            self._fz.value = -1
+            _lib.check(fast(self._h, nl.__array_interface__["data"][0], nm.__array_interface__["data"][0],
+                            pr.__array_interface__["data"][0], self._score_ref, self._fz_ref, None, None, None))
+            return self._score.value, self._fz.value
         score = C.c_double()
         fz = C.c_int32(-1)
         if per_family:
@@ -122,6 +130,16 @@ class Engine:
         _lib.check(self._L.cafehip_eval_posterior(self._h, _d(nl), _d(nm), _d(pr), C.byref(score), C.byref(fz),
                                                   None, None, None))
         return score.value, fz.value
+
+    def _fast_eval(self):
+        f = getattr(self, "_fast", None)
+        if f is None:
+            vp = C.c_void_p
+            proto = C.CFUNCTYPE(C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp)
+            f = self._fast = proto(("cafehip_eval_posterior", self._L))
+            self._score, self._fz = C.c_double(), C.c_int32(-1)
+            self._score_ref, self._fz_ref = C.addressof(self._score), C.addressof(self._fz)
+        return f
 
     def get_posterior_multi(self, node_lambdas, node_mus, prior):
         """Several objective evaluations in one pass: node_lambdas / node_mus are [n_sets, n_nodes].
