@@ -5,7 +5,8 @@
     CAFEHIP_LIB=tools/_variants/stamps/libcafehip.so python tools/k2_stamps.py cfg2 [families] [K2CFG4=G,nrtw,wf,wr]
 
 Prints, per step of the walk (averaged over workgroups; a step's time is taken on the workgroup's slowest wave):
-the kind of step (LL = two leaves, LI = leaf + internal child, II = two internal children), shader cycles from
+the kind of step (LL = two gathered children: leaves or compressed subtrees, LI = one gathered + one internal child,
+II = two internal children), shader cycles from
 the end of the previous step to: gathers issued, factors done, read barrier passed, result visible."""
 import os
 import struct
@@ -67,7 +68,7 @@ def main():
                                                       "wave-skew"))
     for oi in range(n_ops):
         kinds = ops[oi, 4:6]
-        kind = {0: "LL", 1: "LI", 2: "II"}[int(kinds.sum())]
+        kind = {0: "LL", 1: "LI", 2: "II"}[int((kinds == 1).sum())]   # children of kind 0 (leaf) / 2 (compressed subtree) are gathers
         b = 2 + 6 * oi
         def rel(slot, red="max"):
             v = st[:, :, b + slot]
