@@ -367,7 +367,10 @@ __device__ __forceinline__ int k2_wave_min(int v)
                min(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
 }
 
-template <bool REGS>   // REGS: R <= 256, the lane's prior values live in registers for the whole epilogue
+// REGS: the root range fits PR registers per lane (R <= 64 * PR), the lane's prior values and root-vector entries
+// live in registers for the whole epilogue; PR = 2 (R <= 128, e.g. the 125 root sizes of a table whose largest
+// family has 100 members) halves the scan of PR = 4 (R <= 256)
+template <bool REGS, int PR>
 __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0,
                                                  size_t out_off, int wave, int lane, int nwaves)
 {
@@ -378,7 +381,6 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
     unsigned long long* fmaxbits = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(scratch) + 8 * 64);   // [NF]
     const double* prior = a.ep->prior;
     const double* logprior = a.ep->logprior;
-    constexpr int PR = 4;
     double pr[PR], lpr[PR];
     if (REGS) {
         // one global round trip per wave instead of one per family and pass (L2 latency under load is ~1-2 k cycles)
@@ -520,8 +522,9 @@ __device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* L
         }
         return;
     }
-    if (a.R <= 256) k2_epilogue_impl<true>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
-    else k2_epilogue_impl<false>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
+    if (a.R <= 128) k2_epilogue_impl<true, 2>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
+    else if (a.R <= 256) k2_epilogue_impl<true, 4>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
+    else k2_epilogue_impl<false, 1>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
 }
 
 template <int NFT_W, int NRT_W>
