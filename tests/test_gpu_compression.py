@@ -22,7 +22,7 @@ def _table(F, n, seed, top=9):
     return counts
 
 
-def _run(compress, counts, t, rng_tuple, lam, mu, prior, err=None, sets=None):
+def _run(compress, counts, t, rng_tuple, lam, mu, prior, err=None, sets=None, err_leaves=None):
     import cafe_amd
     os.environ["CAFEHIP_COMPRESS"] = "1" if compress else "0"
     try:
@@ -31,7 +31,7 @@ def _run(compress, counts, t, rng_tuple, lam, mu, prior, err=None, sets=None):
             eng.set_tree(t.parent, t.left, t.right, t.branchlength)
             eng.set_families(counts, cafe_amd.FamilySizeRange(*rng_tuple))
             if err is not None:
-                eng.set_error_model(err)
+                eng.set_error_model(err, err_leaves)
             if sets is None:
                 out = eng.get_posterior(lam, mu, prior, per_family=True)
             else:
@@ -102,3 +102,30 @@ def test_small_tables_and_incompressible_tables_are_left_alone():
         assert "compressed(" not in eng.describe()
     finally:
         eng.close()
+
+
+def test_error_model_on_some_species_only_and_root_with_two_compressed_children():
+    """The folded matrix is used for exactly the leaves that carry the model, inside compressed subtrees (k2c_nodes
+    reads the per-leaf flag by count-table column) and above them (the walk's flag is per walk column); here every
+    non-root node compresses, so the walk is the root step alone, gathering two table rows."""
+    from cafe_amd import synth
+    t = O.PyTree("((a:6,b:6):5,(c:4,d:7):3)")
+    counts = _table(4000, t.n_leaves, 21, top=30)
+    rng_tuple = (0, 60, 1, 40)
+    rng = O.make_range(*rng_tuple)
+    prior = O.prior_poisson(1000, 1, 2.0)
+    lam = np.full(t.n_nodes, 0.02)
+    mu = np.full(t.n_nodes, -1.0)
+    err = synth.banded_error_matrix(rng_tuple[1])
+    leaves = np.zeros(t.n_nodes, np.uint8)
+    leaves[0] = leaves[4] = 1          # nodes 0, 2, 4, 6 are the leaves a, b, c, d: the model on a and c only
+    (s1, fz1, ml1, am1, mp1), d1, _ = _run(True, counts, t, rng_tuple, lam, mu, prior, err, err_leaves=leaves)
+    (s0, fz0, ml0, am0, mp0), d0, _ = _run(False, counts, t, rng_tuple, lam, mu, prior, err, err_leaves=leaves)
+    assert "walk_steps=1" in d1 and "used=1" in d1, d1
+    assert s1 == s0 and np.array_equal(ml1, ml0) and np.array_equal(mp1, mp0) and np.array_equal(am1, am0)
+    E = np.asarray(err)
+    so, fzo, mlo, amo, mpo = O.eval_posterior(t, counts, rng, lam, mu, prior, nthreads=os.cpu_count() or 1,
+                                              errormatrix=E, err_mfs=E.shape[0] - 1, leaf_has_err=leaves)
+    nz = mlo > 0
+    assert np.max(np.abs(ml1[nz] - mlo[nz]) / mlo[nz]) < 1e-9
+    assert abs(s1 - so) <= 1e-9 * abs(so)
