@@ -1039,6 +1039,7 @@ struct cafehip_ctx {
         std::vector<K2Cand> cands;
         std::vector<float> best_ms;
         int cur = 0, round = 0, locked = -1;
+        int reps_launched = 1;   // launches inside the pending measurement
         bool pending = false;
         hipEvent_t e0 = nullptr, e1 = nullptr;
     } tune;
@@ -1954,10 +1955,10 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
                 HIP_TRY(hipEventSynchronize(t.e1));
                 float ms = 0;
                 HIP_TRY(hipEventElapsedTime(&ms, t.e0, t.e1));
-                if (t.round >= 1) ms /= kTuneReps;
+                ms /= (float)std::max(t.reps_launched, 1);
                 // round 0 runs while the clocks are still ramping up (a grid measured 0.236 ms there and 0.170 ms
-                // in steady state): it is a warm-up and eliminates nothing.  Round 1 times every grid (kTuneReps
-                // launches each), round 2 once more those within 5 % of round 1's best.
+                // in steady state): it is a warm-up and eliminates nothing.  Round 1 times every grid (up to kTuneReps
+                // launches each, see below), round 2 once more those within 5 % of round 1's best.
                 if (t.round <= 1) t.best_ms[t.cur] = ms;
                 else t.best_ms[t.cur] = std::min(t.best_ms[t.cur], ms);
                 t.pending = false;
@@ -2073,9 +2074,16 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     }
 #endif
     if (tuning_launch) HIP_TRY(hipEventRecord(c->tune.e0, c->stream));
-    // a deciding measurement (rounds 1, 2) times kTuneReps back-to-back launches: the walk is idempotent, and one
-    // launch of a small table (~0.2 ms) is within the noise of the candidates' differences
-    const int reps = (tuning_launch && c->tune.round >= 1) ? kTuneReps : 1;
+    // a deciding measurement (rounds 1, 2) of a SHORT launch times several back-to-back launches: the walk is
+    // idempotent, and one launch of a small table (~0.1 ms) is within the noise of the candidates' differences.  A
+    // launch of a millisecond is its own measurement (the extra launches of ten candidates would cost a one-off
+    // search of ~150 evaluations 30 % of its time)
+    int reps = 1;
+    if (tuning_launch && c->tune.round >= 1) {
+        const float warm = c->tune.best_ms[c->tune.cur];   // round 0's (or round 1's) time of this grid
+        reps = warm < 0.25f ? kTuneReps : (warm < 1.0f ? 2 : 1);
+    }
+    if (tuning_launch) c->tune.reps_launched = reps;
     int rc = 0;
     for (int rep = 0; rep < reps && rc == 0; ++rep) {
         if (use4) rc = launch_mfma4_g(c, a, k.nft_w, k.nrt_w, grid, block, lds);
