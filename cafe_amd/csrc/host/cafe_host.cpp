@@ -2313,6 +2313,36 @@ struct cafehost_session {
         }
     }
 
+    // cafe_cmd_score + cafe_shell_score, cafe/cafe_commands.cpp:2124-2209: the objective at the current parameters
+    // (the objective logs its own line, as the reference's search function does), the summary line again, the
+    // score through `ostream << double`
+    int cmd_score(const std::vector<std::string>&)
+    {
+        prereqs(true, true);
+        if (params.empty()) throw std::runtime_error("ERROR: Lambda values were not set. Please set lambda values with the 'lambda' or 'lambdamu' command.\n");
+        double score;
+        if (k_clusters > 0) {
+            score = -cluster_objective(params.data());
+            log("Lambda : %s\n", join_double(params.data(), num_lambdas * k_clusters).c_str());
+            log("p : %s\n", join_double(k_weights.data(), k_clusters).c_str());
+            log("Score: %f\n", score);
+        } else {
+            score = -objective(params.data());
+            if (has_mu) {
+                log("Lambda : %s ", join_double(params.data(), num_lambdas).c_str());
+                log("Mu : %s & Score: %f\n", join_double(params.data() + num_lambdas, num_mus).c_str(), score);
+            } else {
+                log("Lambda : %s & Score: %f\n", join_double(params.data(), num_lambdas).c_str(), score);
+            }
+        }
+        std::ostringstream os;
+        os << score << std::endl;
+        log("%s", os.str().c_str());
+        if (k_clusters > 0) log_cluster_membership();
+        last_score = -score;
+        return 0;
+    }
+
     int cmd_rootdist(const std::vector<std::string>& tokens)
     {  // cafe_cmd_rootdist, cafe/cafe_commands.cpp:1831-1916
         prereqs(false, true);
@@ -2622,6 +2652,7 @@ struct cafehost_session {
         if (cmd == "report") return cmd_report(tokens);
         if (cmd == "errormodel") return cmd_errormodel(tokens);
         if (cmd == "rootdist") return cmd_rootdist(tokens);
+        if (cmd == "score") return cmd_score(tokens);
         if (cmd == "genfamily") return cmd_genfamily(tokens);
         if (cmd == "lhtest") return cmd_lhtest(tokens);
         if (cmd == "pvalue") return cmd_pvalue(tokens);

@@ -519,3 +519,46 @@ def test_each_family_lambda_search(shell, tmp_path):
         if not flagged and lam > 2e-6:
             here = f(i, lam)
             assert here >= f(i, lam * 1.05) - 1e-6 and here >= f(i, lam * 0.95) - 1e-6, fid
+
+
+def test_score_command(shell, tmp_path):
+    # cafe_cmd_score (cafe/cafe_commands.cpp:2195-2209): the objective at the current parameters -- its own line,
+    # the summary line again (cafe_shell_score :2181-2187), then the score through `ostream << double`
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+    shell.dispatch("seed 10")
+    shell.dispatch("load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"))
+    shell.dispatch("tree " + newick)
+    with pytest.raises(Exception):
+        shell.dispatch("score")                      # no lambda yet
+    shell.dispatch("lambda -l 0.0017")
+    n0 = shell.evaluations
+    shell.dispatch("score")
+    assert shell.evaluations == n0 + 1
+    sp, ids, counts = O.load_family_table(os.path.join(GOLD, "example_data.tab"))
+    t = O.PyTree(newick)
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    prior = O.prior_poisson(1000, rng.root_min, shell.poisson_lambda)
+    so, *_ = O.eval_posterior(t, counts, rng, np.full(t.n_nodes, 0.0017), np.full(t.n_nodes, -1.0), prior)
+    assert shell.score == pytest.approx(-so, rel=1e-12)
+    shell.close()
+    lines = open(str(tmp_path / "log.txt")).read().splitlines()
+    line = "Lambda : %15.14f & Score: %f" % (0.0017, so)
+    hits = [i for i, l in enumerate(lines) if l.lstrip(".") == line]
+    assert len(hits) >= 2, lines[-8:]
+    assert lines[hits[-1] + 1] == "%g" % so          # default ostream formatting: 6 significant digits
+
+    # lambda/mu form of the summary line
+    from cafe_amd.shell import CafeShell
+    s2 = CafeShell(0, str(tmp_path / "log2.txt"))
+    try:
+        s2.dispatch("seed 10")
+        s2.dispatch("load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"))
+        s2.dispatch("tree " + newick)
+        s2.dispatch("lambdamu -l 0.0017 -m 0.0012")
+        s2.dispatch("score")
+        sc = -s2.score
+    finally:
+        s2.close()
+    txt = open(str(tmp_path / "log2.txt")).read()
+    assert ("Lambda : %15.14f Mu : %15.14f & Score: %f" % (0.0017, 0.0012, sc)) in txt
