@@ -129,3 +129,51 @@ def test_error_model_on_some_species_only_and_root_with_two_compressed_children(
     nz = mlo > 0
     assert np.max(np.abs(ml1[nz] - mlo[nz]) / mlo[nz]) < 1e-9
     assert abs(s1 - so) <= 1e-9 * abs(so)
+
+
+def test_plan_follows_tables_trees_and_error_models_through_one_context():
+    """One context through a sequence of tables, trees and error models (what lhtest / a scripted session does): the
+    compression plan is rebuilt by set_families / set_tree and its error-model flags by set_error_model; every
+    evaluation equals the one of a context that never compresses."""
+    import cafe_amd
+    from cafe_amd import synth
+    trees = [O.PyTree(NEWICK), O.PyTree("((a:3,(b:5,c:5):2):4,((d:1,e:9):6,(f:2,(g:4,h:4):7):3):2)")]
+    rng_tuple = (0, 40, 1, 30)
+    prior = O.prior_poisson(1000, 1, 2.0)
+    err = synth.banded_error_matrix(rng_tuple[1])
+    steps = [  # (tree, rows, seed, error model, lambda)
+        (0, 5000, 1, None, 0.02), (0, 300, 2, None, 0.02), (1, 300, 2, None, 0.015), (1, 7000, 3, None, 0.015),
+        (1, 7000, 3, err, 0.015), (0, 7000, 3, err, 0.03), (0, 7000, 3, None, 0.03), (0, 2500, 4, None, 0.01),
+    ]
+
+    def session(compress):
+        os.environ["CAFEHIP_COMPRESS"] = "1" if compress else "0"
+        out = []
+        try:
+            eng = cafe_amd.Engine(0)
+            try:
+                cur = (None, None, None, None)
+                for ti, rows, seed, e, lam in steps:
+                    t = trees[ti]
+                    if cur[0] != ti:
+                        eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+                    if cur[1:3] != (rows, seed):
+                        eng.set_families(_table(rows, t.n_leaves, seed), cafe_amd.FamilySizeRange(*rng_tuple))
+                    if (cur[3] is None) != (e is None) or cur[0] != ti:
+                        eng.set_error_model(e)
+                    cur = (ti, rows, seed, e)
+                    r = eng.get_posterior(np.full(t.n_nodes, lam), np.full(t.n_nodes, -1.0), prior, per_family=True)
+                    out.append((r, "used=1" in eng.describe()))
+            finally:
+                eng.close()
+        finally:
+            os.environ.pop("CAFEHIP_COMPRESS", None)
+        return out
+
+    a, b = session(True), session(False)
+    used = [u for _, u in a]
+    assert used == [True, False, False, True, True, True, True, True], used
+    for (ra, _), (rb, _) in zip(a, b):
+        assert ra[0] == rb[0] and ra[1] == rb[1]
+        for x, y in zip(ra[2:], rb[2:]):
+            assert np.array_equal(x, y)
