@@ -141,3 +141,46 @@ def test_k_loop_phases_and_tiny_matrices(shape):
     finally:
         os.environ.pop("CAFEHIP_MFMA", None)
         os.environ.pop("CAFEHIP_K2", None)
+
+
+@pytest.mark.parametrize("case", [2, 3, 4, 5, 8, 9, 11])
+def test_random_shapes_with_compressed_subtrees(case):
+    """The shapes of CASES at a table size where subtree-state compression engages (>= 1024 unique rows): the
+    compressed walk against the oracle, and bit for bit against the uncompressed walk."""
+    import cafe_amd
+    n, shape, (mn, mx, rmin, rmax), _, model = CASES[case]
+    F = 2600
+    rs = np.random.RandomState(900 + case)
+    nw = random_newick(rs, n, shape)
+    t = O.PyTree(nw)
+    top = min(mx - 1, 12)
+    counts = rs.poisson(1.6, size=(F, n)).clip(0, top).astype(np.int32)
+    counts[0] = 0
+    counts[-1] = top
+    rng = O.make_range(mn, mx, rmin, rmax)
+    prior = O.prior_poisson(1000, max(rmin, 1), 3.0)
+    base = 0.4 / max(t.branchlength.max(), 1)
+    lam = np.full(t.n_nodes, base) if model != "pernode" else base * (0.5 + rs.rand(t.n_nodes))
+    mu = np.full(t.n_nodes, base * 0.6 if model == "lambdamu" else -1.0)
+    res = {}
+    for comp in ("1", "0"):
+        os.environ["CAFEHIP_COMPRESS"] = comp
+        eng = cafe_amd.Engine(0)
+        try:
+            eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+            eng.set_families(counts, cafe_amd.FamilySizeRange(mn, mx, rmin, rmax))
+            res[comp] = (eng.get_posterior(lam, mu, prior, per_family=True), eng.describe())
+        finally:
+            os.environ.pop("CAFEHIP_COMPRESS", None)
+            eng.close()
+    (sg, fzg, mlg, amg, mpg), desc = res["1"]
+    (s0, fz0, ml0, am0, mp0), _ = res["0"]
+    assert "used=1" in desc, desc
+    assert sg == s0 and fzg == fz0 and np.array_equal(mlg, ml0) and np.array_equal(mpg, mp0) and np.array_equal(amg, am0), desc
+    so, fzo, mlo, amo, mpo = O.eval_posterior(t, counts, rng, lam, mu, prior, nthreads=os.cpu_count() or 1)
+    assert fzg == fzo
+    nz = mlo > 0
+    assert np.array_equal(mlg == 0, mlo == 0)
+    assert np.max(np.abs(mlg[nz] - mlo[nz]) / mlo[nz], initial=0) < 1e-9, desc
+    assert np.max(np.abs(mpg[nz] - mpo[nz]) / mpo[nz], initial=0) < 1e-9, desc
+    assert np.all((amg == amo) | ~nz), desc
