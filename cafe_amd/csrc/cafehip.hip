@@ -1191,7 +1191,7 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
     return 0;
 }
 
-int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr)
+int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr, bool defer_ring_event = false)
 {
     const EvalParams* hp = c->cur_params;  // pinned host block staged by stage_params
     const int n_prior = c->cur_prior_n;
@@ -1250,8 +1250,9 @@ int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr)
                            c->d_params, c->n_nodes, n_prior, c->nkeys);
     }
     HIP_TRY(hipGetLastError());
-    // the pinned block may be rewritten once this launch has consumed it
-    HIP_TRY(hipEventRecord(c->h_params_ev[c->cur_slot], c->stream));
+    // the pinned block may be rewritten once this launch has consumed it.  An evaluation records the event behind
+    // its LAST launch instead (a marker packet between K1 and the next kernel cost ~5 us of every evaluation)
+    if (!defer_ring_event) HIP_TRY(hipEventRecord(c->h_params_ev[c->cur_slot], c->stream));
     c->have_matrices = true;
     c->fold_current = false;  // the folded copy (if any) belongs to the previous matrices
     return 0;
@@ -2191,7 +2192,7 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
     EvalParams* h = nullptr;
     if (stage_params(c, node_lambda, node_mu, prior, &h, n_sets)) return -1;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    if (launch_k1(c, d_first_zero)) return -1;
+    if (launch_k1(c, d_first_zero, true)) return -1;
     if (launch_error_fold(c)) return -1;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     K2Args a;
@@ -2239,6 +2240,7 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
         }
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->h_params_ev[c->cur_slot], c->stream));   // (deferred from launch_k1)
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         c->timing_pending = true;
