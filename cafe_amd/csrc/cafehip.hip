@@ -1005,6 +1005,7 @@ struct cafehip_ctx {
     int cur_prior_n = 0, cur_slot = 0;
     EvalParams* d_params = nullptr;
     std::vector<int> node_key;
+    std::vector<double> prior_seen, logprior_seen;   // the last prior staged and its logarithms
     int nkeys = 0;
     bool have_matrices = false;
 
@@ -1177,11 +1178,15 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
     for (int k = 0; k < nk; ++k)
         if (h->keys[k].mode >= 2 && !h->keys[k].fast_ok) c->all_keys_fast = false;
     if (prior) {
-        // compute_posterior adds log(prior[j]) (cafe/lambda.cpp:681); the log is taken on the host
-        for (int j = 0; j < c->R; ++j) {
-            h->logprior[j] = std::log(prior[j]);
-            h->prior[j] = prior[j];
+        // compute_posterior adds log(prior[j]) (cafe/lambda.cpp:681); the log is taken on the host -- once per prior:
+        // a search hands over the same prior at every evaluation
+        if ((int)c->prior_seen.size() != c->R || memcmp(c->prior_seen.data(), prior, sizeof(double) * c->R) != 0) {
+            c->prior_seen.assign(prior, prior + c->R);
+            c->logprior_seen.resize(c->R);
+            for (int j = 0; j < c->R; ++j) c->logprior_seen[j] = std::log(prior[j]);
         }
+        memcpy(h->logprior, c->logprior_seen.data(), sizeof(double) * c->R);
+        memcpy(h->prior, prior, sizeof(double) * c->R);
     }
     if (ensure_matrix_storage(c, (size_t)nk)) return -1;
     *out_h = h;
