@@ -1350,14 +1350,16 @@ int k2c_wave_rows(const cafehip_ctx* c, int* nrt_w)
 // (Re)build the plan from the tree and the unique rows.  A node is compressed when both children are leaves or
 // compressed and its distinct states number at most CAFEHIP_COMPRESS_THETA (default 0.5, 0.7 for matrix sides >= 200) of
 // the unique rows;
-// CAFEHIP_COMPRESS=0 disables.  Tables with fewer than 1024 unique rows are left alone (nothing to win).
+// CAFEHIP_COMPRESS=0 disables.  Tables with fewer than 64 unique rows (CAFEHIP_COMPRESS_MIN) are left alone.
 int rebuild_compression(cafehip_ctx* c)
 {
     free_compression(c);
     if (const char* e = getenv("CAFEHIP_COMPRESS"))
         if (atoi(e) == 0) return 0;
     const int n = c->n_nodes, nl = c->n_leaves, Fu = c->Fu;
-    if (n <= 0 || c->M < 0 || nl != (n + 1) / 2 || Fu < 1024 || (int)c->h_ucounts.size() != Fu * nl) return 0;
+    int min_rows = 64;   // even a 100-row table gains: its walk is a chain of latency-bound steps, and compression shortens the chain
+    if (const char* e = getenv("CAFEHIP_COMPRESS_MIN")) min_rows = std::max(atoi(e), 16);
+    if (n <= 0 || c->M < 0 || nl != (n + 1) / 2 || Fu < min_rows || (int)c->h_ucounts.size() != Fu * nl) return 0;
     int nrt_w = 0;
     if (k2c_wave_rows(c, &nrt_w) == 0) return 0;
     // a table product costs more per state than a walk product per family (16-state tiles re-read the matrix: x1.5

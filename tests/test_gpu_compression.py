@@ -94,7 +94,7 @@ def test_small_tables_and_incompressible_tables_are_left_alone():
     eng = cafe_amd.Engine(0)
     try:
         eng.set_tree(t.parent, t.left, t.right, t.branchlength)
-        eng.set_families(_table(300, t.n_leaves, 13), cafe_amd.FamilySizeRange(0, 40, 1, 30))
+        eng.set_families(_table(40, t.n_leaves, 13), cafe_amd.FamilySizeRange(0, 40, 1, 30))
         assert "compressed(" not in eng.describe()
         rs = np.random.RandomState(5)
         wide = rs.randint(0, 200, size=(3000, t.n_leaves)).astype(np.int32)     # every pair of counts distinct
@@ -142,7 +142,7 @@ def test_plan_follows_tables_trees_and_error_models_through_one_context():
     prior = O.prior_poisson(1000, 1, 2.0)
     err = synth.banded_error_matrix(rng_tuple[1])
     steps = [  # (tree, rows, seed, error model, lambda)
-        (0, 5000, 1, None, 0.02), (0, 300, 2, None, 0.02), (1, 300, 2, None, 0.015), (1, 7000, 3, None, 0.015),
+        (0, 5000, 1, None, 0.02), (0, 50, 2, None, 0.02), (1, 50, 2, None, 0.015), (1, 7000, 3, None, 0.015),
         (1, 7000, 3, err, 0.015), (0, 7000, 3, err, 0.03), (0, 7000, 3, None, 0.03), (0, 2500, 4, None, 0.01),
     ]
 

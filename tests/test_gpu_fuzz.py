@@ -145,7 +145,7 @@ def test_k_loop_phases_and_tiny_matrices(shape):
 
 @pytest.mark.parametrize("case", [2, 3, 4, 5, 8, 9, 11])
 def test_random_shapes_with_compressed_subtrees(case):
-    """The shapes of CASES at a table size where subtree-state compression engages (>= 1024 unique rows): the
+    """The shapes of CASES at a table size where subtree-state compression engages for several levels: the
     compressed walk against the oracle, and bit for bit against the uncompressed walk."""
     import cafe_amd
     n, shape, (mn, mx, rmin, rmax), _, model = CASES[case]
