@@ -1348,8 +1348,8 @@ int k2c_wave_rows(const cafehip_ctx* c, int* nrt_w)
 }
 
 // (Re)build the plan from the tree and the unique rows.  A node is compressed when both children are leaves or
-// compressed and its distinct states number at most CAFEHIP_COMPRESS_THETA (default 0.5, 0.7 for matrix sides >= 200) of
-// the unique rows;
+// compressed and its distinct states number at most CAFEHIP_COMPRESS_THETA of the unique rows (default by table
+// size and matrix side, see below);
 // CAFEHIP_COMPRESS=0 disables.  Tables with fewer than 64 unique rows (CAFEHIP_COMPRESS_MIN) are left alone.
 int rebuild_compression(cafehip_ctx* c)
 {
@@ -1362,10 +1362,16 @@ int rebuild_compression(cafehip_ctx* c)
     if (n <= 0 || c->M < 0 || nl != (n + 1) / 2 || Fu < min_rows || (int)c->h_ucounts.size() != Fu * nl) return 0;
     int nrt_w = 0;
     if (k2c_wave_rows(c, &nrt_w) == 0) return 0;
-    // a table product costs more per state than a walk product per family (16-state tiles re-read the matrix: x1.5
-    // at a 151-wide matrix, x1.2 at 251) and every level is a launch: measured optimum 0.5 / 0.7 (sweep of 0.2..0.9
-    // at the bench shapes)
+    // Threshold.  A table product costs more per state than a walk product per family (16-state tiles re-read the
+    // matrix: x1.5 at a 151-wide matrix, x1.2 at 251) and every level is a launch: for tables that fill the chip
+    // the measured optimum is 0.5 / 0.7 (sweep of 0.2..0.9 at the bench shapes).  A SMALL table does not fill the
+    // chip either way; its cost is the length of the dependency chain -- one latency-bound step of the walk per
+    // internal node against one launch per LEVEL of compressed nodes, all nodes of a level side by side -- so
+    // everything below the root is "compressed" whatever the number of states (250..2,000 rows on the 32- and
+    // 64-taxon trees: 1.4-2.5x faster than 0.5), with 0.8 in between (sweeps at 250..10,000 rows).
     double theta = c->C < 200 ? 0.5 : 0.7;
+    if (Fu < 10 * std::max(c->n_cu, 1)) theta = 1.0;
+    else if (Fu < 32 * std::max(c->n_cu, 1)) theta = 0.8;
     if (const char* e = getenv("CAFEHIP_COMPRESS_THETA")) theta = std::min(std::max(atof(e), 0.0), 1.0);
     const size_t limit = (size_t)(theta * Fu);
     const auto& left = c->left;
