@@ -1362,18 +1362,6 @@ int rebuild_compression(cafehip_ctx* c)
     if (n <= 0 || c->M < 0 || nl != (n + 1) / 2 || Fu < min_rows || (int)c->h_ucounts.size() != Fu * nl) return 0;
     int nrt_w = 0;
     if (k2c_wave_rows(c, &nrt_w) == 0) return 0;
-    // Threshold.  A table product costs more per state than a walk product per family (16-state tiles re-read the
-    // matrix: x1.5 at a 151-wide matrix, x1.2 at 251) and every level is a launch: for tables that fill the chip
-    // the measured optimum is 0.5 / 0.7 (sweep of 0.2..0.9 at the bench shapes).  A SMALL table does not fill the
-    // chip either way; its cost is the length of the dependency chain -- one latency-bound step of the walk per
-    // internal node against one launch per LEVEL of compressed nodes, all nodes of a level side by side -- so
-    // everything below the root is "compressed" whatever the number of states (250..2,000 rows on the 32- and
-    // 64-taxon trees: 1.4-2.5x faster than 0.5), with 0.8 in between (sweeps at 250..10,000 rows).
-    double theta = c->C < 200 ? 0.5 : 0.7;
-    if (Fu < 10 * std::max(c->n_cu, 1)) theta = 1.0;
-    else if (Fu < 32 * std::max(c->n_cu, 1)) theta = 0.8;
-    if (const char* e = getenv("CAFEHIP_COMPRESS_THETA")) theta = std::min(std::max(atof(e), 0.0), 1.0);
-    const size_t limit = (size_t)(theta * Fu);
     const auto& left = c->left;
     const auto& right = c->right;
     auto internal = [&](int v) { return left[v] >= 0; };
@@ -1390,6 +1378,30 @@ int rebuild_compression(cafehip_ctx* c)
             else { post.push_back(v); st.pop_back(); }
         }
     }
+    // Threshold.  A table product costs more per state than a walk product per family (16-state tiles re-read the
+    // matrix: x1.5 at a 151-wide matrix, x1.2 at 251) and every level is a launch: for tables that fill the chip
+    // the measured optimum is 0.5 / 0.7 (sweep of 0.2..0.9 at the bench shapes).  A SMALL table does not fill the
+    // chip either way; its cost is the length of the dependency chain -- one latency-bound step of the walk per
+    // internal node against one launch per LEVEL of compressed nodes, all nodes of a level side by side -- so
+    // everything below the root is "compressed" whatever the number of states (250..2,000 rows on the 32- and
+    // 64-taxon trees: 1.4-2.5x faster than 0.5), with 0.8 in between (sweeps at 250..10,000 rows).
+    double theta = c->C < 200 ? 0.5 : 0.7;
+    {
+        // (a launch costs about two walk steps: the small-table rule only where the tree is at most half as deep as
+        // it has internal nodes -- not for a caterpillar, whose every node is a level of its own)
+        std::vector<int> height(n, 0);
+        int n_internal = 0;
+        for (int v : post)
+            if (left[v] >= 0) {
+                height[v] = 1 + std::max(height[left[v]], height[right[v]]);
+                ++n_internal;
+            }
+        const bool bushy = 2 * (height[c->root] - 1) <= n_internal - 1;
+        if (bushy && Fu < 10 * std::max(c->n_cu, 1)) theta = 1.0;
+        else if (bushy && Fu < 32 * std::max(c->n_cu, 1)) theta = 0.8;
+    }
+    if (const char* e = getenv("CAFEHIP_COMPRESS_THETA")) theta = std::min(std::max(atof(e), 0.0), 1.0);
+    const size_t limit = (size_t)(theta * Fu);
     std::vector<std::vector<int32_t>> sid(n), idx0(n), idx1(n);
     std::vector<int> D(n, 0), level(n, 0);
     std::vector<char> comp(n, 0);
