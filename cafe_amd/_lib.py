@@ -17,6 +17,7 @@ SIGNATURES = {
     "cafehip_abi_version": (C.c_int, []),
     "cafehip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "cafehip_destroy": (None, [C.c_void_p]),
+    "cafehip_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "cafehip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cafehip_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "cafehip_set_tree": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _dp]),
@@ -50,6 +51,7 @@ HOST_SIGNATURES = {
     "cafehost_destroy": (None, [C.c_void_p]),
     "cafehost_dispatch": (C.c_int, [C.c_void_p, C.c_char_p]),
     "cafehost_run_script": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "cafehost_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "cafehost_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "cafehost_shard_bounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cafehost_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -11,15 +11,17 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcafehip.so")
 
-SOURCES = ["cafehip.hip", os.path.join("host", "cafe_host.cpp")]
+# translation units of libcafehip.so: compiled in parallel into cafe_amd/lib/obj/, relinked when any object changes
+SOURCES = ["cafehip.hip", "k1_matrices.hip", "k2_walk16.hip", "k2_walk4.hip", "k2c_tables.hip", "k_misc.hip",
+           os.path.join("host", "cafe_host.cpp")]
+HEADERS = ["device_types.hpp", "kernels.hpp", "k2_mfma.hpp", "host_math.hpp", "schedule.hpp",
+           os.path.join("..", "..", "include", "cafehip.h"), os.path.join("..", "..", "include", "cafehost.h")]
+OBJDIR = os.path.join(LIBDIR, "obj")
 PROBE_LIB = os.path.join(LIBDIR, "libcafeprobe.so")   # measured HBM / MFMA ceilings for bench.py (csrc/probe.hip)
 BINDIR = os.path.join(HERE, "bin")
 CLI = os.path.join(BINDIR, "cafehip")
-DEPS = ["cafehip.hip", "k2_mfma.hpp", "host_math.hpp", "schedule.hpp", os.path.join("host", "cafe_host.cpp"),
-        os.path.join("host", "main.cpp"), os.path.join("..", "..", "include", "cafehip.h"),
-        os.path.join("..", "..", "include", "cafehost.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-ldl",
-         "-Wno-unused-result"]
+DEPS = SOURCES + HEADERS + [os.path.join("host", "main.cpp")]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 
 def hipcc():
@@ -47,11 +49,26 @@ def build(force=False, verbose=False):
         return override
     if not force and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJDIR, exist_ok=True)
+    newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    jobs = []
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header):
+            jobs.append([hipcc()] + CFLAGS + ["-c", "-o", obj, path])
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        for j in jobs:
+            print(" ".join(j))
+    procs = [subprocess.Popen(j) for j in jobs]   # the units are independent: compile side by side
+    failed = [j for j, pr in zip(jobs, procs) if pr.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed: " + " ".join(failed[0]))
+    objs = [os.path.join(OBJDIR, os.path.basename(src).rsplit(".", 1)[0] + ".o") for src in SOURCES]
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link)
     # command-line front end (host C++ only), linked against the in-tree library
     os.makedirs(BINDIR, exist_ok=True)
     cli = [hipcc(), "-O2", "-std=c++17", "-o", CLI, os.path.join(CSRC, "host", "main.cpp"), "-L" + LIBDIR, "-lcafehip",
@@ -59,11 +76,13 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cli))
     subprocess.check_call(cli)
-    probe = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", PROBE_LIB,
-             os.path.join(CSRC, "probe.hip")]
-    if verbose:
-        print(" ".join(probe))
-    subprocess.check_call(probe)
+    probe_src = os.path.join(CSRC, "probe.hip")
+    if force or not os.path.exists(PROBE_LIB) or os.path.getmtime(PROBE_LIB) < os.path.getmtime(probe_src):
+        probe = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", PROBE_LIB,
+                 probe_src]
+        if verbose:
+            print(" ".join(probe))
+        subprocess.check_call(probe)
     return LIB
 
 

@@ -1,16 +1,17 @@
-// cafehip.hip -- MI355X (gfx950) kernels and C ABI for CAFE's per-family likelihood
-// hot path.  See include/cafehip.h for the boundary and DESIGN.md for the layout.
+// cafehip.hip -- context and C ABI of the MI355X (gfx950) engine for CAFE's per-family likelihood hot path.
+// See include/cafehip.h for the boundary and DESIGN.md for the layout.  The kernels live in their own translation
+// units (kernels.hpp):
 //
-//   K1  k1_build_matrices[_rb]  birth-death transition matrices for every unique
-//                           (int branch length, lambda, mu) key of one evaluation
-//                           == compute_birthdeath_rates, libtree/birthdeath.c:238-286
-//       k1e_fold_error      error model folded into those matrices (posterior path), cafe/cafe_tree.c:196-203
-//   K2  k2_prune_mfma[4]    post-order pruning of ALL families in one launch + the
-//       (k2_mfma.hpp),      per-family posterior == compute_tree_likelihoods +
-//       k2_prune_v1         compute_posterior, cafe/cafe_tree.c:191-323, cafe/lambda.cpp:657-689
-//   K3  k3_score            per-chunk sums of log max-posterior in family order and the
-//                           first zero-likelihood family == get_posterior, cafe/lambda.cpp:691-724
-//   K4  k4_viterbi          max-product walk + backtrack == cafe_tree_viterbi, cafe/viterbi.cpp:208-351
+//   K1  k1_matrices.hip     birth-death transition matrices for every unique (int branch length, lambda, mu) key
+//                           of one evaluation == compute_birthdeath_rates, libtree/birthdeath.c:238-286;
+//                           k1e_fold_error: error model folded into those matrices, cafe/cafe_tree.c:196-203
+//   K2  k2_walk16.hip,      post-order pruning of ALL families in one launch + the per-family posterior
+//       k2_walk4.hip,       == compute_tree_likelihoods + compute_posterior, cafe/cafe_tree.c:191-323,
+//       k2c_tables.hip,     cafe/lambda.cpp:657-689 (k2_mfma.hpp); factor tables of compressed subtrees;
+//       k_misc.hip          row-per-thread fallback k2_prune_v1
+//   K3  k_misc.hip          per-chunk sums of log max-posterior in family order and the first zero-likelihood
+//                           family == get_posterior, cafe/lambda.cpp:691-724
+//   K4  k_misc.hip          max-product walk + backtrack == cafe_tree_viterbi, cafe/viterbi.cpp:208-351
 //
 // gfx950 only.  No CPU fallback: every entry point fails if the device work fails.
 #include <hip/hip_runtime.h>
@@ -34,15 +35,11 @@
 
 #include "../../include/cafehip.h"
 #include "host_math.hpp"
-#include "schedule.hpp"
+#include "kernels.hpp"
+
+using namespace cafehip;
 
 namespace {
-
-constexpr int kMaxNodes = 256;   // up to 128 taxa
-constexpr int kMaxPrior = 1000;  // FAMILYSIZEMAX, libtree/family.h:8
-constexpr int kMaxLeaves = kMaxNodes / 2;
-constexpr int kParamRing = 8;
-constexpr int kMaxSets = CAFEHIP_MAX_SETS;   // parameter sets evaluated in one pass (cafehip_eval_posterior_multi)
 
 thread_local std::string g_err;
 
@@ -65,835 +62,15 @@ int fail(const char* fmt, ...)
                         __LINE__);                                                        \
     } while (0)
 
-// ------------------------------------------------------------------------------------
-// device-side parameter blocks
-// ------------------------------------------------------------------------------------
-struct KeyParam {
-    double log_alpha, log_beta, log_coeff, coeff;
-    double l2a, l2b, rho_m;   // product form (host_math.hpp KeyScalars)
-    int rho_e;
-    int fast_ok;
-    int mode;  // host_math.hpp KeyScalars
-    int bl;
-};
-
-struct EvalParams {
-    int nkeys;
-    int n_sets;                        // parameter sets of this evaluation (1 unless cafehip_eval_posterior_multi)
-    int node_key[kMaxSets][kMaxNodes]; // set -> node -> matrix
-    KeyParam keys[kMaxNodes];
-    double logprior[kMaxPrior];
-    double prior[kMaxPrior];   // the same prior, not logged (K2's epilogue filters candidates by L * prior)
-};
-
-struct K2Args {
-    const double* PT;        // [nkeys][KP][LD]  PT[k][c*LD + s] = Pr(c | s)
-    const EvalParams* ep;
-    const cafehip::PruneOp* ops;
-    int n_ops;
-    const int32_t* counts;   // [Fu][n_leaves]
-    int Fu;
-    int n_leaves;
-    int C;                   // range_max + 1 (range_min == 0)
-    int R;                   // root_max - root_min + 1
-    int root_min;
-    int LD, KP, LDv;
-    int n_slots;
-    // error model (optional)
-    const double* err;       // [(mfs+1)^2] row = observed
-    int err_ld;
-    const uint8_t* leaf_has_err;  // [n_leaves] by count column
-    // per-row extents (batch mode; NULL in posterior mode)
-    const int32_t* root_lo;
-    const int32_t* root_hi;
-    const int32_t* col_max;
-    const int64_t* out_off;  // packed offsets of the root vectors
-    double* out_root;
-    // posterior outputs
-    double* max_lik;
-    int32_t* argmax;
-    double* max_post;
-};
-
-// ------------------------------------------------------------------------------------
-// K1: transition matrices.  One 16x16 tile of (s, c) entries per workgroup; the 16
-// consecutive s of a tile are the fast lane index so that the transposed store
-// PT[c][s] is 128 B contiguous.  The two ln C runs of each of the 16 rows are staged
-// in LDS (odd row stride -> conflict-free ds_read_b64).
-// Arithmetic follows libtree/birthdeath.c:52-73 / :34-50 term by term, j ascending,
-// running product for coeff^j, clamp to [0,1]; contraction is off so each term is the
-// same sequence of IEEE operations as the reference's x86-64 build.
-// ------------------------------------------------------------------------------------
-#pragma clang fp contract(off)
-template <bool USE_LDS, bool PRODUCT_FORM>
-__global__ __launch_bounds__(256) void k1_build_matrices(const EvalParams* __restrict__ ep,
-                                                         const double* __restrict__ lncA,
-                                                         const double* __restrict__ lncB,
-                                                         int ld_lnc, double* __restrict__ PT,
-                                                         int M, int LD, int KP, int32_t* first_zero,
-                                                         int keys_per_block, EvalParams* __restrict__ ep_dev,
-                                                         int n_nodes, int n_prior, int nkeys)
+// one argument struct per kernel (device_types.hpp): every launch is hipLaunchKernel(address, ..., &args)
+template <class Args>
+int launch_kernel(const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const Args& args)
 {
-    // `ep` is this evaluation's parameter block in PINNED HOST memory (read over the fabric: one 56-byte
-    // KeyParam per workgroup); block (0,0,0) mirrors the parts the later kernels need (node -> key map,
-    // log prior) into device memory, so an evaluation needs no separate host-to-device copy.
-    extern __shared__ double k1_smem[];
-    // issue the (slow, host-memory) read of this block's first key before the table staging so that the
-    // two latencies overlap
-    const KeyParam kp_first = ep->keys[min((int)blockIdx.z * keys_per_block, nkeys - 1)];
-    if (ep_dev && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-        const int n_sets = ep->n_sets;
-        if (threadIdx.x == 0) {
-            ep_dev->nkeys = nkeys;
-            ep_dev->n_sets = n_sets;
-        }
-        for (int i = threadIdx.x; i < n_sets * kMaxNodes; i += 256)
-            if (i % kMaxNodes < n_nodes) (&ep_dev->node_key[0][0])[i] = (&ep->node_key[0][0])[i];
-        for (int i = threadIdx.x; i < n_prior; i += 256) {
-            ep_dev->logprior[i] = ep->logprior[i];
-            ep_dev->prior[i] = ep->prior[i];
-        }
-    }
-    const int s0 = blockIdx.y * 16;
-    const int c0 = blockIdx.x * 16;
-    const int tx = threadIdx.x & 15;  // s within tile
-    const int ty = threadIdx.x >> 4;  // c within tile
-    const int s = s0 + tx;
-    const int c = c0 + ty;
-    // first kernel of an evaluation: reset the first-zero-family slot K3 will atomicMin into
-    if (first_zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)threadIdx.x < ep->n_sets) first_zero[threadIdx.x] = INT32_MAX;
-
-    // The table runs of this (s, c) tile do not depend on the key: stage them ONCE and build the tile
-    // for keys_per_block keys.  A needs j <= min(s, c) <= min(s0, c0) + 15; B needs i = c - j <= c0 + 15.
-    const double* a;
-    const double* b;
-    if (USE_LDS) {
-        const int nA = min(min(s0, c0) + 16, M + 1);
-        const int nB = min(c0 + 16, M + 1);
-        double* sA = k1_smem;                        // [16][ld_lnc]
-        double* sB = k1_smem + 16 * (size_t)ld_lnc;  // [16][ld_lnc]
-        // thread (r = tid / 16, l = tid % 16) copies row s0 + r, columns l, l+16, ...: 128-byte runs,
-        // eight loads in flight per thread before the first LDS store (the copy is latency-bound)
-        {
-            const int r = threadIdx.x >> 4, l = threadIdx.x & 15;
-            const int sr = min(s0 + r, M);
-            const double* ga = lncA + (size_t)sr * ld_lnc;
-            const double* gb = lncB + (size_t)sr * ld_lnc;
-            double* da = sA + r * ld_lnc;
-            double* db = sB + r * ld_lnc;
-            for (int i0 = l; i0 < nA; i0 += 128) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = (i0 + 16 * u < nA) ? ga[i0 + 16 * u] : 0.0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (i0 + 16 * u < nA) da[i0 + 16 * u] = v[u];
-            }
-            for (int i0 = l; i0 < nB; i0 += 128) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = (i0 + 16 * u < nB) ? gb[i0 + 16 * u] : 0.0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (i0 + 16 * u < nB) db[i0 + 16 * u] = v[u];
-            }
-        }
-        __syncthreads();
-        a = sA + tx * ld_lnc;
-        b = sB + tx * ld_lnc;
-    } else {
-        a = lncA + (size_t)min(s, M) * ld_lnc;
-        b = lncB + (size_t)min(s, M) * ld_lnc;
-    }
-    if (s > M || c > M) return;
-    const int m = min(s, c);
-    const int key_end = min(nkeys, (int)(blockIdx.z + 1) * keys_per_block);
-    for (int key = blockIdx.z * keys_per_block; key < key_end; ++key) {
-        const KeyParam kp = (key == (int)blockIdx.z * keys_per_block) ? kp_first : ep->keys[key];
-        double p;
-        if (s == 0) {
-            p = (c == 0) ? 1.0 : 0.0;  // row 0 is e_0 in every mode (libtree/birthdeath.c:244, :212-215)
-        } else if (kp.mode < 2) {
-            p = (kp.mode == 1 && s == c) ? 1.0 : 0.0;  // zero / identity matrices
-        } else {
-            p = 0.0;
-            // terms are accumulated strictly in j order (the reference's order)
-            if (PRODUCT_FORM && kp.fast_ok) {
-                // Same sum with the exponentials factored: a/b hold exp(ln C) (binomials through the
-                // reference's Lanczos lgamma), the power part alpha^(..) coeff^j is a geometric sequence
-                // kept as mantissa in [1,2) x 2^e so that nothing under/overflows before the final ldexp.
-                // One exp2 per ENTRY instead of one exp per TERM; deviation from the per-term form
-                // <~ 5e-13 relative, the size of the rounding the reference itself commits forming t.
-                const double y0 = (kp.mode == 2) ? (double)(s + c) * kp.l2a : (double)s * kp.l2a + (double)c * kp.l2b;
-                const double e0 = floor(y0);
-                double gm = exp2(y0 - e0);
-                int e = (int)e0;
-#pragma unroll 4
-                for (int j = 0; j <= m; ++j) {
-                    const double term = a[j] * b[c - j] * gm;
-                    p += ldexp(term, e);
-                    gm *= kp.rho_m;
-                    e += kp.rho_e;
-                    if (gm >= 2.0) {
-                        gm *= 0.5;
-                        e += 1;
-                    }
-                }
-            } else if (kp.mode == 2) {
-                double lastterm = 1.0;
-                const int s_add_c = s + c;
-#pragma unroll 4
-                for (int j = 0; j <= m; ++j) {
-                    const double t = a[j] + b[c - j] + (double)(s_add_c - 2 * j) * kp.log_alpha;
-                    p += exp(t) * lastterm;
-                    lastterm *= kp.coeff;
-                }
-            } else {
-#pragma unroll 4
-                for (int j = 0; j <= m; ++j) {
-                    const double t = a[j] + b[c - j] + (double)(s - j) * kp.log_alpha +
-                                     (double)(c - j) * kp.log_beta + (double)j * kp.log_coeff;
-                    p += exp(t);
-                }
-            }
-            p = fmax(fmin(p, 1.0), 0.0);  // MAX(MIN(p,1),0)
-        }
-        PT[(size_t)key * KP * LD + (size_t)c * LD + s] = p;
-    }
+    if (!fn) return fail("internal: kernel shape not built");
+    void* argv[1] = {const_cast<Args*>(&args)};
+    HIP_TRY(hipLaunchKernel(fn, grid, block, argv, lds, stream));
+    return 0;
 }
-
-// ------------------------------------------------------------------------------------
-// K1, register-blocked product form.  Thread = one row s x K1Q consecutive columns c..c+K1Q-1.
-// For a fixed row the power part of term j is the same geometric sequence for every column up to a
-// per-column constant (alpha^q or beta^q), so the K1Q sums share a[j] * rho^j and slide a window over
-// the second binomial run b[c + q - j]:  per 8 terms of K1Q entries the thread issues 8 + 8 LDS reads
-// and 8 + 8 + 8*K1Q FP64 operations, instead of 2 reads + ~10 operations per single term.
-// rho^j is carried as (g in [1,2)) * 2^e, renormalised once per 8-term chunk; inside a chunk plain
-// doubles are safe because the host marks a key fast_ok == 2 only if binomials * rho^8 < 2^1000.
-// Terms are still accumulated in the reference's order (j ascending).  Negative b indices (j > c + q)
-// and a[j] beyond s read staged zeros, which add exact zeros.
-// ------------------------------------------------------------------------------------
-#ifndef CAFEHIP_K1Q
-#define CAFEHIP_K1Q 8
-#endif
-constexpr int K1Q = CAFEHIP_K1Q;
-constexpr int K1_BPAD = 24;  // zeros in front of every staged B row (window indices down to -22)
-
-__global__ __launch_bounds__(256) void k1_build_matrices_rb(const EvalParams* __restrict__ ep,
-                                                            const double* __restrict__ expA,
-                                                            const double* __restrict__ expB, int ld_lnc,
-                                                            double* __restrict__ PT, int M, int LD, int KP,
-                                                            int32_t* first_zero, int keys_per_block,
-                                                            EvalParams* __restrict__ ep_dev, int n_nodes, int n_prior,
-                                                            int nkeys)
-{
-    extern __shared__ double k1_smem[];
-    const KeyParam kp_first = ep->keys[min((int)blockIdx.z * keys_per_block, nkeys - 1)];
-    if (ep_dev && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-        const int n_sets = ep->n_sets;
-        if (threadIdx.x == 0) {
-            ep_dev->nkeys = nkeys;
-            ep_dev->n_sets = n_sets;
-        }
-        for (int i = threadIdx.x; i < n_sets * kMaxNodes; i += 256)
-            if (i % kMaxNodes < n_nodes) (&ep_dev->node_key[0][0])[i] = (&ep->node_key[0][0])[i];
-        for (int i = threadIdx.x; i < n_prior; i += 256) {
-            ep_dev->logprior[i] = ep->logprior[i];
-            ep_dev->prior[i] = ep->prior[i];
-        }
-    }
-    if (first_zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)threadIdx.x < ep->n_sets) first_zero[threadIdx.x] = INT32_MAX;
-    const int s0 = blockIdx.y * 16;
-    const int c0 = blockIdx.x * (16 * K1Q);
-    const int tx = threadIdx.x & 15;   // row within the tile (fast lane index: PT[c][s] stores are 128-byte runs)
-    const int tq = threadIdx.x >> 4;   // column group
-    const int s = s0 + tx;
-    const int cb = c0 + tq * K1Q;      // first column of this thread
-
-    // staged runs: A needs j <= min(s, c+q) (+7 chunk overrun), B needs i = c + q - j in [-22, c0 + 16*K1Q)
-    const int ldA = ld_lnc + 8;                 // odd + 8 = odd: conflict-free over the 16 rows
-    const int ldB = ld_lnc + K1_BPAD + 8;       // odd
-    const int nA = min(min(s0 + 16, c0 + 16 * K1Q), M + 1) + 8;
-    const int nB = min(c0 + 16 * K1Q, M + 1) + 8;
-    double* sA = k1_smem;
-    double* sB = k1_smem + 16 * (size_t)ldA;
-    {
-        const int r = threadIdx.x >> 4, l = threadIdx.x & 15;
-        const int sr = min(s0 + r, M);
-        const double* ga = expA + (size_t)sr * ld_lnc;
-        const double* gb = expB + (size_t)sr * ld_lnc;
-        double* da = sA + r * ldA;
-        double* db = sB + r * ldB + K1_BPAD;
-        for (int i0 = l; i0 < nA; i0 += 128) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (i0 + 16 * u <= M) ? ga[i0 + 16 * u] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (i0 + 16 * u < nA) da[i0 + 16 * u] = v[u];
-        }
-        for (int i0 = l; i0 < nB; i0 += 128) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (i0 + 16 * u <= M) ? gb[i0 + 16 * u] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (i0 + 16 * u < nB) db[i0 + 16 * u] = v[u];
-        }
-        for (int i = l; i < K1_BPAD; i += 16) sB[r * ldB + i] = 0.0;
-    }
-    __syncthreads();
-    if (s > M || cb > M) return;
-    const double* a = sA + tx * ldA;
-    const double* b = sB + tx * ldB + K1_BPAD;
-    const int mmax = min(s, min(cb + K1Q - 1, M));
-    const int key_end = min(nkeys, (int)(blockIdx.z + 1) * keys_per_block);
-    for (int key = blockIdx.z * keys_per_block; key < key_end; ++key) {
-        const KeyParam kp = (key == (int)blockIdx.z * keys_per_block) ? kp_first : ep->keys[key];
-        double p[K1Q];
-        if (s == 0) {
-#pragma unroll
-            for (int q = 0; q < K1Q; ++q) p[q] = (cb + q == 0) ? 1.0 : 0.0;  // row 0 is e_0 in every mode
-        } else if (kp.mode < 2) {
-#pragma unroll
-            for (int q = 0; q < K1Q; ++q) p[q] = (kp.mode == 1 && s == cb + q) ? 1.0 : 0.0;  // zero / identity
-        } else if (kp.fast_ok == 2) {
-            double gm0[K1Q];
-            int e0[K1Q];
-#pragma unroll
-            for (int q = 0; q < K1Q; ++q) {
-                const double y0 = (kp.mode == 2) ? (double)(s + cb + q) * kp.l2a
-                                                 : (double)s * kp.l2a + (double)(cb + q) * kp.l2b;
-                const double ef = floor(y0);
-                gm0[q] = exp2(y0 - ef);
-                e0[q] = (int)ef;
-                p[q] = 0.0;
-            }
-            const double rho = ldexp(kp.rho_m, kp.rho_e);
-            double g = 1.0;
-            int e = 0;
-            double win[K1Q + 7];  // win[d + 7] = b[cb - j0 + d], d in [-7, K1Q)
-#pragma unroll
-            for (int t = 0; t < K1Q + 7; ++t) win[t] = b[cb - 7 + t];
-            for (int j0 = 0; j0 <= mmax; j0 += 8) {
-                double acc[K1Q];
-#pragma unroll
-                for (int q = 0; q < K1Q; ++q) acc[q] = 0.0;
-                double gu = g;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const double ag = a[j0 + u] * gu;
-#pragma unroll
-                    for (int q = 0; q < K1Q; ++q) acc[q] = fma(ag, win[q - u + 7], acc[q]);
-                    gu *= rho;
-                }
-#pragma unroll
-                for (int q = 0; q < K1Q; ++q) p[q] += ldexp(acc[q], e + e0[q]);
-                int ex;
-                g = 2.0 * frexp(gu, &ex);  // gu = g * 2^(ex - 1), g in [1, 2)
-                e += ex - 1;
-                // slide the window by 8 terms: indices move down by 8
-#pragma unroll
-                for (int t = K1Q + 6; t >= 8; --t) win[t] = win[t - 8];
-#pragma unroll
-                for (int t = 0; t < 8 && t < K1Q + 7; ++t) win[t] = b[cb - j0 - 15 + t];
-            }
-#pragma unroll
-            for (int q = 0; q < K1Q; ++q) p[q] = fmax(fmin(p[q] * gm0[q], 1.0), 0.0);
-        } else {
-            // keys whose rho^8 could leave the double range: per-term mantissa/exponent form (as k1_build_matrices)
-#pragma unroll 1
-            for (int q = 0; q < K1Q; ++q) {
-                const int c = cb + q;
-                if (c > M) {
-                    p[q] = 0.0;
-                    continue;
-                }
-                const int m = min(s, c);
-                const double y0 = (kp.mode == 2) ? (double)(s + c) * kp.l2a : (double)s * kp.l2a + (double)c * kp.l2b;
-                const double e0 = floor(y0);
-                double gm = exp2(y0 - e0);
-                int e = (int)e0;
-                double acc = 0.0;
-                for (int j = 0; j <= m; ++j) {
-                    const double term = a[j] * b[c - j] * gm;
-                    acc += ldexp(term, e);
-                    gm *= kp.rho_m;
-                    e += kp.rho_e;
-                    if (gm >= 2.0) {
-                        gm *= 0.5;
-                        e += 1;
-                    }
-                }
-                p[q] = fmax(fmin(acc, 1.0), 0.0);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < K1Q; ++q)
-            if (cb + q <= M) PT[(size_t)key * KP * LD + (size_t)(cb + q) * LD + s] = p[q];
-    }
-}
-#pragma clang fp contract(fast)
-
-// ------------------------------------------------------------------------------------
-// K2 (v1, vector FMA): one workgroup carries NF families through the whole tree.
-// Thread r owns output row r of every node vector; node vectors live in LDS slots
-// [slot][fam][LDv].  Per child edge the thread streams its column of the transposed
-// matrix PT[k][row_lo + r] (coalesced across the workgroup, L2 resident, shared by
-// all families) and accumulates NF dot products with the child's vectors, which are
-// LDS broadcasts.  k runs ascending, i.e. in the reference's summation order
-// (libtree/birthdeath.c:173-180).  A one-hot leaf (cafe/cafe_tree.c:208-209) turns
-// the product into the gather PT[count][row].
-// ------------------------------------------------------------------------------------
-template <int NF, int SMEM_DOUBLES>
-__global__ __launch_bounds__(1024) void k2_prune_v1(K2Args a)
-{
-    // static LDS: gfx950 admits up to 160 KiB per workgroup when declared statically
-    __shared__ double smem[SMEM_DOUBLES];
-    __shared__ int s_cnt[NF][kMaxLeaves];
-    __shared__ int s_colmax[NF];
-
-    const int tid = threadIdx.x;
-    const int r = tid;
-    const int fam0 = blockIdx.x * NF;
-    const size_t slot_stride = (size_t)NF * a.LDv;
-    const bool batch = (a.col_max != nullptr);
-
-    for (int i = tid; i < NF * a.n_leaves; i += blockDim.x) {
-        const int f = i / a.n_leaves, j = i - f * a.n_leaves;
-        const int u = fam0 + f;
-        s_cnt[f][j] = (u < a.Fu) ? a.counts[(size_t)u * a.n_leaves + j] : 0;
-    }
-    if (tid < NF) {
-        const int u = fam0 + tid;
-        s_colmax[tid] = (batch && u < a.Fu) ? a.col_max[u] : (a.C - 1);
-    }
-    __syncthreads();
-
-    const int err_slot = a.n_slots;  // scratch slot for error-model leaf vectors
-    int root_slot = 0;
-
-    for (int oi = 0; oi < a.n_ops; ++oi) {
-        const cafehip::PruneOp op = a.ops[oi];
-        const int rows = op.is_root ? a.R : a.C;
-        const int row_lo = op.is_root ? a.root_min : 0;
-        double y[2][NF];
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            const double* PTc =
-                a.PT + (size_t)a.ep->node_key[0][op.child[ch]] * a.KP * a.LD + row_lo + r;
-            const bool errleaf =
-                (op.kind[ch] == 0) && a.err != nullptr && a.leaf_has_err[op.src[ch]];
-            if (op.kind[ch] == 0 && !errleaf) {
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const int cnt = s_cnt[f][op.src[ch]];
-                    y[ch][f] = (r < rows && cnt <= s_colmax[f]) ? PTc[(size_t)cnt * a.LD] : 0.0;
-                }
-            } else {
-                const double* src;
-                if (errleaf) {
-                    // leaf vector = errormatrix[observed][0..C) (cafe/cafe_tree.c:196-203)
-                    double* es = smem + (size_t)err_slot * slot_stride;
-                    __syncthreads();
-                    for (int i = tid; i < NF * a.LDv; i += blockDim.x) {
-                        const int f = i / a.LDv, k = i - f * a.LDv;
-                        const int cnt = s_cnt[f][op.src[ch]];
-                        es[i] = (k < a.C && k <= s_colmax[f]) ? a.err[(size_t)cnt * a.err_ld + k] : 0.0;
-                    }
-                    __syncthreads();
-                    src = es;
-                } else {
-                    src = smem + (size_t)op.src[ch] * slot_stride;
-                }
-#pragma unroll
-                for (int f = 0; f < NF; ++f) y[ch][f] = 0.0;
-                if (r < rows) {
-                    for (int k = 0; k < a.C; k += 2) {
-                        const double p0 = PTc[(size_t)k * a.LD];
-                        const double p1 = PTc[(size_t)(k + 1) * a.LD];
-#pragma unroll
-                        for (int f = 0; f < NF; ++f) {
-                            const double2 l = *reinterpret_cast<const double2*>(src + f * a.LDv + k);
-                            y[ch][f] = fma(p0, l.x, y[ch][f]);
-                            y[ch][f] = fma(p1, l.y, y[ch][f]);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();  // every read of the source slots is done: dst may alias a source
-        double* dst = smem + (size_t)op.dst * slot_stride;
-        for (int rr = tid; rr < a.LDv; rr += blockDim.x) {
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                double v = 0.0;
-                if (rr == r && r < rows) {
-                    v = y[0][f] * y[1][f];
-                    // rows beyond this family's column range do not exist in the reference
-                    // (range.max is per call there); zero them so they add exact zeros upstream
-                    if (!op.is_root && r > s_colmax[f]) v = 0.0;
-                }
-                dst[f * a.LDv + rr] = v;
-            }
-        }
-        __syncthreads();
-        root_slot = op.dst;
-    }
-
-    // ---- root vector -> posterior (cafe/lambda.cpp:657-689) or packed root rows ----
-    const double* Lr = smem + (size_t)root_slot * slot_stride;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int nwaves = blockDim.x >> 6;
-    for (int f = wave; f < NF; f += nwaves) {
-        const int u = fam0 + f;
-        if (u >= a.Fu) continue;
-        const double* L = Lr + f * a.LDv;
-        if (batch) {
-            const int lo = a.root_lo[u] - a.root_min, hi = a.root_hi[u] - a.root_min;
-            double* o = a.out_root + a.out_off[u];
-            for (int i = lo + lane; i <= hi; i += 64) o[i - lo] = L[i];
-            continue;
-        }
-        double best = -INFINITY, bestp = -INFINITY;
-        int bi = INT_MAX;  // INT_MAX = this lane has seen no element yet
-        for (int i = lane; i < a.R; i += 64) {
-            const double v = L[i];
-            if (bi == INT_MAX || v > best) {
-                best = v;
-                bi = i;
-            }
-            const double p = exp(log(v) + a.ep->logprior[i]);
-            bestp = fmax(bestp, p);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ov = __shfl_xor(best, off);
-            const int oi2 = __shfl_xor(bi, off);
-            const double op2 = __shfl_xor(bestp, off);
-            // first maximum wins (libcommon/mathfunc.c:9-24): larger value, then lower index
-            if (oi2 != INT_MAX && (bi == INT_MAX || ov > best || (ov == best && oi2 < bi))) {
-                best = ov;
-                bi = oi2;
-            }
-            bestp = fmax(bestp, op2);
-        }
-        if (lane == 0) {
-            a.max_lik[u] = best;
-            a.argmax[u] = bi;
-            a.max_post[u] = bestp;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// K3: score.  One workgroup per chunk of CAFEHIP_CHUNK families in FAMILY order
-// (duplicates expanded through fam2u), fixed-shape tree sum -> chunk_sums[chunk].
-// ------------------------------------------------------------------------------------
-// Results of the synchronous path go straight to pinned, device-visible host memory (no copy kernels,
-// no interrupt-driven wait): every block stores its chunk sum there, the last block to arrive (device
-// counter) publishes the first-zero index and a sequence number the host spins on.
-struct HostResult {
-    volatile int32_t done_seq;
-    int32_t first_zero[kMaxSets];
-    int32_t pad;
-    double chunk_sums[1];  // [n_sets][n_chunks]
-};
-
-template <bool HOST_OUT>
-__global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(const double* __restrict__ max_post_u,
-                                                          const double* __restrict__ max_lik_u,
-                                                          const int32_t* __restrict__ fam2u, int F, int Fu,
-                                                          double* __restrict__ chunk_sums,
-                                                          int32_t* __restrict__ first_zero,
-                                                          HostResult* host, int32_t* arrive, int32_t seq)
-{
-    // blockIdx.y = parameter set: its per-family values start at set * Fu, its chunk sums at set * gridDim.x
-    __shared__ double red[CAFEHIP_CHUNK];
-    __shared__ int s_last;
-    const int set = blockIdx.y;
-    max_post_u += (size_t)set * Fu;
-    max_lik_u += (size_t)set * Fu;
-    const int i = blockIdx.x * CAFEHIP_CHUNK + threadIdx.x;
-    double v = 0.0;
-    if (i < F) {
-        const int u = fam2u[i];
-        v = log(max_post_u[u]);                                   // cafe/lambda.cpp:721
-        if (max_lik_u[u] == 0.0) atomicMin(first_zero + set, i);  // cafe/lambda.cpp:715-720
-    }
-    red[threadIdx.x] = v;
-    __syncthreads();
-#pragma unroll
-    for (int s = CAFEHIP_CHUNK / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    const size_t slot = (size_t)set * gridDim.x + blockIdx.x;
-    if (!HOST_OUT) {
-        if (threadIdx.x == 0) chunk_sums[slot] = red[0];
-        return;
-    }
-    if (threadIdx.x == 0) {
-        host->chunk_sums[slot] = red[0];
-        __threadfence_system();
-        s_last = (atomicAdd(arrive, 1) == (int)(gridDim.x * gridDim.y) - 1);
-    }
-    __syncthreads();
-    if (s_last && threadIdx.x == 0) {
-        __threadfence();
-        for (int q = 0; q < (int)gridDim.y; ++q) host->first_zero[q] = atomicMin(first_zero + q, INT32_MAX);  // atomic read of the final value
-        *arrive = 0;
-        __threadfence_system();
-        host->done_seq = seq;
-    }
-}
-
-
-// ------------------------------------------------------------------------------------
-// K3 of the k-cluster model (cafe_get_clustered_posterior, cafe/cafe_main.c:165-253).  K2 has left the per-family
-// max posterior of every cluster (set) in max_post_u[k * Fu + u].  Per family, clusters ascending as the reference
-// loops them: MAP_k = max_post_k * weight_k (:196), sum (:197), membership p_z[k] = MAP_k / sum (:204),
-// MAP = sum_k p_z[k] * MAP_k (:210-213); the score adds log(MAP) (:241) and the new weights are the mean memberships
-// (:243-245).  One workgroup per chunk of CAFEHIP_CHUNK families in family order, fixed-shape tree sums for the
-// score and for each cluster's membership; MAP == 0 marks the family (:231-240).
-// ------------------------------------------------------------------------------------
-struct ClusterWeights {
-    double w[kMaxSets];
-};
-
-__global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_cluster_score(const double* __restrict__ max_post_u,
-                                                                  const int32_t* __restrict__ fam2u, int F, int Fu, int K,
-                                                                  ClusterWeights cw, double* __restrict__ chunk_sums,
-                                                                  double* __restrict__ memb_sums /* [K][n_chunks] */,
-                                                                  int32_t* __restrict__ first_zero,
-                                                                  double* __restrict__ map_out /* [F] or NULL */,
-                                                                  double* __restrict__ pz_out /* [F][K] or NULL */)
-{
-    __shared__ double red[CAFEHIP_CHUNK];
-    const int i = blockIdx.x * CAFEHIP_CHUNK + threadIdx.x;
-    double pz[kMaxSets];
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k < kMaxSets; ++k) pz[k] = 0.0;
-    if (i < F) {
-        const int u = fam2u[i];
-        double mapk[kMaxSets];
-        double sum = 0.0;
-#pragma unroll
-        for (int k = 0; k < kMaxSets; ++k) {
-            mapk[k] = 0.0;
-            if (k < K) {
-                mapk[k] = max_post_u[(size_t)k * Fu + u] * cw.w[k];
-                sum += mapk[k];
-            }
-        }
-        double expected = 0.0;
-#pragma unroll
-        for (int k = 0; k < kMaxSets; ++k) {
-            if (k < K) {
-                pz[k] = mapk[k] / sum;
-                expected += pz[k] * mapk[k];
-                if (pz_out) pz_out[(size_t)i * K + k] = pz[k];
-            }
-        }
-        if (map_out) map_out[i] = expected;
-        if (expected == 0.0) atomicMin(first_zero, i);
-        v = log(expected);
-    }
-    // score, then one tree sum per cluster membership
-    for (int q = -1; q < K; ++q) {
-        double x = v;
-#pragma unroll
-        for (int k = 0; k < kMaxSets; ++k)
-            if (q == k) x = pz[k];
-        __syncthreads();
-        red[threadIdx.x] = x;
-        __syncthreads();
-#pragma unroll
-        for (int s = CAFEHIP_CHUNK / 2; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            if (q < 0) chunk_sums[blockIdx.x] = red[0];
-            else memb_sums[(size_t)q * gridDim.x + blockIdx.x] = red[0];
-        }
-    }
-}
-
-// device words -> pinned host mirror, then a sequence number (cafehip_fetch_small)
-__global__ __launch_bounds__(256) void k_fetch_small(const uint64_t* __restrict__ src, uint64_t* host_dst, size_t n_words,
-                                                     volatile int32_t* host_seq, int32_t seq)
-{
-    for (size_t i = threadIdx.x; i < n_words; i += 256) host_dst[i] = src[i];
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) *host_seq = seq;
-}
-
-#include "k2_mfma.hpp"
-
-// ------------------------------------------------------------------------------------
-// K4: Viterbi (cafe/viterbi.cpp:208-351).  Same walk as K2 with (max, argmax) in place of the
-// sum: thread r owns row r, factor[r] = max_k PT[k][row] * L_child[k] with strict '>' over
-// ascending k (first maximum wins), node vector = product of the two factors; the argmax
-// tables of the internal children stay in LDS (16-bit) and one thread per family backtracks
-// root -> leaves in prefix order.  No sums: every value is a chain of single multiplications,
-// so given the same matrices the sizes equal a host evaluation bit for bit.
-// ------------------------------------------------------------------------------------
-struct K4Args {
-    const double* PT;
-    const EvalParams* ep;
-    const cafehip::PruneOp* ops;
-    int n_ops;
-    const int32_t* counts;
-    int B, n_leaves, n_nodes;
-    int C, R, root_min;
-    int LD, KP, LDv;
-    int n_slots;
-    int root;
-    const int32_t* parent;     // [n_nodes]
-    const int32_t* prefix;     // [n_nodes] prefix order
-    const int32_t* vit_slot;   // [n_nodes] table index of internal non-root nodes, -1 otherwise
-    int n_tables;
-    const int32_t* root_lo;
-    const int32_t* root_hi;
-    const int32_t* col_max;
-    int32_t* node_sizes;       // [B][n_nodes]
-    unsigned short* vit_global;  // argmax tables in global scratch [grid][n_tables][NF][LDv], or NULL: in LDS
-};
-
-template <int NF>
-__global__ __launch_bounds__(1024) void k4_viterbi(K4Args a)
-{
-    extern __shared__ double smem4[];
-    double* slots = smem4;                                                  // [n_slots][NF][LDv]
-    // argmax tables [n_tables][NF][LDv]: written once per (node, row), read ~n_nodes times per family by the
-    // backtrack -- in global scratch they cost next to no traffic and leave LDS to the node vectors, i.e. several
-    // workgroups per CU instead of one (the k loop is latency-bound at one wave per SIMD)
-    unsigned short* vit = a.vit_global
-                              ? a.vit_global + (size_t)blockIdx.x * a.n_tables * NF * a.LDv
-                              : reinterpret_cast<unsigned short*>(slots + (size_t)a.n_slots * NF * a.LDv);
-    __shared__ int s_cnt[NF][kMaxLeaves];
-    __shared__ int s_colmax[NF];
-
-    const int tid = threadIdx.x;
-    const int r = tid;
-    const int fam0 = blockIdx.x * NF;
-    const size_t slot_stride = (size_t)NF * a.LDv;
-
-    for (int i = tid; i < NF * a.n_leaves; i += blockDim.x) {
-        const int f = i / a.n_leaves, j = i - f * a.n_leaves;
-        const int u = fam0 + f;
-        s_cnt[f][j] = (u < a.B) ? a.counts[(size_t)u * a.n_leaves + j] : 0;
-    }
-    if (tid < NF) s_colmax[tid] = (fam0 + tid < a.B) ? a.col_max[fam0 + tid] : (a.C - 1);
-    if (!a.vit_global)   // (every entry the backtrack reads is written by the walk; the LDS copy is cleared for tidiness)
-        for (int i = tid; i < a.n_tables * NF * a.LDv; i += blockDim.x) vit[i] = 0;
-    __syncthreads();
-
-    int root_slot = 0;
-    for (int oi = 0; oi < a.n_ops; ++oi) {
-        const cafehip::PruneOp op = a.ops[oi];
-        const int rows = op.is_root ? a.R : a.C;
-        const int row_lo = op.is_root ? a.root_min : 0;
-        double y[2][NF];
-        int arg[2][NF];
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            const double* PTc = a.PT + (size_t)a.ep->node_key[0][op.child[ch]] * a.KP * a.LD + row_lo + r;
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                y[ch][f] = 0.0;
-                arg[ch][f] = 0;
-            }
-            if (op.kind[ch] == 0) {
-                // one-hot leaf: the only non-zero product is at k = count
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const int cnt = s_cnt[f][op.src[ch]];
-                    if (r < rows && cnt <= s_colmax[f]) y[ch][f] = PTc[(size_t)cnt * a.LD];
-                }
-            } else if (r < rows) {
-                const double* src = slots + (size_t)op.src[ch] * slot_stride;
-                for (int k = 0; k < a.C; ++k) {
-                    const double pv = PTc[(size_t)k * a.LD];
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) {
-                        const double tmp = pv * src[f * a.LDv + k];
-                        if (tmp > y[ch][f]) {   // cafe/viterbi.cpp:296-300
-                            y[ch][f] = tmp;
-                            arg[ch][f] = k;
-                        }
-                    }
-                }
-            }
-            if (op.kind[ch] == 1 && r < rows) {
-                const int tb = a.vit_slot[op.child[ch]];
-#pragma unroll
-                for (int f = 0; f < NF; ++f) vit[((size_t)tb * NF + f) * a.LDv + r] = (unsigned short)arg[ch][f];
-            }
-        }
-        __syncthreads();
-        double* dst = slots + (size_t)op.dst * slot_stride;
-        for (int rr = tid; rr < a.LDv; rr += blockDim.x) {
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                double v = 0.0;
-                if (rr == r && r < rows) {
-                    v = y[0][f] * y[1][f];
-                    if (!op.is_root && r > s_colmax[f]) v = 0.0;
-                }
-                dst[f * a.LDv + rr] = v;
-            }
-        }
-        __syncthreads();
-        root_slot = op.dst;
-    }
-
-    __threadfence_block();
-    __syncthreads();
-    // backtrack (cafe/viterbi.cpp:322-351): one thread per family, prefix order
-    if (tid < NF && fam0 + tid < a.B) {
-        const int f = tid;
-        const int u = fam0 + f;
-        int32_t* out = a.node_sizes + (size_t)u * a.n_nodes;
-        const double* L = slots + (size_t)root_slot * slot_stride + f * a.LDv;
-        const int lo = a.root_lo[u], hi = a.root_hi[u];
-        for (int j = 0; j < a.n_leaves; ++j) out[2 * j] = s_cnt[f][j];
-        int best = 0;
-        if (hi >= lo) {
-            double bv = L[lo - a.root_min];
-            for (int s = lo + 1; s <= hi; ++s) {
-                const double v = L[s - a.root_min];
-                if (bv < v) {   // __maxidx: first maximum
-                    bv = v;
-                    best = s - lo;
-                }
-            }
-        }
-        out[a.root] = lo + best;
-        for (int pi = 0; pi < a.n_nodes; ++pi) {
-            const int node = a.prefix[pi];
-            if (node == a.root || (node & 1) == 0) continue;   // leaves keep their counts
-            const int par = a.parent[node];
-            const int ps = out[par];
-            int idx = ps;                      // base = range.min = 0
-            int size;
-            if (par == a.root) {
-                // rows of a root child are indexed by root size; an empty root range computes none of
-                // them in the reference (stale zeros)
-                idx = ps - a.root_min;
-                size = (hi >= lo && idx >= 0 && idx < a.R) ? vit[((size_t)a.vit_slot[node] * NF + f) * a.LDv + idx] : 0;
-            } else {
-                size = (idx >= 0 && idx < a.C) ? vit[((size_t)a.vit_slot[node] * NF + f) * a.LDv + idx] : 0;
-            }
-            out[node] = size;
-        }
-    }
-}
-
 
 }  // namespace
 
@@ -953,6 +130,27 @@ struct cafehip_ctx {
         size_t tables_cap = 0;              // elements
         long states = 0;                    // sum of D over the compressed nodes
     } cp;
+    // run-time switches (cafehip_set_option; CAFEHIP_<NAME> in the environment is read ONCE, by cafehip_create)
+    struct Options {
+        int compress = 1;             // subtree-state compression of the objective path
+        double compress_theta = -1;   // < 0: by table size and matrix side (rebuild_compression)
+        int compress_min = 64;        // unique rows below which a table is left alone
+        int errfold = 1;              // error model folded into the matrices (posterior mode)
+        int errband = 1;              // banded error models as short sums of gathers
+        int k1 = 0;                   // 0 auto, 1 exact form, 2 per-term product form
+        int k1_kpb = 1;               // keys per K1 workgroup
+        int k2 = 0;                   // 0 matrix cores, 1 row-per-thread kernel (k2_prune_v1)
+        int mfma = 0;                 // 0 either shape, 4 / 16: only that one
+        bool have_cfg16 = false, have_cfg4 = false;
+        int cfg16[4] = {0, 0, 0, 0}, cfg4[4] = {0, 0, 0, 0};   // pinned wave grids "nftw|G,nrtw,wf,wr"
+        int k2tune = 1;               // measured choice of the wave grid
+        int k2tune_log = 0;
+        int k2slots = 1;              // park scratch by resident workgroup (0: one region per family tile)
+        int ldspark = -1;             // park buffers kept in LDS (< 0: by residency)
+        int vitlds = 0;               // Viterbi argmax tables in LDS
+        int k2c_prefetch = 0;         // k2c_nodes: k-steps of the matrix operand requested up front (0: the walk's short ring, -1: that + batched gathers)
+        int batch_trim = 1;           // batch mode: a tile's products stop at its largest column limit (round 3)
+    } opt;
     bool walk_compressed = false;           // the MFMA launcher walks the reduced tree (set around one launch)
     bool last_compressed = false;           // ... and the last objective evaluation did
     std::vector<int32_t> h_ucounts;         // unique rows, host copy
@@ -979,8 +177,6 @@ struct cafehip_ctx {
     double *d_expA = nullptr, *d_expB = nullptr;
     bool all_keys_fast = false, k1_product_form = false;
     bool force_exact = false;   // cafehip_set_exact_matrices: the reference's per-term arithmetic for the next builds
-    size_t k1rb_lds_attr = 0;
-    size_t k1_lds_attr = 0;
     // hipFuncAttributeMaxDynamicSharedMemorySize already granted, per kernel instantiation: the attribute is
     // per DEVICE, so the high-water marks live in the context (several contexts of one process may sit on
     // different GPUs)
@@ -998,13 +194,18 @@ struct cafehip_ctx {
     size_t pt_keys_cap = 0;
 
     // per-evaluation parameters (ring of pinned staging buffers)
-    EvalParams* h_params[kParamRing] = {};
+    EvalHeader* h_params[kParamRing] = {};   // pinned, device-mapped; sized by the tree (eval_block_bytes)
     hipEvent_t h_params_ev[kParamRing] = {};
     int ring_pos = 0;
-    const EvalParams* cur_params = nullptr;  // staged block the next K1 launch reads
-    int cur_prior_n = 0, cur_slot = 0;
-    EvalParams* d_params = nullptr;
+    int key_cap = 0;                          // KeyParam slots of a ring block: kMaxSets x (n_nodes - 1)
+    size_t ring_bytes = 0;
+    const EvalHeader* cur_params = nullptr;   // staged block the next K1 launch reads
+    int cur_slot = 0, cur_sets = 1;
+    int32_t* d_node_key = nullptr;            // [kMaxSets][n_nodes] mirror of the staged node -> matrix map (K1 writes it)
+    double *d_prior = nullptr, *d_logprior = nullptr;   // [kMaxPrior] the prior of the evaluations and its logarithms
     std::vector<int> node_key;
+    std::vector<double> stage_l, stage_m;   // key dedup scratch of stage_params (kept: no allocation per evaluation)
+    std::vector<int> stage_b;
     std::vector<double> prior_seen, logprior_seen;   // the last prior staged and its logarithms
     int nkeys = 0;
     bool have_matrices = false;
@@ -1012,7 +213,7 @@ struct cafehip_ctx {
     // error model
     double* d_err = nullptr;
     int err_mfs = -1;
-    int err_banded = 0, err_dlo = 0, err_dhi = 0;
+    int err_banded = 0, err_dlo = 0, err_dhi = 0, err_band_width = 0;
     uint8_t* d_leaf_has_err = nullptr;
 
     // pinned, device-visible result block of the synchronous path
@@ -1092,13 +293,12 @@ int ensure_matrix_storage(cafehip_ctx* c, size_t min_keys = 0)
 }
 
 // Posterior mode with an error model: fold it into this evaluation's matrices (k1e_fold_error), so that every
-// leaf stays a column gather.  CAFEHIP_ERRFOLD=0 keeps the per-family sums (A/B runs).
+// leaf stays a column gather.  Option errfold=0 keeps the per-family sums (A/B runs).
 int launch_error_fold(cafehip_ctx* c)
 {
     c->fold_current = false;
     if (!c->d_err || c->nkeys == 0) return 0;
-    if (const char* e = getenv("CAFEHIP_ERRFOLD"))
-        if (atoi(e) == 0) return 0;
+    if (!c->opt.errfold) return 0;
     const size_t need = c->pt_keys_cap * (size_t)c->KP * c->LD * sizeof(double);
     if (!c->d_PTfold || c->ptfold_cap < need) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1110,17 +310,38 @@ int launch_error_fold(cafehip_ctx* c)
         c->ptfold_cap = need;
     }
     dim3 grid((c->LD + 255) / 256, c->C, c->nkeys);
-    hipLaunchKernelGGL(k1e_fold_error, grid, dim3(256), 0, c->stream, c->d_PT, c->d_PTfold, c->d_err, c->err_mfs + 1,
-                       c->err_banded, c->err_dlo, c->err_dhi, c->C, c->KP, c->LD);
-    HIP_TRY(hipGetLastError());
+    FoldArgs fa{c->d_PT, c->d_PTfold, c->d_err, c->err_mfs + 1, c->err_banded, c->err_dlo, c->err_dhi, c->C, c->KP, c->LD};
+    if (launch_kernel(k1e_fold_kernel(), grid, dim3(256), 0, c->stream, fa)) return -1;
     c->fold_current = true;
     return 0;
 }
 
+// the parameter ring is sized by the tree: (re)allocated by cafehip_set_tree
+int ensure_param_ring(cafehip_ctx* c)
+{
+    const int key_cap = kMaxSets * std::max(c->n_nodes - 1, 1);
+    const size_t bytes = eval_block_bytes(key_cap, c->n_nodes);
+    if (c->h_params[0] && bytes <= c->ring_bytes && key_cap == c->key_cap) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < kParamRing; ++i) {
+        if (c->h_params[i]) hipHostFree(c->h_params[i]);
+        c->h_params[i] = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&c->h_params[i], bytes, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(c->h_params[i], 0, bytes);
+    }
+    hipFree(c->d_node_key);
+    c->d_node_key = nullptr;
+    HIP_TRY(hipMalloc(&c->d_node_key, (size_t)kMaxSets * c->n_nodes * sizeof(int32_t)));
+    HIP_TRY(hipMemset(c->d_node_key, 0, (size_t)kMaxSets * c->n_nodes * sizeof(int32_t)));
+    c->key_cap = key_cap;
+    c->ring_bytes = bytes;
+    return 0;
+}
+
 // host part of reset_birthdeath_cache: unique keys over non-root nodes
-// (cafe/cafe_tree.c:374-391, 461-483) -> staged EvalParams
+// (cafe/cafe_tree.c:374-391, 461-483) -> staged parameter block
 int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_mu,
-                 const double* prior, EvalParams** out_h, int n_sets = 1)
+                 const double* prior, int n_sets = 1)
 {
     if (c->n_nodes <= 0) return fail("no tree set");
     if (c->M < 0) return fail("no families/ranges set");
@@ -1128,16 +349,22 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
     const int slot = c->ring_pos;
     c->ring_pos = (c->ring_pos + 1) % kParamRing;
     HIP_TRY(hipEventSynchronize(c->h_params_ev[slot]));
-    EvalParams* h = c->h_params[slot];
+    EvalHeader* h = c->h_params[slot];
+    KeyParam* keys = eval_keys(h);
+    int32_t* node_key = eval_node_key(h, c->key_cap);
     c->node_key.assign(c->n_nodes, -1);
     int nk = 0;
-    std::vector<double> kl, km;
-    std::vector<int> kb;
+    auto& kl = c->stage_l;
+    auto& km = c->stage_m;
+    auto& kb = c->stage_b;
+    kl.clear();
+    km.clear();
+    kb.clear();
     for (int set = 0; set < n_sets; ++set) {
         const double* nl = node_lambda + (size_t)set * c->n_nodes;
         const double* nm = node_mu + (size_t)set * c->n_nodes;
         for (int i = 0; i < c->n_nodes; ++i) {
-            h->node_key[set][i] = 0;
+            node_key[(size_t)set * c->n_nodes + i] = 0;
             if (i == c->root) continue;
             if (!(c->bl[i] > 0))
                 return fail("node %d has branch length %g <= 0: the reference binds no matrix to it "
@@ -1147,136 +374,130 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
             for (; k < nk; ++k)
                 if (kb[k] == bl && kl[k] == nl[i] && km[k] == nm[i]) break;
             if (k == nk) {
-                if (nk == kMaxNodes) return fail("more than %d distinct matrices in one evaluation", kMaxNodes);
+                if (nk == c->key_cap) return fail("more than %d distinct matrices in one evaluation", c->key_cap);
                 kb.push_back(bl);
                 kl.push_back(nl[i]);
                 km.push_back(nm[i]);
                 const cafehip::KeyScalars ks = cafehip::key_scalars(bl, nl[i], nm[i]);
-                h->keys[k].log_alpha = ks.log_alpha;
-                h->keys[k].log_beta = ks.log_beta;
-                h->keys[k].log_coeff = ks.log_coeff;
-                h->keys[k].coeff = ks.coeff;
-                h->keys[k].mode = ks.mode;
-                h->keys[k].bl = bl;
-                h->keys[k].l2a = ks.l2a;
-                h->keys[k].l2b = ks.l2b;
-                h->keys[k].rho_m = ks.rho_m;
-                h->keys[k].rho_e = ks.rho_e;
+                keys[k].log_alpha = ks.log_alpha;
+                keys[k].log_beta = ks.log_beta;
+                keys[k].log_coeff = ks.log_coeff;
+                keys[k].coeff = ks.coeff;
+                keys[k].mode = ks.mode;
+                keys[k].bl = bl;
+                keys[k].l2a = ks.l2a;
+                keys[k].l2b = ks.l2b;
+                keys[k].rho_m = ks.rho_m;
+                keys[k].rho_e = ks.rho_e;
                 // 2: the register-blocked kernel may run rho^j in plain doubles over 8-term chunks without leaving
                 // the double range (binomial products * rho^8 stay below 2^1000); 1: per-term mantissa/exponent form
-                h->keys[k].fast_ok = !ks.fast_ok ? 0 : ((8.0 * std::abs(ks.rho_e) + c->lnc.log2_max_prod + 8.0 < 1000.0) ? 2 : 1);
+                keys[k].fast_ok = !ks.fast_ok ? 0 : ((8.0 * std::abs(ks.rho_e) + c->lnc.log2_max_prod + 8.0 < 1000.0) ? 2 : 1);
                 ++nk;
             }
             if (set == 0) c->node_key[i] = k;
-            h->node_key[set][i] = k;
+            node_key[(size_t)set * c->n_nodes + i] = k;
         }
     }
     h->nkeys = nk;
     h->n_sets = n_sets;
+    h->n_nodes = c->n_nodes;
+    h->key_cap = c->key_cap;
     c->nkeys = nk;
     c->all_keys_fast = true;
     for (int k = 0; k < nk; ++k)
-        if (h->keys[k].mode >= 2 && !h->keys[k].fast_ok) c->all_keys_fast = false;
+        if (keys[k].mode >= 2 && !keys[k].fast_ok) c->all_keys_fast = false;
     if (prior) {
         // compute_posterior adds log(prior[j]) (cafe/lambda.cpp:681); the log is taken on the host -- once per prior:
-        // a search hands over the same prior at every evaluation
+        // a search hands over the same prior at every evaluation, and the device copy is refreshed only when it
+        // changes (a pageable source: the copy has left the vectors when the call returns)
         if ((int)c->prior_seen.size() != c->R || memcmp(c->prior_seen.data(), prior, sizeof(double) * c->R) != 0) {
             c->prior_seen.assign(prior, prior + c->R);
             c->logprior_seen.resize(c->R);
             for (int j = 0; j < c->R; ++j) c->logprior_seen[j] = std::log(prior[j]);
+            HIP_TRY(hipMemcpyAsync(c->d_prior, c->prior_seen.data(), sizeof(double) * c->R, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_logprior, c->logprior_seen.data(), sizeof(double) * c->R, hipMemcpyHostToDevice, c->stream));
         }
-        memcpy(h->logprior, c->logprior_seen.data(), sizeof(double) * c->R);
-        memcpy(h->prior, prior, sizeof(double) * c->R);
     }
     if (ensure_matrix_storage(c, (size_t)nk)) return -1;
-    *out_h = h;
     c->cur_params = h;
-    c->cur_prior_n = prior ? c->R : 0;
     c->cur_slot = slot;
+    c->cur_sets = n_sets;
     return 0;
 }
 
+// The pinned block may be rewritten once K1 has consumed it.  Every path that staged a block records the slot's
+// event -- on success behind the evaluation's LAST launch (a marker packet between K1 and the next kernel cost ~5 us
+// of every evaluation), and on EVERY early return too (a slot left unrecorded would look free to hipEventSynchronize
+// eight stagings later while K1 might still be reading it).
+struct RingGuard {
+    cafehip_ctx* c;
+    bool armed = false;
+    explicit RingGuard(cafehip_ctx* ctx) : c(ctx) {}
+    void arm() { armed = true; }
+    int record_now()
+    {
+        armed = false;
+        HIP_TRY(hipEventRecord(c->h_params_ev[c->cur_slot], c->stream));
+        return 0;
+    }
+    ~RingGuard()
+    {
+        if (armed) (void)hipEventRecord(c->h_params_ev[c->cur_slot], c->stream);
+    }
+};
+
 int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr, bool defer_ring_event = false)
 {
-    const EvalParams* hp = c->cur_params;  // pinned host block staged by stage_params
-    const int n_prior = c->cur_prior_n;
     if (c->nkeys == 0) return 0;
     // table rows are staged once per workgroup and reused for keys_per_block keys; keep >= ~3 workgroups
-    // per CU in flight
-    const int tiles = ((c->S + 15) / 16) * ((c->S + 15) / 16);
-    int kpb = 1;  // measured: more keys per block only lengthens the heavy tiles (tools/sweep_k1.py)
-    (void)tiles;
-    if (const char* e = getenv("CAFEHIP_K1KPB")) kpb = std::max(1, atoi(e));
+    // per CU in flight.  Measured: more keys per block only lengthens the heavy tiles (tools/sweep_k1.py)
+    const int kpb = std::max(1, c->opt.k1_kpb);
+    K1Args a;
+    memset(&a, 0, sizeof a);
+    a.ep = c->cur_params;   // pinned host block staged by stage_params
+    a.ld_lnc = c->lnc.ld;
+    a.PT = c->d_PT;
+    a.M = c->M;
+    a.LD = c->LD;
+    a.KP = c->KP;
+    a.first_zero = d_first_zero;
+    a.keys_per_block = kpb;
+    a.node_key_dev = c->d_node_key;
+    a.n_nodes = c->n_nodes;
+    a.n_sets = c->cur_sets;
+    a.nkeys = c->nkeys;
+    a.key_cap = c->key_cap;
     dim3 grid((c->S + 15) / 16, (c->S + 15) / 16, (c->nkeys + kpb - 1) / kpb);
     size_t lds = 2 * 16 * (size_t)c->lnc.ld * sizeof(double);
-    const int use_lds = lds <= 150 * 1024;  // bigger tables are read through L1/L2 instead
+    const bool use_lds = lds <= 150 * 1024;  // bigger tables are read through L1/L2 instead
     if (!use_lds) lds = 0;
-    if (lds > 48 * 1024 && lds > c->k1_lds_attr) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_build_matrices<true, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_build_matrices<true, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        c->k1_lds_attr = lds;
-    }
-    const char* k1env = getenv("CAFEHIP_K1");
-    const bool product = c->lnc.product_form_ok && c->all_keys_fast && !c->force_exact && !(k1env && strcmp(k1env, "exact") == 0);
+    const bool product = c->lnc.product_form_ok && c->all_keys_fast && !c->force_exact && c->opt.k1 != 1;
     c->k1_product_form = product;
-    const bool blocked = product && !(k1env && strcmp(k1env, "perterm") == 0);
-    const size_t lds_rb = 16 * (size_t)((c->lnc.ld + 8) + (c->lnc.ld + K1_BPAD + 8)) * sizeof(double);
+    const bool blocked = product && c->opt.k1 != 2;
+    const int K1Q = k1_rb_columns();
+    const size_t lds_rb = 16 * (size_t)((c->lnc.ld + 8) + (c->lnc.ld + k1_rb_bpad() + 8)) * sizeof(double);
     if (blocked && lds_rb <= 150 * 1024) {
-        if (lds_rb > 48 * 1024 && lds_rb > c->k1rb_lds_attr) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_build_matrices_rb),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rb));
-            c->k1rb_lds_attr = lds_rb;
-        }
-        int kpb_rb = 1;
-        if (const char* e = getenv("CAFEHIP_K1KPB")) kpb_rb = std::max(1, atoi(e));
-        dim3 grid_rb((c->S + 16 * K1Q - 1) / (16 * K1Q), (c->S + 15) / 16, (c->nkeys + kpb_rb - 1) / kpb_rb);
-        hipLaunchKernelGGL(k1_build_matrices_rb, grid_rb, dim3(256), lds_rb, c->stream, hp, c->d_expA, c->d_expB,
-                           c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb_rb, c->d_params, c->n_nodes,
-                           n_prior, c->nkeys);
-    } else if (product) {
-        // every key of this evaluation qualifies: the staged tables are exp(ln C)
-        if (use_lds)
-            hipLaunchKernelGGL((k1_build_matrices<true, true>), grid, dim3(256), lds, c->stream, hp,
-                               c->d_expA, c->d_expB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb,
-                               c->d_params, c->n_nodes, n_prior, c->nkeys);
-        else
-            hipLaunchKernelGGL((k1_build_matrices<false, true>), grid, dim3(256), 0, c->stream, hp,
-                               c->d_expA, c->d_expB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb,
-                               c->d_params, c->n_nodes, n_prior, c->nkeys);
-    } else if (use_lds) {
-        hipLaunchKernelGGL((k1_build_matrices<true, false>), grid, dim3(256), lds, c->stream, hp,
-                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb,
-                           c->d_params, c->n_nodes, n_prior, c->nkeys);
+        const void* fn = k1_rb_kernel();
+        if (grant_lds(c, fn, lds_rb, 48 * 1024)) return -1;
+        a.tabA = c->d_expA;
+        a.tabB = c->d_expB;
+        dim3 grid_rb((c->S + 16 * K1Q - 1) / (16 * K1Q), (c->S + 15) / 16, (c->nkeys + kpb - 1) / kpb);
+        if (launch_kernel(fn, grid_rb, dim3(256), lds_rb, c->stream, a)) return -1;
     } else {
-        hipLaunchKernelGGL((k1_build_matrices<false, false>), grid, dim3(256), 0, c->stream, hp,
-                           c->d_lncA, c->d_lncB, c->lnc.ld, c->d_PT, c->M, c->LD, c->KP, d_first_zero, kpb,
-                           c->d_params, c->n_nodes, n_prior, c->nkeys);
+        // product form: every key of this evaluation qualifies and the staged tables are exp(ln C); else the exact form
+        const void* fn = k1_kernel(use_lds, product);
+        if (grant_lds(c, fn, lds, 48 * 1024)) return -1;
+        a.tabA = product ? c->d_expA : c->d_lncA;
+        a.tabB = product ? c->d_expB : c->d_lncB;
+        if (launch_kernel(fn, grid, dim3(256), lds, c->stream, a)) return -1;
     }
-    HIP_TRY(hipGetLastError());
-    // the pinned block may be rewritten once this launch has consumed it.  An evaluation records the event behind
-    // its LAST launch instead (a marker packet between K1 and the next kernel cost ~5 us of every evaluation)
     if (!defer_ring_event) HIP_TRY(hipEventRecord(c->h_params_ev[c->cur_slot], c->stream));
     c->have_matrices = true;
     c->fold_current = false;  // the folded copy (if any) belongs to the previous matrices
     return 0;
 }
 
-constexpr int kSmemSmall = 7680;    // 60 KiB of node-vector slots (several workgroups per CU)
-constexpr int kSmemLarge = 19200;   // 150 KiB (one workgroup per CU)
-
-template <int NF>
-int launch_k2_nf(cafehip_ctx* c, const K2Args& a, int n_items, int block, size_t lds)
-{
-    const int grid = (n_items + NF - 1) / NF;
-    if (lds <= kSmemSmall * sizeof(double))
-        hipLaunchKernelGGL((k2_prune_v1<NF, kSmemSmall>), dim3(grid), dim3(block), 0, c->stream, a);
-    else
-        hipLaunchKernelGGL((k2_prune_v1<NF, kSmemLarge>), dim3(grid), dim3(block), 0, c->stream, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
+constexpr size_t kV1LdsLarge = 150 * 1024;   // node-vector slots of the row-per-thread kernel (one workgroup per CU)
 
 int launch_k2_v1(cafehip_ctx* c, K2Args& a, int n_items)
 {
@@ -1289,23 +510,19 @@ int launch_k2_v1(cafehip_ctx* c, K2Args& a, int n_items)
     int nf = 16;
     size_t lds = 0;
     for (; nf >= 1; nf >>= 1) {
-        lds = (size_t)slots * nf * c->LDv * sizeof(double);
-        if (lds <= kSmemLarge * sizeof(double)) break;
+        lds = (size_t)slots * nf * c->LDv * sizeof(double) + (size_t)nf * (c->n_leaves + 1) * sizeof(int);
+        if (lds <= kV1LdsLarge) break;
     }
     if (nf < 1)
         return fail("tree needs %d live node vectors of %d doubles: does not fit %zu B of LDS",
-                    slots, c->LDv, kSmemLarge * sizeof(double));
+                    slots, c->LDv, kV1LdsLarge);
     c->k2_nf = nf;
     c->k2_block = block;
     c->k2_lds = lds;
     a.n_slots = c->sched.n_slots;
-    switch (nf) {
-        case 16: return launch_k2_nf<16>(c, a, n_items, block, lds);
-        case 8: return launch_k2_nf<8>(c, a, n_items, block, lds);
-        case 4: return launch_k2_nf<4>(c, a, n_items, block, lds);
-        case 2: return launch_k2_nf<2>(c, a, n_items, block, lds);
-        default: return launch_k2_nf<1>(c, a, n_items, block, lds);
-    }
+    const void* fn = k2_v1_kernel(nf);
+    if (grant_lds(c, fn, lds, 64 * 1024)) return -1;
+    return launch_kernel(fn, dim3((n_items + nf - 1) / nf), dim3(block), lds, c->stream, a);
 }
 
 
@@ -1348,17 +565,15 @@ int k2c_wave_rows(const cafehip_ctx* c, int* nrt_w)
 }
 
 // (Re)build the plan from the tree and the unique rows.  A node is compressed when both children are leaves or
-// compressed and its distinct states number at most CAFEHIP_COMPRESS_THETA of the unique rows (default by table
-// size and matrix side, see below);
-// CAFEHIP_COMPRESS=0 disables.  Tables with fewer than 64 unique rows (CAFEHIP_COMPRESS_MIN) are left alone.
+// compressed and its distinct states number at most `compress_theta` of the unique rows (default by table size
+// and matrix side, see below); option compress=0 disables.  Tables with fewer than 64 unique rows (`compress_min`)
+// are left alone.
 int rebuild_compression(cafehip_ctx* c)
 {
     free_compression(c);
-    if (const char* e = getenv("CAFEHIP_COMPRESS"))
-        if (atoi(e) == 0) return 0;
+    if (!c->opt.compress) return 0;
     const int n = c->n_nodes, nl = c->n_leaves, Fu = c->Fu;
-    int min_rows = 64;   // even a 100-row table gains: its walk is a chain of latency-bound steps, and compression shortens the chain
-    if (const char* e = getenv("CAFEHIP_COMPRESS_MIN")) min_rows = std::max(atoi(e), 16);
+    const int min_rows = std::max(c->opt.compress_min, 16);   // (default 64) even a 100-row table gains: its walk is a chain of latency-bound steps, and compression shortens the chain
     if (n <= 0 || c->M < 0 || nl != (n + 1) / 2 || Fu < min_rows || (int)c->h_ucounts.size() != Fu * nl) return 0;
     int nrt_w = 0;
     if (k2c_wave_rows(c, &nrt_w) == 0) return 0;
@@ -1400,7 +615,7 @@ int rebuild_compression(cafehip_ctx* c)
         if (bushy && Fu < 10 * std::max(c->n_cu, 1)) theta = 1.0;
         else if (bushy && Fu < 32 * std::max(c->n_cu, 1)) theta = 0.8;
     }
-    if (const char* e = getenv("CAFEHIP_COMPRESS_THETA")) theta = std::min(std::max(atof(e), 0.0), 1.0);
+    if (c->opt.compress_theta >= 0) theta = std::min(c->opt.compress_theta, 1.0);
     const size_t limit = (size_t)(theta * Fu);
     std::vector<std::vector<int32_t>> sid(n), idx0(n), idx1(n);
     std::vector<int> D(n, 0), level(n, 0);
@@ -1533,14 +748,12 @@ int rebuild_compression(cafehip_ctx* c)
     return upload_col_has_err(c);
 }
 
-template <int NFT_W, int NRT_W>
-int launch_k2c_inst(cafehip_ctx* c, const K2cArgs& a, int grid, int n_sets, int block)
+int launch_k2c_inst(cafehip_ctx* c, const void* fn, int nft_w, const K2cArgs& a, int grid, int n_sets, int block)
 {
-    const size_t lds = (size_t)16 * NFT_W * c->LDv * sizeof(double);
-    if (grant_lds(c, reinterpret_cast<const void*>(&k2c_nodes<NFT_W, NRT_W>), lds, 64 * 1024)) return -1;
-    hipLaunchKernelGGL((k2c_nodes<NFT_W, NRT_W>), dim3(grid, n_sets), dim3(block), lds, c->stream, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    const size_t lds = (size_t)16 * nft_w * c->LDv * sizeof(double);
+    if (!fn) return fail("internal: no k2c_nodes instantiation for this shape");
+    if (grant_lds(c, fn, lds, 64 * 1024)) return -1;
+    return launch_kernel(fn, dim3(grid, n_sets), dim3(block), lds, c->stream, a);
 }
 
 // factor tables of the compressed subtrees for the matrices just built: one launch per level, children first
@@ -1565,7 +778,8 @@ int launch_compressed_levels(cafehip_ctx* c, int n_sets)
     memset(&a, 0, sizeof a);
     a.PT = c->d_PT;
     a.PTfold = (c->d_err && c->fold_current) ? c->d_PTfold : nullptr;
-    a.ep = c->d_params;
+    a.node_key = c->d_node_key;
+    a.n_nodes = c->n_nodes;
     a.leaf_has_err = c->d_leaf_has_err;
     a.tables = p.d_tables;
     a.table_set_stride = p.table_elems;
@@ -1581,11 +795,12 @@ int launch_compressed_levels(cafehip_ctx* c, int n_sets)
         a.tiles = p.d_tiles + first;
         const int nft = p.level_nft[l];
         slots += (double)n_tiles * nft;
-        int rc = -1;
-#define CAFE_K2C(NFT, NRT) if (nft == NFT && nrt_w == NRT) rc = launch_k2c_inst<NFT, NRT>(c, a, n_tiles, n_sets, 64 * wr);
-        CAFE_K2C(1, 1) CAFE_K2C(1, 2)
-#undef CAFE_K2C
-        if (rc) return rc < 0 ? rc : fail("internal: no k2c_nodes<%d,%d>", nft, nrt_w);
+        // one row tile per wave: the wave's whole matrix operand is requested up front (all of it up to 40 k-steps,
+        // a 32-deep ring up to 64); option k2c_prefetch=0 keeps the short ring of round 2 (A/B runs)
+        int kpf = (nft == 1 && nrt_w == 1 && a.ksteps <= 64) ? c->opt.k2c_prefetch : 0;
+        if (kpf == 40 && a.ksteps > 40) kpf = 32;
+        const int kmax = kpf == 40 ? 40 : (kpf > 0 ? 64 : 0);
+        if (launch_k2c_inst(c, k2c_kernel(nft, nrt_w, kpf, kmax), nft, a, n_tiles, n_sets, 64 * wr)) return -1;
     }
     const double kpad = 4.0 * ((c->C + 3) / 4), rows = 16.0 * ((c->C + 15) / 16);
     c->issued_tables = 2.0 * kpad * rows * 16.0 * slots * n_sets;
@@ -1597,13 +812,12 @@ int launch_compressed_levels(cafehip_ctx* c, int n_sets)
 // can be RESIDENT (occupancy query x CUs, doubled as margin), claimed by the workgroups at run time
 // (k2_acquire_park_slot), instead of one region per family tile: at the configs[2] shape 2 x 1,280 slots x 2 parks x
 // 33 KB = 169 MB at most instead of 413 MB, and only the slots in use are touched -- they stay in the 256 MB Infinity
-// Cache (round 1: 7.7 GB of HBM traffic per launch).  CAFEHIP_K2SLOTS=0 restores one region per tile.
+// Cache (round 1: 7.7 GB of HBM traffic per launch).  Option k2slots=0 restores one region per tile.
 int k2_fit_grid(cafehip_ctx* c, const void* fn, K2MfmaArgs& a, int* grid, int block, size_t lds)
 {
     const bool global_parks = walk_sched(c).n_parks > a.lds_parks;
     int slots = 0;
-    bool per_tile = false;
-    if (const char* e = getenv("CAFEHIP_K2SLOTS")) per_tile = atoi(e) == 0;
+    const bool per_tile = c->opt.k2slots == 0;
     if (global_parks && !per_tile) {
         auto it = c->k2_occ.find({fn, block, lds});
         if (it == c->k2_occ.end()) {
@@ -1639,32 +853,15 @@ int k2_fit_grid(cafehip_ctx* c, const void* fn, K2MfmaArgs& a, int* grid, int bl
     return 0;
 }
 
-constexpr int kMaxTiles16 = 8;      // NFT_W * NRT_W accumulator tiles per wave (16x16x4 shape)
-template <int NFT_W, int NRT_W>
-int launch_mfma_inst(cafehip_ctx* c, K2MfmaArgs a, int grid, int block, size_t lds)
-{
-    if (grant_lds(c, reinterpret_cast<const void*>(&k2_prune_mfma<NFT_W, NRT_W>), lds, 64 * 1024)) return -1;
-    if (k2_fit_grid(c, reinterpret_cast<const void*>(&k2_prune_mfma<NFT_W, NRT_W>), a, &grid, block, lds)) return -1;
-    hipLaunchKernelGGL((k2_prune_mfma<NFT_W, NRT_W>), dim3(grid, a.n_sets), dim3(block), lds, c->stream, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int NFT_W>
-int launch_mfma_nrt(cafehip_ctx* c, const K2MfmaArgs& a, int nrt_w, int grid, int block, size_t lds)
+int launch_mfma16(cafehip_ctx* c, K2MfmaArgs a, int nft_w, int nrt_w, int grid, int block, size_t lds)
 {
     // only the (NFT_W, NRT_W) pairs within the register budget (NFT_W * NRT_W <= 8 accumulator tiles, NRT_W <= 7:
     // no scratch spills) are instantiated
-#define CAFE_M16(N)                                                             \
-    case N:                                                                     \
-        if constexpr (NFT_W * N <= kMaxTiles16 && N <= 7)                       \
-            return launch_mfma_inst<NFT_W, N>(c, a, grid, block, lds);          \
-        break;
-    switch (nrt_w) {
-        CAFE_M16(1) CAFE_M16(2) CAFE_M16(3) CAFE_M16(4) CAFE_M16(5) CAFE_M16(6) CAFE_M16(7)
-    }
-#undef CAFE_M16
-    return fail("unsupported 16x16 wave grid NFT_W=%d NRT_W=%d", NFT_W, nrt_w);
+    const void* fn = k2_mfma16_kernel(nft_w, nrt_w);
+    if (!fn) return fail("unsupported 16x16 wave grid NFT_W=%d NRT_W=%d", nft_w, nrt_w);
+    if (grant_lds(c, fn, lds, 64 * 1024)) return -1;
+    if (k2_fit_grid(c, fn, a, &grid, block, lds)) return -1;
+    return launch_kernel(fn, dim3(grid, a.n_sets), dim3(block), lds, c->stream, a);
 }
 
 // The park buffers (node vectors waiting for their sibling) stay in LDS when the whole set still lets two
@@ -1679,12 +876,12 @@ size_t mfma_lds_bytes_with(const cafehip_ctx* c, int nf, int lds_parks)
 // round trip but cost residency: they are used only as far as the CU still holds as many workgroups as the grid
 // can put on it (measured at the configs[3] shape: one LDS park at the price of 5 -> 3 workgroups per CU is
 // 25 % slower; at configs[1], where 500 workgroups give every CU two either way, it is 4 % faster).
-// CAFEHIP_LDSPARK=<n> overrides (0 = none).
+// Option ldspark=<n> overrides (0 = none).
 int mfma_lds_parks(const cafehip_ctx* c, int nf, int n_items)
 {
     const int n_parks = walk_sched(c).n_parks;
     if (n_parks <= 0) return 0;
-    if (const char* e = getenv("CAFEHIP_LDSPARK")) return std::min(std::max(atoi(e), 0), n_parks);
+    if (c->opt.ldspark >= 0) return std::min(c->opt.ldspark, n_parks);
     const size_t cu_lds = 160 * 1024;
     const int grid = (n_items + nf - 1) / nf;
     const int wanted = std::max(1, (grid + c->n_cu - 1) / std::max(c->n_cu, 1));
@@ -1737,15 +934,14 @@ double k2_cost(const cafehip_ctx* c, int n_items, int nf, int groups, int wf, in
     return cost;
 }
 
-// 16x16x4 shape: NF = 16 * nft_w * wf.  CAFEHIP_K2CFG="nftw,nrtw,wf,wr" overrides (tuning sweeps).
+// 16x16x4 shape: NF = 16 * nft_w * wf.  Option k2cfg="nftw,nrtw,wf,wr" overrides (tuning sweeps).
 bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_cost, std::vector<K2Cand>* all = nullptr)
 {
     const int RT = (std::max(c->C, c->R) + 15) / 16;
     const int RTc = (c->C + 15) / 16;
-    if (const char* e = getenv("CAFEHIP_K2CFG")) {
-        K2Cfg k;
-        if (sscanf(e, "%d,%d,%d,%d", &k.nft_w, &k.nrt_w, &k.wf, &k.wr) == 4 && k.nft_w >= 1 && k.nft_w <= 2 &&
-            k.nrt_w >= 1 && k.nrt_w <= 7 && k.nft_w * k.nrt_w <= kMaxTiles16 && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 && k.wr * k.nrt_w >= RT &&
+    if (c->opt.have_cfg16) {
+        const K2Cfg k{c->opt.cfg16[0], c->opt.cfg16[1], c->opt.cfg16[2], c->opt.cfg16[3]};
+        if (k2_fits16(k.nft_w, k.nrt_w) && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 && k.wr * k.nrt_w >= RT &&
             mfma_lds_bytes(c, 16 * k.nft_w * k.wf, n_items) <= (size_t)c->lds_limit) {
             *out = k;
             *out_cost = 0;
@@ -1776,18 +972,14 @@ bool choose_mfma_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_
     return found;
 }
 
-// 4x4x4_4b shape: NF = 4 * G * wf (K2Cfg.nft_w carries G).  CAFEHIP_K2CFG4="G,nrtw,wf,wr" overrides.
-// (G, NRT_W) wave tiles of the 4-family kernel that compile without scratch spills at 2 waves per SIMD (256 registers
-// per lane; checked with tools/k2_regs.py after every kernel change)
-constexpr bool k2_fits4(int G, int nrt_w) { return G * nrt_w <= 18 && !(G == 8 && nrt_w == 2); }   // beyond: spills (tools/k2_regs.py)
+// 4x4x4_4b shape: NF = 4 * G * wf (K2Cfg.nft_w carries G).  Option k2cfg4="G,nrtw,wf,wr" overrides.
 bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out_cost, std::vector<K2Cand>* all = nullptr)
 {
     const int RT = (std::max(c->C, c->R) + 15) / 16;
     const int RTc = (c->C + 15) / 16;
-    if (const char* e = getenv("CAFEHIP_K2CFG4")) {
-        K2Cfg k;
-        if (sscanf(e, "%d,%d,%d,%d", &k.nft_w, &k.nrt_w, &k.wf, &k.wr) == 4 && k.nft_w >= 1 && k.nft_w <= 8 &&
-            k.nrt_w >= 1 && k.nrt_w <= 7 && k2_fits4(k.nft_w, k.nrt_w) && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 &&
+    if (c->opt.have_cfg4) {
+        const K2Cfg k{c->opt.cfg4[0], c->opt.cfg4[1], c->opt.cfg4[2], c->opt.cfg4[3]};
+        if (k2_fits4(k.nft_w, k.nrt_w) && k.wf * k.wr >= 1 && k.wf * k.wr <= 8 &&
             k.wr * k.nrt_w >= RT && mfma_lds_bytes(c, 4 * k.nft_w * k.wf, n_items) <= (size_t)c->lds_limit) {
             *out = k;
             *out_cost = 0;
@@ -1820,45 +1012,14 @@ bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out
     return found;
 }
 
-template <int G, int NRT_W>
-int launch_mfma4_inst(cafehip_ctx* c, K2MfmaArgs a, int grid, int block, size_t lds)
-{
-    if (grant_lds(c, reinterpret_cast<const void*>(&k2_prune_mfma4<G, NRT_W>), lds, 64 * 1024)) return -1;
-    if (k2_fit_grid(c, reinterpret_cast<const void*>(&k2_prune_mfma4<G, NRT_W>), a, &grid, block, lds)) return -1;
-    hipLaunchKernelGGL((k2_prune_mfma4<G, NRT_W>), dim3(grid, a.n_sets), dim3(block), lds, c->stream, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int G>
-int launch_mfma4_nrt(cafehip_ctx* c, const K2MfmaArgs& a, int nrt_w, int grid, int block, size_t lds)
+int launch_mfma4_g(cafehip_ctx* c, K2MfmaArgs a, int G, int nrt_w, int grid, int block, size_t lds)
 {
     // only the (G, NRT_W) pairs within the register budget are instantiated
-#define CAFE_M4(N)                                                              \
-    case N:                                                                     \
-        if constexpr (k2_fits4(G, N))                                           \
-            return launch_mfma4_inst<G, N>(c, a, grid, block, lds);             \
-        break;
-    switch (nrt_w) {
-        CAFE_M4(1) CAFE_M4(2) CAFE_M4(3) CAFE_M4(4) CAFE_M4(5) CAFE_M4(6) CAFE_M4(7)
-    }
-#undef CAFE_M4
-    return fail("unsupported 4x4 wave grid G=%d NRT_W=%d", G, nrt_w);
-}
-
-int launch_mfma4_g(cafehip_ctx* c, const K2MfmaArgs& a, int G, int nrt_w, int grid, int block, size_t lds)
-{
-    switch (G) {
-        case 1: return launch_mfma4_nrt<1>(c, a, nrt_w, grid, block, lds);
-        case 2: return launch_mfma4_nrt<2>(c, a, nrt_w, grid, block, lds);
-        case 3: return launch_mfma4_nrt<3>(c, a, nrt_w, grid, block, lds);
-        case 4: return launch_mfma4_nrt<4>(c, a, nrt_w, grid, block, lds);
-        case 5: return launch_mfma4_nrt<5>(c, a, nrt_w, grid, block, lds);
-        case 6: return launch_mfma4_nrt<6>(c, a, nrt_w, grid, block, lds);
-        case 7: return launch_mfma4_nrt<7>(c, a, nrt_w, grid, block, lds);
-        case 8: return launch_mfma4_nrt<8>(c, a, nrt_w, grid, block, lds);
-    }
-    return fail("unsupported G %d", G);
+    const void* fn = k2_mfma4_kernel(G, nrt_w);
+    if (!fn) return fail("unsupported 4x4 wave grid G=%d NRT_W=%d", G, nrt_w);
+    if (grant_lds(c, fn, lds, 64 * 1024)) return -1;
+    if (k2_fit_grid(c, fn, a, &grid, block, lds)) return -1;
+    return launch_kernel(fn, dim3(grid, a.n_sets), dim3(block), lds, c->stream, a);
 }
 
 // measured wave-grid choices of this process, by problem shape
@@ -1876,9 +1037,9 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     if (n_items <= 0) return 0;
     K2Cfg k16{}, k4{};
     double cost16 = 1e300, cost4 = 1e300;
-    const char* shape_env = getenv("CAFEHIP_MFMA");
-    const bool allow16 = !(shape_env && strcmp(shape_env, "4") == 0);
-    const bool allow4 = !(shape_env && strcmp(shape_env, "16") == 0);
+    const bool shape_env = c->opt.mfma != 0;
+    const bool allow16 = c->opt.mfma != 4;
+    const bool allow4 = c->opt.mfma != 16;
     const bool have16 = allow16 && choose_mfma_cfg(c, n_items, &k16, &cost16);
     const bool have4 = allow4 && choose_mfma4_cfg(c, n_items, &k4, &cost4);
     if (!have16 && !have4) {
@@ -1893,15 +1054,13 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     K2Cfg k = use4 ? k4 : k16;
     // The cost model ranks the wave grids to within ~10 %; every grid produces bit-identical values (same
     // accumulation order), so the objective path MEASURES its few best candidates on the first evaluations of a
-    // table (each of them a normal, valid evaluation) and keeps the fastest.  CAFEHIP_K2TUNE=0 disables;
-    // explicit CAFEHIP_K2CFG / CAFEHIP_K2CFG4 / CAFEHIP_MFMA overrides do too.
+    // table (each of them a normal, valid evaluation) and keeps the fastest.  option k2tune=0 disables;
+    // explicit k2cfg / k2cfg4 / mfma options do too.
     bool tuning_launch = false;
     {
-        const char* te = getenv("CAFEHIP_K2TUNE");
-        const bool enabled = n_sets == 1 && v1.col_max == nullptr && !(te && atoi(te) == 0) && !shape_env && !getenv("CAFEHIP_K2CFG") &&
-                             !getenv("CAFEHIP_K2CFG4");
+        const bool overridden = !c->opt.k2tune || shape_env || c->opt.have_cfg16 || c->opt.have_cfg4;
+        const bool enabled = n_sets == 1 && v1.col_max == nullptr && !overridden;
         auto& t = c->tune;
-        const bool overridden = (te && atoi(te) == 0) || shape_env || getenv("CAFEHIP_K2CFG") || getenv("CAFEHIP_K2CFG4");
         if (!enabled && n_sets > 1) {
             // several parameter sets in one pass: no measurement; the grid a single-set evaluation settled on is
             // kept if there is one, else the cost model's choice stands
@@ -2000,7 +1159,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
                 } while (t.round == 2 && t.best_ms[t.cur] > 1.05f * best);
                 if (t.round >= 3) {
                     t.locked = (int)(std::min_element(t.best_ms.begin(), t.best_ms.end()) - t.best_ms.begin());
-                    if (getenv("CAFEHIP_K2TUNE_LOG"))
+                    if (c->opt.k2tune_log)
                         for (size_t i = 0; i < t.cands.size(); ++i)
                             fprintf(stderr, "cafehip: wave grid %s %d,%d,%d,%d  model %.3g  measured %.4f ms%s\n", t.cands[i].use4 ? "4x4" : "16x16",
                                     t.cands[i].cfg.nft_w, t.cands[i].cfg.nrt_w, t.cands[i].cfg.wf, t.cands[i].cfg.wr, t.cands[i].cost, t.best_ms[i],
@@ -2024,7 +1183,10 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     K2MfmaArgs a;
     memset(&a, 0, sizeof a);
     a.PT = v1.PT;
-    a.ep = v1.ep;
+    a.node_key = v1.node_key;
+    a.n_nodes = v1.n_nodes;
+    a.prior = v1.prior;
+    a.logprior = v1.logprior;
     a.ops = c->walk_compressed ? c->cp.d_ops : c->d_mops;
     a.n_ops = (int)walk_sched(c).ops.size();
     a.n_sets = n_sets;
@@ -2113,8 +1275,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     int rc = 0;
     for (int rep = 0; rep < reps && rc == 0; ++rep) {
         if (use4) rc = launch_mfma4_g(c, a, k.nft_w, k.nrt_w, grid, block, lds);
-        else if (k.nft_w == 1) rc = launch_mfma_nrt<1>(c, a, k.nrt_w, grid, block, lds);
-        else rc = launch_mfma_nrt<2>(c, a, k.nrt_w, grid, block, lds);
+        else rc = launch_mfma16(c, a, k.nft_w, k.nrt_w, grid, block, lds);
     }
     if (rc == 0 && tuning_launch) {
         HIP_TRY(hipEventRecord(c->tune.e1, c->stream));
@@ -2140,8 +1301,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
 
 int launch_k2(cafehip_ctx* c, K2Args& a, int n_items, int n_sets = 1)
 {
-    const char* e = getenv("CAFEHIP_K2");
-    if (e && strcmp(e, "v1") == 0) {
+    if (c->opt.k2 == 1) {
         c->k2_used_mfma = false;
         if (n_sets > 1) return fail("several parameter sets per pass need the matrix-core kernel");
         return launch_k2_v1(c, a, n_items);
@@ -2153,7 +1313,10 @@ void fill_common_k2(cafehip_ctx* c, K2Args& a)
 {
     memset(&a, 0, sizeof a);
     a.PT = c->d_PT;
-    a.ep = c->d_params;
+    a.node_key = c->d_node_key;
+    a.n_nodes = c->n_nodes;
+    a.prior = c->d_prior;
+    a.logprior = c->d_logprior;
     a.ops = c->d_ops;
     a.n_ops = (int)c->sched.ops.size();
     a.n_leaves = c->n_leaves;
@@ -2214,9 +1377,10 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
     if (n_sets > 1 && d_chunk_sums == nullptr) {
         d_chunk_sums = c->d_chunk_sums;   // (re)allocated above
     }
-    EvalParams* h = nullptr;
-    if (stage_params(c, node_lambda, node_mu, prior, &h, n_sets)) return -1;
+    if (stage_params(c, node_lambda, node_mu, prior, n_sets)) return -1;
+    RingGuard ring(c);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    ring.arm();   // from here on the slot's event is recorded on every way out
     if (launch_k1(c, d_first_zero, true)) return -1;
     if (launch_error_fold(c)) return -1;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -2235,8 +1399,7 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
     {
         // the objective path walks the reduced tree when the table compresses (matrix-core kernels; an error model
         // only in its folded form, so that every leaf stays a column gather)
-        const char* k2e = getenv("CAFEHIP_K2");
-        const bool use_c = c->cp.valid && !(k2e && strcmp(k2e, "v1") == 0) && (!c->d_err || c->fold_current);
+        const bool use_c = c->cp.valid && c->opt.k2 != 1 && (!c->d_err || c->fold_current);
         c->issued_tables = 0;
         if (use_c && launch_compressed_levels(c, n_sets)) return -1;
         c->ev_mid_used = false;
@@ -2253,19 +1416,15 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     if (c->n_chunks > 0) {
+        K3Args k3{c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, c->Fu, d_chunk_sums, d_first_zero, nullptr, nullptr, 0};
         if (host_out) {
-            ++c->host_seq;
-            hipLaunchKernelGGL(k3_score<true>, dim3(c->n_chunks, n_sets), dim3(CAFEHIP_CHUNK), 0, c->stream,
-                               c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, c->Fu, d_chunk_sums, d_first_zero,
-                               c->h_result, c->d_arrive, c->host_seq);
-        } else {
-            hipLaunchKernelGGL(k3_score<false>, dim3(c->n_chunks, n_sets), dim3(CAFEHIP_CHUNK), 0, c->stream,
-                               c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, c->Fu, d_chunk_sums, d_first_zero,
-                               (HostResult*)nullptr, (int32_t*)nullptr, 0);
+            k3.host = c->h_result;
+            k3.arrive = c->d_arrive;
+            k3.seq = ++c->host_seq;
         }
+        if (launch_kernel(k3_kernel(host_out), dim3(c->n_chunks, n_sets), dim3(CAFEHIP_CHUNK), 0, c->stream, k3)) return -1;
     }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->h_params_ev[c->cur_slot], c->stream));   // (deferred from launch_k1)
+    if (ring.record_now()) return -1;   // (deferred from launch_k1)
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         c->timing_pending = true;
@@ -2293,16 +1452,83 @@ int collect_kernel_ms(cafehip_ctx* c)
     return 0;
 }
 
+// ---- run-time switches ---------------------------------------------------------------------------------------
+// (name, what it selects) -- cafehip_set_option; the same names upper-cased behind CAFEHIP_ are read from the
+// environment ONCE, when the context is created (tools/ sweeps), never during an evaluation
+const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
+                                    "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_prefetch",
+                                    "batch_trim"};
+
+int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
+{
+    auto& o = c->opt;
+    const int iv = atoi(val.c_str());
+    bool replan = false;
+    if (key == "compress") { o.compress = iv != 0; replan = true; }
+    else if (key == "compress_theta") { o.compress_theta = val.empty() ? -1.0 : std::min(std::max(atof(val.c_str()), 0.0), 1.0); replan = true; }
+    else if (key == "compress_min") { o.compress_min = iv; replan = true; }
+    else if (key == "errfold") o.errfold = iv != 0;
+    else if (key == "errband") {
+        o.errband = iv != 0;
+        c->err_banded = c->err_mfs >= 0 && c->err_band_width <= 16 && o.errband;
+    } else if (key == "k1") {
+        if (val == "exact") o.k1 = 1;
+        else if (val == "perterm") o.k1 = 2;
+        else if (val.empty() || val == "auto" || val == "rb") o.k1 = 0;
+        else return fail("option k1: auto | exact | perterm, got '%s'", val.c_str());
+    } else if (key == "k1kpb") o.k1_kpb = std::max(1, iv);
+    else if (key == "k2") {
+        if (val == "v1") o.k2 = 1;
+        else if (val.empty() || val == "auto" || val == "mfma") o.k2 = 0;
+        else return fail("option k2: auto | mfma | v1, got '%s'", val.c_str());
+    } else if (key == "mfma") {
+        if (val == "4") o.mfma = 4;
+        else if (val == "16") o.mfma = 16;
+        else if (val.empty() || val == "auto") o.mfma = 0;
+        else return fail("option mfma: auto | 4 | 16, got '%s'", val.c_str());
+    } else if (key == "k2cfg" || key == "k2cfg4") {
+        int* dst = key == "k2cfg" ? o.cfg16 : o.cfg4;
+        bool& have = key == "k2cfg" ? o.have_cfg16 : o.have_cfg4;
+        have = false;
+        if (!val.empty()) {
+            if (sscanf(val.c_str(), "%d,%d,%d,%d", dst, dst + 1, dst + 2, dst + 3) != 4)
+                return fail("option %s: \"a,b,wf,wr\", got '%s'", key.c_str(), val.c_str());
+            have = true;
+        }
+    } else if (key == "k2tune") o.k2tune = iv != 0;
+    else if (key == "k2tune_log") o.k2tune_log = iv != 0;
+    else if (key == "k2slots") o.k2slots = iv != 0;
+    else if (key == "ldspark") o.ldspark = val.empty() ? -1 : iv;
+    else if (key == "vitlds") o.vitlds = iv != 0;
+    else if (key == "k2c_prefetch") o.k2c_prefetch = iv;
+    else if (key == "batch_trim") o.batch_trim = iv != 0;
+    else return fail("unknown option '%s'", key.c_str());
+    c->tune.n_items = -1;   // the wave grid is measured again under the new switches
+    if (replan && c->M >= 0 && c->n_nodes > 0) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (rebuild_compression(c)) return -1;
+    }
+    return 0;
+}
+
+void options_from_environment(cafehip_ctx* c)
+{
+    for (const char* name : kOptionNames) {
+        std::string env = "CAFEHIP_";
+        for (const char* p = name; *p; ++p) env += (char)toupper((unsigned char)*p);
+        if (const char* v = getenv(env.c_str()))
+            if (set_option(c, name, v) != 0) fprintf(stderr, "cafehip: %s=%s ignored: %s\n", env.c_str(), v, g_err.c_str());
+    }
+}
+
 }  // namespace
 
-template <int NF>
-static int launch_k4_nf(cafehip_ctx* c, const K4Args& a, int block, size_t lds)
+static int launch_k4_nf(cafehip_ctx* c, int nf, const K4Args& a, int block, size_t lds)
 {
-    if (grant_lds(c, reinterpret_cast<const void*>(&k4_viterbi<NF>), lds, 48 * 1024)) return -1;
-    const int grid = (a.B + NF - 1) / NF;
-    hipLaunchKernelGGL(k4_viterbi<NF>, dim3(grid), dim3(block), lds, c->stream, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    const void* fn = k4_kernel(nf);
+    if (grant_lds(c, fn, lds, 48 * 1024)) return -1;
+    return launch_kernel(fn, dim3((a.B + nf - 1) / nf), dim3(block), lds, c->stream, a);
 }
 
 
@@ -2341,12 +1567,10 @@ int cafehip_create(cafehip_ctx** out, int device_id)
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    HIP_TRY(hipMalloc(&c->d_params, sizeof(EvalParams)));
-    for (int i = 0; i < kParamRing; ++i) {
-        HIP_TRY(hipHostMalloc(&c->h_params[i], sizeof(EvalParams), hipHostMallocMapped | hipHostMallocCoherent));
-        memset(c->h_params[i], 0, sizeof(EvalParams));
-        HIP_TRY(hipEventCreateWithFlags(&c->h_params_ev[i], hipEventDisableTiming));
-    }
+    HIP_TRY(hipMalloc(&c->d_prior, kMaxPrior * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_logprior, kMaxPrior * sizeof(double)));
+    for (int i = 0; i < kParamRing; ++i) HIP_TRY(hipEventCreateWithFlags(&c->h_params_ev[i], hipEventDisableTiming));
+    options_from_environment(c);
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
     HIP_TRY(hipMalloc(&c->d_first_zero, kMaxSets * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&c->d_arrive, sizeof(int32_t)));
@@ -2378,12 +1602,14 @@ void cafehip_destroy(cafehip_ctx* c)
     hipFree(c->d_vit);
     hipFree(c->d_PTfold);
     hipFree(c->d_PT);
-    hipFree(c->d_params);
+    hipFree(c->d_node_key);
+    hipFree(c->d_prior);
+    hipFree(c->d_logprior);
     hipFree(c->d_err);
     hipFree(c->d_leaf_has_err);
     hipFree(c->d_first_zero);
     for (int i = 0; i < kParamRing; ++i) {
-        hipHostFree(c->h_params[i]);
+        if (c->h_params[i]) hipHostFree(c->h_params[i]);
         hipEventDestroy(c->h_params_ev[i]);
     }
     for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
@@ -2392,6 +1618,12 @@ void cafehip_destroy(cafehip_ctx* c)
     hipFree(c->d_arrive);
     hipStreamDestroy(c->own_stream);
     delete c;
+}
+
+int cafehip_set_option(cafehip_ctx* c, const char* key, const char* value)
+{
+    if (!c || !key) return fail("null argument");
+    return set_option(c, key, value ? value : "");
 }
 
 int cafehip_set_stream(cafehip_ctx* c, void* hip_stream)
@@ -2418,7 +1650,7 @@ int cafehip_set_tree(cafehip_ctx* c, int n_nodes, const int32_t* parent, const i
     if (!c) return fail("null context");
     c->tune.n_items = -1;  // a new problem: measure the wave grids again
     if (n_nodes < 3 || (n_nodes & 1) == 0) return fail("a binary tree has an odd number (>= 3) of nodes, got %d", n_nodes);
-    if (n_nodes > kMaxNodes - 1) return fail("at most %d nodes supported, got %d", kMaxNodes - 1, n_nodes);
+    if (n_nodes > kMaxNodesCap) return fail("at most %d nodes supported, got %d", kMaxNodesCap, n_nodes);
     HIP_TRY(hipSetDevice(c->device));
     int root = -1;
     for (int i = 0; i < n_nodes; ++i) {
@@ -2486,6 +1718,7 @@ int cafehip_set_tree(cafehip_ctx* c, int n_nodes, const int32_t* parent, const i
         HIP_TRY(hipMemcpy(c->d_vit_slot, vslot.data(), n_nodes * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     c->have_matrices = false;
+    if (ensure_param_ring(c)) return -1;
     if (c->M >= 0 && ensure_matrix_storage(c)) return -1;
     if (c->M >= 0 && rebuild_compression(c)) return -1;
     return 0;
@@ -2497,7 +1730,7 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
 {
     if (!c) return fail("null context");
     c->tune.n_items = -1;  // a new problem: measure the wave grids again
-    if (F < 0 || n_leaves <= 0 || n_leaves > kMaxLeaves) return fail("bad table shape %d x %d", F, n_leaves);
+    if (F < 0 || n_leaves <= 0 || n_leaves > (kMaxNodesCap + 1) / 2) return fail("bad table shape %d x %d", F, n_leaves);
     if (range_min != 0) return fail("range_min must be 0 (cafe/cafe_family.c:357-364), got %d", range_min);
     if (range_max < 0 || root_min < 0 || root_max < root_min) return fail("bad ranges");
     const int R = root_max - root_min + 1;
@@ -2645,8 +1878,8 @@ int cafehip_set_error_model(cafehip_ctx* c, int mfs, const double* errormatrix,
         if (dlo > dhi) dlo = dhi = 0;
         c->err_dlo = dlo;
         c->err_dhi = dhi;
-        const char* e = getenv("CAFEHIP_ERRBAND");
-        c->err_banded = (dhi - dlo + 1 <= 16) && !(e && strcmp(e, "0") == 0);
+        c->err_band_width = dhi - dlo + 1;
+        c->err_banded = c->err_band_width <= 16 && c->opt.errband;
     }
     HIP_TRY(hipMalloc(&c->d_err, n * sizeof(double)));
     HIP_TRY(hipMemcpy(c->d_err, errormatrix, n * sizeof(double), hipMemcpyHostToDevice));
@@ -2782,8 +2015,7 @@ int cafehip_eval_clustered_posterior(cafehip_ctx* c, int K, const double* node_l
         return fail("error model covers sizes 0..%d but range_max is %d", c->err_mfs, c->range_max);
     HIP_TRY(hipSetDevice(c->device));
     if (ensure_output_sets(c, std::max(K, 2))) return -1;
-    EvalParams* h = nullptr;
-    if (stage_params(c, node_lambda, node_mu, prior, &h, K)) return -1;
+    if (stage_params(c, node_lambda, node_mu, prior, K)) return -1;
     if (launch_k1(c, c->d_first_zero)) return -1;
     if (launch_error_fold(c)) return -1;
     K2Args a;
@@ -2818,9 +2050,10 @@ int cafehip_eval_clustered_posterior(cafehip_ctx* c, int K, const double* node_l
     TRY4(hipMalloc(&d_memb, (size_t)K * c->n_chunks * sizeof(double)));
     if (family_map) TRY4(hipMalloc(&d_map, (size_t)c->F * sizeof(double)));
     if (family_membership) TRY4(hipMalloc(&d_pz, (size_t)c->F * K * sizeof(double)));
-    hipLaunchKernelGGL(k3_cluster_score, dim3(c->n_chunks), dim3(CAFEHIP_CHUNK), 0, c->stream, c->d_max_post, c->d_fam2u,
-                       c->F, c->Fu, K, cw, c->d_chunk_sums, d_memb, c->d_first_zero, d_map, d_pz);
-    TRY4(hipGetLastError());
+    {
+        K3cArgs ka{c->d_max_post, c->d_fam2u, c->F, c->Fu, K, cw, c->d_chunk_sums, d_memb, c->d_first_zero, d_map, d_pz};
+        if (launch_kernel(k3_cluster_kernel(), dim3(c->n_chunks), dim3(CAFEHIP_CHUNK), 0, c->stream, ka)) { cleanup(); return -1; }
+    }
     std::vector<double> sums(c->n_chunks), memb((size_t)K * c->n_chunks);
     int32_t fz_dev = INT32_MAX;
     TRY4(hipMemcpyAsync(sums.data(), c->d_chunk_sums, sums.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -2866,8 +2099,7 @@ int cafehip_reset_birthdeath_cache(cafehip_ctx* c, const double* node_lambda, co
     if (check_ready(c)) return -1;
     if (!node_lambda || !node_mu) return fail("null argument");
     HIP_TRY(hipSetDevice(c->device));
-    EvalParams* h = nullptr;
-    if (stage_params(c, node_lambda, node_mu, nullptr, &h)) return -1;
+    if (stage_params(c, node_lambda, node_mu, nullptr)) return -1;
     if (launch_k1(c)) return -1;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -2984,15 +2216,15 @@ int cafehip_viterbi(cafehip_ctx* c, int B, const int32_t* counts, const int32_t*
     if (block > 1024) return fail("matrix side %d exceeds the 1024 rows this kernel handles", rows_max);
     int nf = 8;
     size_t lds = 0;
-    const size_t stat = 8 * kMaxLeaves * 4 + 64;
+    const size_t stat = 64;   // the kernel's static LDS (column limits)
+    const auto cnt_bytes = [&](int nf_) { return (size_t)((nf_ * c->n_leaves + 1) & ~1) * sizeof(int); };   // counts behind the slots
     // argmax tables in global scratch (default): LDS holds the node-vector slots only, sized for >= 4 workgroups
-    // per CU; CAFEHIP_VITLDS=1 keeps the tables in LDS (one workgroup per CU at the larger shapes)
-    const char* vl = getenv("CAFEHIP_VITLDS");
-    bool tables_global = !(vl && atoi(vl) == 1);
+    // per CU; option vitlds=1 keeps the tables in LDS (one workgroup per CU at the larger shapes)
+    bool tables_global = c->opt.vitlds != 1;
     const size_t per_family_tables = (size_t)c->n_vit_tables * c->LDv * sizeof(unsigned short);
     if (tables_global) {
         for (nf = 8; nf >= 1; nf >>= 1) {
-            lds = (size_t)c->sched.n_slots * nf * c->LDv * sizeof(double) + 16;
+            lds = (size_t)c->sched.n_slots * nf * c->LDv * sizeof(double) + cnt_bytes(nf) + 16;
             if (lds + stat <= (size_t)40 * 1024 || nf == 1) break;
         }
         if (lds + stat > (size_t)c->lds_limit) return fail("Viterbi node vectors of this tree do not fit LDS");
@@ -3009,7 +2241,7 @@ int cafehip_viterbi(cafehip_ctx* c, int B, const int32_t* counts, const int32_t*
     }
     if (!tables_global) {
         for (nf = 8; nf >= 1; nf >>= 1) {
-            lds = (size_t)c->sched.n_slots * nf * c->LDv * sizeof(double) + (size_t)nf * per_family_tables + 16;
+            lds = (size_t)c->sched.n_slots * nf * c->LDv * sizeof(double) + cnt_bytes(nf) + (size_t)nf * per_family_tables + 16;
             if (lds + stat <= (size_t)c->lds_limit) break;
         }
         if (nf < 1) return fail("Viterbi tables of this tree do not fit LDS");
@@ -3029,7 +2261,7 @@ int cafehip_viterbi(cafehip_ctx* c, int B, const int32_t* counts, const int32_t*
     K4Args a;
     memset(&a, 0, sizeof a);
     a.PT = c->d_PT;
-    a.ep = c->d_params;
+    a.node_key = c->d_node_key;
     a.ops = c->d_ops;
     a.n_ops = (int)c->sched.ops.size();
     a.counts = d_cnt;
@@ -3064,12 +2296,7 @@ int cafehip_viterbi(cafehip_ctx* c, int B, const int32_t* counts, const int32_t*
         ab.col_max = d_cm + b0;
         ab.node_sizes = d_out + (size_t)b0 * c->n_nodes;
         ab.vit_global = tables_global ? c->d_vit : nullptr;
-        switch (nf) {
-            case 8: rc = launch_k4_nf<8>(c, ab, block, lds); break;
-            case 4: rc = launch_k4_nf<4>(c, ab, block, lds); break;
-            case 2: rc = launch_k4_nf<2>(c, ab, block, lds); break;
-            default: rc = launch_k4_nf<1>(c, ab, block, lds); break;
-        }
+        rc = launch_k4_nf(c, nf, ab, block, lds);
     }
     if (rc) { cleanup(); return -1; }
     TRY3(hipMemcpyAsync(node_sizes, d_out, (size_t)B * c->n_nodes * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -3096,9 +2323,10 @@ int cafehip_fetch_small(cafehip_ctx* c, const void* d_src, size_t nbytes, const 
     }
     const int32_t want = ++c->fetch_seq;
     volatile int32_t* flag = reinterpret_cast<volatile int32_t*>(c->h_fetch);
-    hipLaunchKernelGGL(k_fetch_small, dim3(1), dim3(256), 0, c->stream, static_cast<const uint64_t*>(d_src), c->h_fetch + 1,
-                       n_words, flag, want);
-    HIP_TRY(hipGetLastError());
+    {
+        FetchArgs fa{static_cast<const uint64_t*>(d_src), c->h_fetch + 1, n_words, flag, want};
+        if (launch_kernel(fetch_small_kernel(), dim3(1), dim3(256), 0, c->stream, fa)) return -1;
+    }
     unsigned long spins = 0;
     while (*flag != want) {
         if ((++spins & 0x3FFFF) == 0) {  // a faulted launch must not hang the caller
@@ -3160,9 +2388,11 @@ const char* cafehip_describe(cafehip_ctx* c)
              c->k2_cfg[2], c->k2_cfg[3], c->k2_grid, c->k2_park_slots);
     c->desc = buf;
     if (c->cp.valid) {
-        snprintf(buf, sizeof buf, " compressed(nodes=%d levels=%zu states=%ld walk_steps=%zu walk_cols=%d used=%d)", c->cp.n_nodes,
+        snprintf(buf, sizeof buf, " compressed(nodes=%d levels=%zu states=%ld walk_steps=%zu walk_cols=%d used=%d level_tiles=", c->cp.n_nodes,
                  c->cp.level_first.size() - 1, c->cp.states, c->cp.sched.ops.size(), c->cp.n_cols, (int)c->last_compressed);
         c->desc += buf;
+        for (size_t l = 0; l + 1 < c->cp.level_first.size(); ++l) c->desc += (l ? "/" : "") + std::to_string(c->cp.level_first[l + 1] - c->cp.level_first[l]);
+        c->desc += ")";
     }
     return c->desc.c_str();
 }

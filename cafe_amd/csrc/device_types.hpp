@@ -1,0 +1,237 @@
+// device_types.hpp -- parameter blocks shared by the kernel translation units (k1_matrices.hip, k2_walk16.hip,
+// k2_walk4.hip, k2c_tables.hip, k_misc.hip) and the context / C ABI (cafehip.hip).  Every kernel takes ONE struct by
+// value, so the context launches any of them through hipLaunchKernel with the function address a translation unit
+// hands out (kernels.hpp) -- the kernels themselves stay private to their unit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/cafehip.h"
+#include "schedule.hpp"
+
+namespace cafehip {
+
+constexpr int kMaxNodesCap = 4095;   // sanity bound on the tree (2,048 taxa); nothing is sized by it
+constexpr int kMaxPrior = 1000;      // FAMILYSIZEMAX, libtree/family.h:8
+constexpr int kParamRing = 8;
+constexpr int kMaxSets = CAFEHIP_MAX_SETS;   // parameter sets evaluated in one pass (cafehip_eval_posterior_multi)
+
+// one transition matrix of an evaluation: (int branch length, lambda, mu) reduced to the scalars K1 needs
+struct KeyParam {
+    double log_alpha, log_beta, log_coeff, coeff;
+    double l2a, l2b, rho_m;   // product form (host_math.hpp KeyScalars)
+    int rho_e;
+    int fast_ok;
+    int mode;  // host_math.hpp KeyScalars
+    int bl;
+};
+
+// Per-evaluation parameter block in PINNED, device-mapped host memory (a ring of kParamRing): K1 reads its keys
+// straight from it and mirrors the node -> matrix map into device memory for the later launches.  Flat, sized by
+// the tree: [EvalHeader][KeyParam keys[key_cap]][int32 node_key[kMaxSets][n_nodes]]
+struct EvalHeader {
+    int nkeys, n_sets, n_nodes, key_cap;
+};
+__host__ __device__ inline const KeyParam* eval_keys(const EvalHeader* h) { return reinterpret_cast<const KeyParam*>(h + 1); }
+__host__ __device__ inline KeyParam* eval_keys(EvalHeader* h) { return reinterpret_cast<KeyParam*>(h + 1); }
+__host__ __device__ inline const int32_t* eval_node_key(const EvalHeader* h, int key_cap)
+{
+    return reinterpret_cast<const int32_t*>(eval_keys(h) + key_cap);
+}
+__host__ __device__ inline int32_t* eval_node_key(EvalHeader* h, int key_cap) { return reinterpret_cast<int32_t*>(eval_keys(h) + key_cap); }
+inline size_t eval_block_bytes(int key_cap, int n_nodes)
+{
+    return sizeof(EvalHeader) + (size_t)key_cap * sizeof(KeyParam) + (size_t)kMaxSets * n_nodes * sizeof(int32_t);
+}
+
+// ---- K1 ------------------------------------------------------------------------------------------------------
+struct K1Args {
+    const EvalHeader* ep;        // pinned host block of this evaluation
+    const double* tabA;          // ln C tables (exact form) or their exp() twins (product forms)
+    const double* tabB;
+    int ld_lnc;
+    double* PT;
+    int M, LD, KP;
+    int32_t* first_zero;         // reset to INT32_MAX per set (the score kernel atomicMin's into it), or NULL
+    int keys_per_block;
+    int32_t* node_key_dev;       // mirror target [n_sets][n_nodes], or NULL
+    int n_nodes, n_sets, nkeys, key_cap;
+};
+
+struct FoldArgs {   // k1e_fold_error
+    const double* PT;
+    double* PTfold;
+    const double* err;
+    int err_ld, banded, dlo, dhi, C, KP, LD;
+};
+
+// ---- K2, row-per-thread kernel (k2_prune_v1) and the carrier the launchers fill -------------------------------
+struct K2Args {
+    const double* PT;        // [nkeys][KP][LD]  PT[k][c*LD + s] = Pr(c | s)
+    const int32_t* node_key; // device [n_sets][n_nodes]
+    int n_nodes;
+    const double* prior;     // device [R]
+    const double* logprior;  // device [R]
+    const PruneOp* ops;
+    int n_ops;
+    const int32_t* counts;   // [Fu][n_leaves]
+    int Fu;
+    int n_leaves;
+    int C;                   // range_max + 1 (range_min == 0)
+    int R;                   // root_max - root_min + 1
+    int root_min;
+    int LD, KP, LDv;
+    int n_slots;
+    // error model (optional)
+    const double* err;       // [(mfs+1)^2] row = observed
+    int err_ld;
+    const uint8_t* leaf_has_err;  // [n_leaves] by count column
+    // per-row extents (batch mode; NULL in posterior mode)
+    const int32_t* root_lo;
+    const int32_t* root_hi;
+    const int32_t* col_max;
+    const int64_t* out_off;  // packed offsets of the root vectors
+    double* out_root;
+    // posterior outputs
+    double* max_lik;
+    int32_t* argmax;
+    double* max_post;
+};
+
+// ---- K2 on the matrix cores (k2_mfma.hpp) ----------------------------------------------------------------------
+struct K2MfmaArgs {
+    const double* PT;
+    const int32_t* node_key;   // device [n_sets][n_nodes]
+    int n_nodes;
+    const double* prior;       // device [R]
+    const double* logprior;
+    const MfmaOp* ops;
+    int n_ops;
+    int32_t* park_flags;   // [n_park_slots] 0 = free: a workgroup that parks in global memory owns one slot of the
+    int n_park_slots;      // scratch while it runs (slots ~ 2x the resident workgroups, not one per family tile)
+    int n_sets;            // gridDim.y: parameter sets evaluated in this pass; set s reads node_key[s], writes outputs at s * Fu
+    int lds_parks;         // park slots [0, lds_parks) live in LDS behind the node buffer (no global round trip)
+    const int32_t* counts;
+    int Fu;
+    int n_leaves;
+    int C, R, root_min;
+    int LD, KP, LDv;
+    int ksteps;            // ceil(C / 4)
+    int Wf, Wr;            // wave grid
+    int NF;                // families per workgroup = 16 * Wf * NFT_W
+    double* park;          // [n_park_slots][n_parks][NF][LDv]
+    int n_parks;
+    // error model
+    const double* err;
+    int err_ld;
+    const uint8_t* leaf_has_err;
+    int err_banded;        // 1: errormatrix[obs][true] is zero unless err_dlo <= true - obs <= err_dhi
+    int err_dlo, err_dhi;
+    const double* PTfold;  // posterior mode: error model folded into the leaf matrices (k1e_fold_error), or NULL
+    // batch mode (per-row extents)
+    const int32_t* root_lo;
+    const int32_t* root_hi;
+    const int32_t* col_max;
+    const int64_t* out_off;
+    double* out_root;
+    // posterior outputs
+    double* max_lik;
+    int32_t* argmax;
+    double* max_post;
+    // compressed subtrees (schedule.hpp, CTile): factor tables [set][node table][state][LD], rows gathered like
+    // matrix columns by a child of kind 2; table_off[node] = element offset of the node's table
+    const double* tables;
+    const int32_t* table_off;
+    size_t table_set_stride;
+    // debug builds (-DCAFE_K2_STAMPS): s_memtime stamps [workgroup][wave][K2_STAMP_SLOTS], else NULL and unused
+    unsigned long long* stamps;
+};
+
+// ---- k2c_nodes: factor tables of compressed subtrees -----------------------------------------------------------
+struct K2cArgs {
+    const double* PT;
+    const double* PTfold;             // or NULL
+    const int32_t* node_key;          // device [n_sets][n_nodes]
+    int n_nodes;
+    const CTile* tiles;               // this level's tiles
+    const uint8_t* leaf_has_err;      // by count-table column, or NULL
+    double* tables;
+    size_t table_set_stride;
+    int C, LD, KP, LDv, ksteps;
+};
+
+// ---- K3 --------------------------------------------------------------------------------------------------------
+// Results of the synchronous path go straight to pinned, device-visible host memory (no copy kernels, no
+// interrupt-driven wait): every block stores its chunk sum there, the last block to arrive (device counter)
+// publishes the first-zero index and a sequence number the host spins on.
+struct HostResult {
+    volatile int32_t done_seq;
+    int32_t first_zero[kMaxSets];
+    int32_t pad;
+    double chunk_sums[1];  // [n_sets][n_chunks]
+};
+
+struct K3Args {
+    const double* max_post_u;
+    const double* max_lik_u;
+    const int32_t* fam2u;
+    int F, Fu;
+    double* chunk_sums;
+    int32_t* first_zero;
+    HostResult* host;
+    int32_t* arrive;
+    int32_t seq;
+};
+
+struct ClusterWeights {
+    double w[kMaxSets];
+};
+
+struct K3cArgs {   // k3_cluster_score
+    const double* max_post_u;
+    const int32_t* fam2u;
+    int F, Fu, K;
+    ClusterWeights cw;
+    double* chunk_sums;
+    double* memb_sums;      // [K][n_chunks]
+    int32_t* first_zero;
+    double* map_out;        // [F] or NULL
+    double* pz_out;         // [F][K] or NULL
+};
+
+struct FetchArgs {   // k_fetch_small
+    const uint64_t* src;
+    uint64_t* host_dst;
+    size_t n_words;
+    volatile int32_t* host_seq;
+    int32_t seq;
+};
+
+// ---- K4 --------------------------------------------------------------------------------------------------------
+struct K4Args {
+    const double* PT;
+    const int32_t* node_key;   // device [n_nodes] (set 0)
+    const PruneOp* ops;
+    int n_ops;
+    const int32_t* counts;
+    int B, n_leaves, n_nodes;
+    int C, R, root_min;
+    int LD, KP, LDv;
+    int n_slots;
+    int root;
+    const int32_t* parent;     // [n_nodes]
+    const int32_t* prefix;     // [n_nodes] prefix order
+    const int32_t* vit_slot;   // [n_nodes] table index of internal non-root nodes, -1 otherwise
+    int n_tables;
+    const int32_t* root_lo;
+    const int32_t* root_hi;
+    const int32_t* col_max;
+    int32_t* node_sizes;       // [B][n_nodes]
+    unsigned short* vit_global;  // argmax tables in global scratch [grid][n_tables][NF][LDv], or NULL: in LDS
+};
+
+constexpr int K2_STAMP_SLOTS = 512;
+
+}  // namespace cafehip

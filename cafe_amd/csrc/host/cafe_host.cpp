@@ -741,6 +741,13 @@ struct cafehost_session {
     }
 
     bool report_sharded() const { return shard_world > 1 && allgather != nullptr; }
+    // report-phase commands read `params` as ONE model's rates (node_rates); after `lambda -k` it holds K x lambdas
+    // plus K - 1 weights
+    void require_single_model(const char* what) const
+    {
+        if (k_clusters > 0)
+            throw std::runtime_error(std::string(what) + " is not supported after `lambda -k` (clustered model): set a single model with lambda / lambdamu first");
+    }
     // contiguous block of [0, n) owned by rank r
     void block_of(int n, int r, int& lo, int& hi) const
     {
@@ -850,6 +857,7 @@ struct cafehost_session {
     void upload()
     {
         if (device_families_current) return;
+        spec.clear();   // cached scores belong to the table / tree / error model that was on the device
         hip_check(cafehip_set_tree(ctx, tree.n, tree.parent.data(), tree.left.data(), tree.right.data(), tree.bl.data()));
         const int nl = tree.n_leaves();
         const int Fall = fam.F();
@@ -882,6 +890,7 @@ struct cafehost_session {
     // ---- prior: cafe_set_prior_rfsize_empirical, cafe/lambda.cpp:808-870 ----
     void set_prior_rfsize_empirical()
     {
+        spec.clear();   // ... and to the prior they were computed under
         std::vector<int> leaf_sizes;  // collect_leaf_sizes :789-806
         const int ns = (int)fam.species.size();
         for (int idx = 0; idx < fam.F(); ++idx)
@@ -956,11 +965,13 @@ struct cafehost_session {
     };
     std::vector<SpecEntry> spec;
     long spec_launches = 0, spec_points = 0, spec_hits = 0;
+    int opt_speculate = -1;      // cafehost_set_option "speculate": -1 by how full the chip is, 0 off, 1 on
+    bool opt_timing = false;     // "timing": phase times of report / the Monte-Carlo null on stderr
 
     bool speculation_pays()
     {
         if (exchange) return false;   // sharded: every evaluation already ends in a collective
-        if (const char* e = getenv("CAFEHOST_SPECULATE")) return atoi(e) != 0;
+        if (opt_speculate >= 0) return opt_speculate != 0;
         int wg = 0, cu = 0;
         if (cafehip_launch_info(ctx, &wg, &cu) != 0) return false;
         return wg > 0 && 2 * wg <= cu;
@@ -1142,7 +1153,7 @@ struct cafehost_session {
         lambda_tree = lt;
         have_lambda_tree = true;
         num_lambdas = (int)seen.size();
-        if (!quiet) {
+        if (!quiet && shard_rank == 0) {   // (every rank runs the script; one echo)
             printf("The number of lambdas is %d\n", num_lambdas);
             fflush(stdout);
         }
@@ -1296,6 +1307,10 @@ struct cafehost_session {
     // pass over the table for all K clusters, then the weights become the mean memberships (cafe_main.c:243-245).
     double cluster_objective(const double* x)
     {
+        // the device call scores the table that is on THIS device: a shard would give every rank a different score
+        // and memberships indexed by local family
+        if (exchange || shard_world > 1)
+            throw std::runtime_error("the k-cluster model is not sharded: run `lambda -k` / `score` of a clustered model on one rank");
         const int K = k_clusters, fix = fixcluster0 ? 1 : 0;
         const int n_lam = num_lambdas * (K - fix);
         double score = 0;
@@ -1328,7 +1343,7 @@ struct cafehost_session {
         ++n_evals;
         for (int i = 0; i < num_params; ++i) trace.push_back(x[i]);
         trace.push_back(score);
-        if (!quiet) {
+        if (!quiet && shard_rank == 0) {
             printf("Lambda : %s\n", join_double(x, n_lam).c_str());
             printf("p : %s\n", join_double(k_weights.data(), K).c_str());
             printf("Score: %f\n", score);
@@ -1686,6 +1701,7 @@ struct cafehost_session {
                 }
             }
             if (fp) fclose(fp);
+            spec.clear();   // the last batch of grid points must not outlive the command
             return 0;
         }
         set_prior_rfsize_empirical();
@@ -1736,6 +1752,8 @@ struct cafehost_session {
         checkconv = false;
         have_lambda_tree = false;
         num_lambdas = 1;
+        k_clusters = 0;        // a lambda/mu model replaces a clustered one (cafe/lambdamu.cpp:218-269 has no -k)
+        fixcluster0 = false;
         bool search_flag = false;
         std::vector<double> lambdas, mus;
         for (auto& a : args) {
@@ -1837,7 +1855,7 @@ struct cafehost_session {
                 });
             for (auto& th : pool) th.join();
         }
-        const bool show_times = getenv("CAFEHOST_TIMING") != nullptr;
+        const bool show_times = opt_timing;
         const auto t_sampled = std::chrono::steady_clock::now();
         std::vector<double> probs((size_t)R * trials);
         if (report_sharded()) {
@@ -1871,7 +1889,8 @@ struct cafehost_session {
     int cmd_report(const std::vector<std::string>& tokens)
     {  // cafe_cmd_report / cafe_do_report, cafe/cafe_commands.cpp:1010-1018, cafe/reports.cpp:650-708 (text format)
         prereqs(true, true);
-        const bool show_times = getenv("CAFEHOST_TIMING") != nullptr;
+        require_single_model("report");
+        const bool show_times = opt_timing;
         auto t_last = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) {
             if (!show_times) return;
@@ -2223,6 +2242,7 @@ struct cafehost_session {
                 if (species_index[s_] >= 0) err_leaf[species_index[s_]] = 1;
         }
         device_families_current = false;
+        spec.clear();
         fprintf(stderr, "errormodel: %s set.\n", model.c_str());
         return 0;
     }
@@ -2303,8 +2323,10 @@ struct cafehost_session {
             for (int s_ = 0; s_ < ns; ++s_)
                 if (species_index[s_] >= 0) counts[(size_t)i * nl + species_index[s_] / 2] = fam.counts[(size_t)i * ns + s_];
         std::vector<int32_t> sizes((size_t)std::max(F, 1) * n);
-        printf("Viterbi\n");
-        fflush(stdout);
+        if (shard_rank == 0) {
+            printf("Viterbi\n");
+            fflush(stdout);
+        }
         if (F) hip_check(cafehip_viterbi(ctx, F, counts.data(), lo.data(), hi.data(), cm.data(), sizes.data()));
         root_dist.assign(range.root_max - range.root_min + 2, 0);
         for (int i = 0; i < F; ++i) {
@@ -2323,7 +2345,8 @@ struct cafehost_session {
         double score;
         if (k_clusters > 0) {
             score = -cluster_objective(params.data());
-            log("Lambda : %s\n", join_double(params.data(), num_lambdas * k_clusters).c_str());
+            const int fix = fixcluster0 ? 1 : 0;
+            log("Lambda : %s%s\n", fix ? "0," : "", join_double(params.data(), num_lambdas * (k_clusters - fix)).c_str());
             log("p : %s\n", join_double(k_weights.data(), k_clusters).c_str());
             log("Score: %f\n", score);
         } else {
@@ -2388,6 +2411,7 @@ struct cafehost_session {
     {  // cafe_cmd_generate_random_family, cafe/cafe_commands.cpp:718-815
         if (tokens.size() == 1) throw std::runtime_error("Usage: genfamily directory/fileprefix -t integer");
         prereqs(false, true);
+        require_single_model("genfamily");
         int num_trials = 1;
         for (auto& a : build_argument_list(tokens))
             if (a.opt == "-t" && !a.argv.empty()) num_trials = atoi(a.argv[0].c_str());
@@ -2472,6 +2496,7 @@ struct cafehost_session {
     int cmd_lhtest(const std::vector<std::string>& tokens)
     {  // cafe_cmd_lhtest, cafe/cafe_commands.cpp:1473-1536
         prereqs(false, true);
+        require_single_model("lhtest");
         if (shard_world > 1 && !native_comm)
             throw std::runtime_error("lhtest under a callback exchange is not supported: every file it loads needs the "
                                      "exchange re-wired; use the native communicator (cafehost_init_comm) or one rank");
@@ -2523,6 +2548,7 @@ struct cafehost_session {
     int cmd_pvalue(const std::vector<std::string>& tokens)
     {  // cafe_cmd_pvalue, cafe/cafe_commands.cpp:1373-1412 (-o / -i / -idx)
         prereqs(false, true);
+        require_single_model("pvalue");
         std::string outfile, infile;
         int index = -1;
         for (auto& a : build_argument_list(tokens)) {
@@ -2575,7 +2601,7 @@ struct cafehost_session {
             const int32_t lo = range.root_min, hi = range.root_max, cm = range.max;
             std::vector<double> lh(hi - lo + 1);
             hip_check(cafehip_eval_root_likelihoods(ctx, 1, counts.data(), &lo, &hi, &cm, lh.data()));
-            for (int i = 0; i <= hi - lo; ++i)
+            for (int i = 0; i <= hi - lo && shard_rank == 0; ++i)
                 printf("%d\t%lg\t%lg\n", i + range.root_min, lh[i], pvalue_rank(lh[i], cond_dist[i].data(), num_random_samples));
             fflush(stdout);
             return 0;
@@ -2624,7 +2650,7 @@ struct cafehost_session {
         }
         if (cmd == "log") {  // cafe_cmd_log, cafe/cafe_commands.cpp:325-344
             if (tokens.size() == 1) {
-                printf("Log: %s\n", flog == stdout ? "stdout" : log_name.c_str());
+                if (shard_rank == 0) printf("Log: %s\n", flog == stdout ? "stdout" : log_name.c_str());
                 fflush(stdout);
                 return 0;
             }
@@ -2708,7 +2734,29 @@ int cafehost_create(cafehost_session** out, int device_id, const char* log_path)
         s->own_log = true;
         s->log_name = log_path;
     }
+    // read once, here: nothing consults the environment during a command
+    if (const char* e = getenv("CAFEHOST_SPECULATE")) s->opt_speculate = atoi(e) != 0;
+    if (getenv("CAFEHOST_TIMING")) s->opt_timing = true;
     *out = s;
+    return 0;
+}
+
+int cafehost_set_option(cafehost_session* s, const char* key, const char* value)
+{
+    if (!s || !key) return host_fail("null argument");
+    const std::string k = key, v = value ? value : "";
+    if (k == "speculate") {
+        s->opt_speculate = (v.empty() || v == "auto") ? -1 : (atoi(v.c_str()) != 0);
+        return 0;
+    }
+    if (k == "timing") {
+        s->opt_timing = atoi(v.c_str()) != 0;
+        return 0;
+    }
+    // everything else is a switch of the device context(s)
+    if (cafehip_set_option(s->ctx, key, v.c_str()) != 0) return host_fail(std::string("cafehip: ") + cafehip_last_error());
+    if (s->ctx_one && cafehip_set_option(s->ctx_one, key, v.c_str()) != 0) return host_fail(std::string("cafehip: ") + cafehip_last_error());
+    s->spec.clear();
     return 0;
 }
 

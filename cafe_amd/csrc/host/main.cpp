@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <algorithm>
+#include <csignal>
 #include <string>
 #include <vector>
 
@@ -82,11 +84,22 @@ int main(int argc, char** argv)
             }
             kids.push_back(pid);
         }
+        // wait for whichever child ends next; one that dies (e.g. before it joins the communicator) would leave the
+        // others waiting in ncclCommInitRank or a collective forever: end them too
         int bad = 0;
-        for (pid_t k : kids) {
+        size_t left = kids.size();
+        while (left > 0) {
             int st = 0;
-            waitpid(k, &st, 0);
-            if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) ++bad;
+            const pid_t k = waitpid(-1, &st, 0);
+            if (k < 0) break;
+            if (std::find(kids.begin(), kids.end(), k) == kids.end()) continue;
+            --left;
+            if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+                if (!bad)
+                    for (pid_t other : kids)
+                        if (other != k) kill(other, SIGTERM);   // exact pids of our own children (already-reaped ones are gone)
+                ++bad;
+            }
         }
         unlink(path);
         return bad ? 1 : 0;

@@ -20,59 +20,21 @@
 // B lane holds PT[k0 + (l>>4)][row0 + (l&15)]; D reg r holds
 // Y[fam0 + (l>>4) + 4r][row0 + (l&15)]   (verified by tools/mfma_f64_probe.hip).
 #pragma once
+#include <climits>
+#include <cmath>
+
+#include "kernels.hpp"
+
+namespace {
+using namespace cafehip;
 
 typedef double cafe_d4 __attribute__((ext_vector_type(4)));
 
-struct K2MfmaArgs {
-    const double* PT;
-    const EvalParams* ep;
-    const cafehip::MfmaOp* ops;
-    int n_ops;
-    int32_t* park_flags;   // [n_park_slots] 0 = free: a workgroup that parks in global memory owns one slot of the
-    int n_park_slots;      // scratch while it runs (slots ~ 2x the resident workgroups, not one per family tile)
-    int n_sets;            // gridDim.y: parameter sets evaluated in this pass; set s reads node_key[s], writes outputs at s * Fu
-    int lds_parks;         // park slots [0, lds_parks) live in LDS behind the node buffer (no global round trip)
-    const int32_t* counts;
-    int Fu;
-    int n_leaves;
-    int C, R, root_min;
-    int LD, KP, LDv;
-    int ksteps;            // ceil(C / 4)
-    int Wf, Wr;            // wave grid
-    int NF;                // families per workgroup = 16 * Wf * NFT_W
-    double* park;          // [n_park_slots][n_parks][NF][LDv]
-    int n_parks;
-    // error model
-    const double* err;
-    int err_ld;
-    const uint8_t* leaf_has_err;
-    int err_banded;        // 1: errormatrix[obs][true] is zero unless err_dlo <= true - obs <= err_dhi
-    int err_dlo, err_dhi;
-    const double* PTfold;  // posterior mode: error model folded into the leaf matrices (k1e_fold_error), or NULL
-    // batch mode (per-row extents)
-    const int32_t* root_lo;
-    const int32_t* root_hi;
-    const int32_t* col_max;
-    const int64_t* out_off;
-    double* out_root;
-    // posterior outputs
-    double* max_lik;
-    int32_t* argmax;
-    double* max_post;
-    // compressed subtrees (schedule.hpp, CTile): factor tables [set][node table][state][LD], rows gathered like
-    // matrix columns by a child of kind 2; table_off[node] = element offset of the node's table
-    const double* tables;
-    const int32_t* table_off;
-    size_t table_set_stride;
-    // debug builds (-DCAFE_K2_STAMPS): s_memtime stamps [workgroup][wave][K2_STAMP_SLOTS], else NULL and unused
-    unsigned long long* stamps;
-};
 
 // Phase timeline of the walk for tools/k2_stamps.py: lane 0 of every wave records the shader clock at fixed points
 // (slot 0 kernel start, 1 after the prologue, 2 + 6 * step + {0: leaf gathers issued, 1: first child factor done,
 // 2: second child factor done, 3: past the read barrier, 4: result written + visible}, last: after the epilogue).
 // Compiled out of the product library.
-constexpr int K2_STAMP_SLOTS = 512;
 #ifdef CAFE_K2_STAMPS
 #define K2_STAMP(slot)                                                                                         \
     do {                                                                                                       \
@@ -82,28 +44,6 @@ constexpr int K2_STAMP_SLOTS = 512;
 #else
 #define K2_STAMP(slot) ((void)0)
 #endif
-
-// Error model folded into the matrices (posterior mode).  For a leaf with an error model the edge factor of a
-// family is  sum_k errormatrix[observed][k] * P[row][k]  (cafe/cafe_tree.c:196-203 then :213-224), a function of
-// (matrix, observed count, row) only -- not of the family.  It is formed once per evaluation,
-//   PTfold[key][observed][row] = sum_{k ascending} err[observed][k] * PT[key][k][row],
-// in the same order as the per-family sums of the walk, and the leaf becomes a plain column gather on PTfold.
-// Not usable with per-row column limits (batch mode clips the sum at col_max of each row).
-__global__ __launch_bounds__(256) void k1e_fold_error(const double* __restrict__ PT, double* __restrict__ PTfold,
-                                                      const double* __restrict__ err, int err_ld, int banded,
-                                                      int dlo, int dhi, int C, int KP, int LD)
-{
-    const int key = blockIdx.z, cnt = blockIdx.y;
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= LD) return;
-    const double* P = PT + (size_t)key * KP * LD + s;
-    const double* erow = err + (size_t)cnt * err_ld;
-    const int klo = banded ? max(cnt + dlo, 0) : 0;
-    const int khi = banded ? min(cnt + dhi, C - 1) : C - 1;
-    double v = 0.0;
-    for (int k = klo; k <= khi; ++k) v += erow[k] * P[(size_t)k * LD];
-    PTfold[(size_t)key * KP * LD + (size_t)cnt * LD + s] = v;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // One edge product: acc[i][j] += node-vector tile(i) x matrix tile(j) over all k-steps, explicitly software-
@@ -286,18 +226,6 @@ __device__ __forceinline__ void mfma4_edge_p(k2_gbytes sb, const unsigned (&voff
 // Pieces shared by the two kernels
 // ---------------------------------------------------------------------------------------------------
 
-// LDS behind the node-vector buffers: the walk's scratch (counts, column limits, step list) and, once the walk is
-// over, the epilogue's scratch (candidate lists + per-family maxima) share it; the launcher sizes it for both.
-// Layout: [step list, matrix offsets, error flags: loaded once per workgroup] then, per family tile, the union of
-// [counts, column limits] (walk) and [candidate lists, per-family maxima] (epilogue).
-__host__ __device__ inline size_t k2_scratch_bytes(int nf, int n_leaves, int n_ops)
-{
-    const size_t fixed = (size_t)n_ops * (12 + 2 + 2) * 4;
-    const size_t walk = (size_t)nf * n_leaves * 4 + (size_t)nf * 4 + 8;   // + the park-slot word
-    const size_t epi = 8 * 64 * 4 + (size_t)nf * 8 + 16;
-    return fixed + (walk > epi ? walk : epi);
-}
-
 // Park scratch in global memory (node vectors waiting for their sibling, when they do not fit LDS): a workgroup owns
 // one SLOT of it while it runs.  Slots are claimed with one atomic compare-and-swap on a flag array, scanning from
 // blockIdx.x % slots (workgroups are dispatched in order, so the first try almost always succeeds) and released at
@@ -379,8 +307,8 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
     int32_t* const argmax = a.argmax + out_off;
     unsigned* cand = reinterpret_cast<unsigned*>(scratch) + wave * 64;                        // (family << 16) | root index
     unsigned long long* fmaxbits = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(scratch) + 8 * 64);   // [NF]
-    const double* prior = a.ep->prior;
-    const double* logprior = a.ep->logprior;
+    const double* prior = a.prior;
+    const double* logprior = a.logprior;
     double pr[PR], lpr[PR];
     if (REGS) {
         // one global round trip per wave instead of one per family and pass (L2 latency under load is ~1-2 k cycles)
@@ -560,7 +488,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
         const cafehip::MfmaOp& o = a.ops[i >> 1];
         // element offset (< 2^31) of the child's matrix, or of its factor table when it is a compressed subtree
-        s_key[i] = (o.kind[i & 1] == 2) ? a.table_off[o.child[i & 1]] : a.ep->node_key[blockIdx.y][o.child[i & 1]] * a.KP * a.LD;
+        s_key[i] = (o.kind[i & 1] == 2) ? a.table_off[o.child[i & 1]] : a.node_key[blockIdx.y * a.n_nodes + o.child[i & 1]] * a.KP * a.LD;
         s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
     }
 
@@ -795,7 +723,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     for (int i = tid; i < a.n_ops * 2; i += blockDim.x) {
         const cafehip::MfmaOp& o = a.ops[i >> 1];
         // element offset (< 2^31) of the child's matrix, or of its factor table when it is a compressed subtree
-        s_key[i] = (o.kind[i & 1] == 2) ? a.table_off[o.child[i & 1]] : a.ep->node_key[blockIdx.y][o.child[i & 1]] * a.KP * a.LD;
+        s_key[i] = (o.kind[i & 1] == 2) ? a.table_off[o.child[i & 1]] : a.node_key[blockIdx.y * a.n_nodes + o.child[i & 1]] * a.KP * a.LD;
         s_err[i] = (o.kind[i & 1] == 0 && a.err != nullptr && a.leaf_has_err[o.leafcol[i & 1]]) ? 1 : 0;
     }
 
@@ -997,25 +925,60 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 // rows [0, C) of the result as table[state][row]; the consumer adds the root offset exactly as for a leaf column.
 // 16x16x4 shape, one 16-state tile, Wr = blockDim.x / 64 wave rows of NRT_W row tiles.
 // ====================================================================================
-struct K2cArgs {
-    const double* PT;
-    const double* PTfold;             // or NULL
-    const EvalParams* ep;
-    const cafehip::CTile* tiles;      // this level's tiles
-    const uint8_t* leaf_has_err;      // by count-table column, or NULL
-    double* tables;
-    size_t table_set_stride;
-    int C, LD, KP, LDv, ksteps;
-};
 
-// A level is a few hundred workgroups: one or two waves per SIMD, nothing to switch to while an operand is in flight,
-// so the rings are deep and a tile's rows are spread over as many waves as it has row tiles (up to 16).  A tile holds
-// 16 * NFT_W states; the launcher uses NFT_W = 1 (larger tiles measured slower).
+// A level is a few hundred workgroups: one or two waves per SIMD, nothing to switch to while an operand is in flight --
+// a tile is a chain of memory round trips (tile record -> matrix keys -> child columns -> matrix operand), so the
+// chain is made as short as the data dependencies allow (round 3):
+//   * the child columns of ALL the tile's states are requested in one batch (registers), not one round trip per
+//     slice of the vector;
+//   * the node's own matrix does not depend on the states at all: a wave requests its whole operand -- every k-step
+//     of its row tile, KPF of them at once, the rest as ring slots free up -- BEHIND the column gathers (loads return
+//     in order) and before the vectors are formed, so the product loop finds it in registers;
+//   * one wave per row tile up to 16 waves.  A tile holds 16 * NFT_W states; the launcher uses NFT_W = 1 (larger
+//     tiles measured slower).
+// Same matrix instructions on the same operands in the same k order as the ring loop: bit-identical tables.
 #ifndef CAFE_K2C_DEPTH
 #define CAFE_K2C_DEPTH 6
 #endif
-template <int NFT_W, int NRT_W>
-__global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
+constexpr int K2C_GATHER_MAX = 6;   // vector slices per thread kept in registers (LDv <= 6 * threads per state, else a loop)
+
+// NRT_W == 1: KPF k-steps of the wave's row tile requested up front, straight-line product over at most KMAX k-steps
+// (unconditional and branch-free: a branch around a load makes the compiler drain every outstanding load at the join
+// before the gathers can be consumed; k-steps beyond the matrix re-read the last one and are never multiplied)
+template <int KPF, int KMAX>
+__device__ __forceinline__ void k2c_issue_b(k2_gbytes sb, unsigned vo, unsigned kstride_bytes, int ksteps, double (&bq)[KPF])
+{
+#pragma unroll
+    for (int k = 0; k < KPF; ++k) {
+        const unsigned off = (unsigned)min(k, ksteps - 1) * kstride_bytes;   // scalar
+        bq[k] = *(k2_gptr)(sb + off + vo);
+    }
+}
+
+template <int KPF, int KMAX>
+__device__ __forceinline__ void k2c_product(k2_gbytes sb, unsigned vo, unsigned kstride_bytes, const double* ap, int ksteps,
+                                            double (&bq)[KPF], cafe_d4& acc)
+{
+    const k2_lptr pa = (k2_lptr)ap;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < ksteps) {
+            const double av = pa[k * 4];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bq[k % KPF], acc, 0, 0, 0);
+            if constexpr (KPF < KMAX) {
+                if (k + KPF < KMAX) {   // the slot is free: ask for k-step k + KPF (clamped, unconditional)
+                    const unsigned off = (unsigned)min(k + KPF, ksteps - 1) * kstride_bytes;
+                    bq[k % KPF] = *(k2_gptr)(sb + off + vo);
+                }
+            }
+        }
+    }
+}
+
+// (matrix sides up to 160 have at most 10 row tiles = 10 waves: the tighter bound leaves the 40-k-step variant 170
+// registers per lane instead of 128)
+template <int NFT_W, int NRT_W, int KPF, int KMAX, bool BATCH>
+__global__ __launch_bounds__(KMAX == 40 ? 640 : 1024) void k2c_nodes(K2cArgs a)
 {
     extern __shared__ double Lbuf[];   // [16 * NFT_W][LDv]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
@@ -1023,58 +986,81 @@ __global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
     const int set = blockIdx.y;
     double* const tab = a.tables + (size_t)set * a.table_set_stride;
     const int node = t.node, n_live = t.n_live;
-    {
-        // L[state][k] = F_a[k] * F_b[k]
-        const double* base[2];
-        bool leaf[2];
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            leaf[ch] = t.kind[ch] == 0;
-            if (leaf[ch]) {
-                const bool folded = a.PTfold != nullptr && a.leaf_has_err[t.leafcol[ch]];
-                base[ch] = (folded ? a.PTfold : a.PT) + (size_t)a.ep->node_key[set][t.child[ch]] * a.KP * a.LD;
-            } else {
-                base[ch] = tab + t.tab_off[ch];
-            }
-        }
-        // blockDim / states threads per state (all threads busy; contiguous runs of both columns)
-        const int per_state = blockDim.x / (16 * NFT_W);
-        const int f = tid / per_state, l = tid - f * per_state;
-        if (f < 16 * NFT_W) {
-            const int i0 = t.idx[0][f], i1 = t.idx[1][f];
-            // a count beyond the column range: no such column (cafe/cafe_tree.c:208-209)
-            const bool live = f < n_live && !(leaf[0] && i0 > a.C - 1) && !(leaf[1] && i1 > a.C - 1);
-            const double* c0 = base[0] + (size_t)(live ? i0 : 0) * a.LD;
-            const double* c1 = base[1] + (size_t)(live ? i1 : 0) * a.LD;
-            double* L = Lbuf + (size_t)f * a.LDv;
-            for (int k = l; k < a.LDv; k += per_state) L[k] = (live && k < a.C) ? c0[k] * c1[k] : 0.0;
-        }
-    }
-    __syncthreads();
     const int Wr = blockDim.x >> 6;
     const int RT = (a.C + 15) >> 4;
     const int rt_base = RT / Wr, rt_rem = RT - rt_base * Wr;
     const int ntile = rt_base + (wave < rt_rem ? 1 : 0);
     const int rt0 = wave * rt_base + min(wave, rt_rem);
+    const unsigned kstride_bytes = 32u * (unsigned)a.LD;
+    constexpr bool PREFETCH = (NRT_W == 1 && NFT_W == 1 && KPF > 0);
+    double bq[PREFETCH ? KPF : 1];
+    // every index this tile needs from the evaluation's node -> matrix map, requested together (no branches: one
+    // round trip behind the tile record)
+    const int32_t* nk = a.node_key + set * a.n_nodes;
+    const int key_node = nk[node], key_c0 = nk[t.child[0]], key_c1 = nk[t.child[1]];
+    const uint8_t* lhe = a.leaf_has_err ? a.leaf_has_err : reinterpret_cast<const uint8_t*>(a.tiles);   // (any readable byte)
+    const bool err0 = lhe[t.leafcol[0]] != 0, err1 = lhe[t.leafcol[1]] != 0;
+    const size_t msz = (size_t)a.KP * a.LD;
+    const k2_gbytes sb = k2_uniform(a.PT + (size_t)key_node * msz);
+    const unsigned vo0 = (unsigned)(lk * a.LD + li + min(rt0, RT - 1) * 16) * 8u;   // (a wave without a tile re-reads the last one)
+    {
+        // L[state][k] = F_a[k] * F_b[k]
+        const bool leaf0 = t.kind[0] == 0, leaf1 = t.kind[1] == 0;
+        const bool fold0 = a.PTfold != nullptr && a.leaf_has_err != nullptr && err0;
+        const bool fold1 = a.PTfold != nullptr && a.leaf_has_err != nullptr && err1;
+        const double* base0 = leaf0 ? (fold0 ? a.PTfold : a.PT) + (size_t)key_c0 * msz : tab + t.tab_off[0];
+        const double* base1 = leaf1 ? (fold1 ? a.PTfold : a.PT) + (size_t)key_c1 * msz : tab + t.tab_off[1];
+        // blockDim / states threads per state (all threads busy; contiguous runs of both columns)
+        const int per_state = blockDim.x / (16 * NFT_W);
+        const int f = tid / per_state, l = tid - f * per_state;   // f < 16 * NFT_W
+        const int i0 = t.idx[0][f], i1 = t.idx[1][f];
+        // a count beyond the column range: no such column (cafe/cafe_tree.c:208-209)
+        const bool live = f < n_live && !(leaf0 && i0 > a.C - 1) && !(leaf1 && i1 > a.C - 1);
+        const double* c0 = base0 + (size_t)(live ? i0 : 0) * a.LD;
+        const double* c1 = base1 + (size_t)(live ? i1 : 0) * a.LD;
+        double* L = Lbuf + (size_t)f * a.LDv;
+        if (BATCH && a.LDv <= K2C_GATHER_MAX * per_state) {
+            // all slices of both columns in one batch (clamped addresses, no branches), the matrix operand behind them
+            double g0[K2C_GATHER_MAX], g1[K2C_GATHER_MAX];
+#pragma unroll
+            for (int q = 0; q < K2C_GATHER_MAX; ++q) {
+                const int kc = min(l + q * per_state, a.C - 1);
+                g0[q] = c0[kc];
+                g1[q] = c1[kc];
+            }
+            if constexpr (PREFETCH) k2c_issue_b<KPF, KMAX>(sb, vo0, kstride_bytes, a.ksteps, bq);
+#pragma unroll
+            for (int q = 0; q < K2C_GATHER_MAX; ++q) {
+                const int k = l + q * per_state;
+                if (k < a.LDv) L[k] = (live && k < a.C) ? g0[q] * g1[q] : 0.0;
+            }
+        } else {
+            if constexpr (PREFETCH) k2c_issue_b<KPF, KMAX>(sb, vo0, kstride_bytes, a.ksteps, bq);
+            for (int k = l; k < a.LDv; k += per_state) L[k] = (live && k < a.C) ? c0[k] * c1[k] : 0.0;
+        }
+    }
+    __syncthreads();
     cafe_d4 fac[NFT_W][NRT_W];
 #pragma unroll
     for (int i = 0; i < NFT_W; ++i)
 #pragma unroll
         for (int j = 0; j < NRT_W; ++j) fac[i][j] = cafe_d4{0.0, 0.0, 0.0, 0.0};
     if (ntile > 0) {
-        unsigned voff[NRT_W];
-#pragma unroll
-        for (int j = 0; j < NRT_W; ++j) voff[j] = (unsigned)(lk * a.LD + li + ((j < ntile) ? (rt0 + j) : rt0) * 16) * 8u;
-        const k2_gbytes sb = k2_uniform(a.PT + (size_t)a.ep->node_key[set][node] * a.KP * a.LD);
         const double* ap = Lbuf + (size_t)li * a.LDv + lk;
-        const unsigned kstride_bytes = 32u * (unsigned)a.LD;
-        if constexpr (NRT_W > 1) {
-            if (ntile == NRT_W - 1)
-                mfma_edge_p<NFT_W, NRT_W, NRT_W - 1, CAFE_K2C_DEPTH>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
-            else
-                mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2C_DEPTH>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+        if constexpr (PREFETCH) {
+            k2c_product<KPF, KMAX>(sb, vo0, kstride_bytes, ap, a.ksteps, bq, fac[0][0]);
         } else {
-            mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2C_DEPTH>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+            unsigned voff[NRT_W];
+#pragma unroll
+            for (int j = 0; j < NRT_W; ++j) voff[j] = (unsigned)(lk * a.LD + li + ((j < ntile) ? (rt0 + j) : rt0) * 16) * 8u;
+            if constexpr (NRT_W > 1) {
+                if (ntile == NRT_W - 1)
+                    mfma_edge_p<NFT_W, NRT_W, NRT_W - 1, CAFE_K2C_DEPTH>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+                else
+                    mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2C_DEPTH>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+            } else {
+                mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2C_DEPTH>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+            }
         }
     }
     double* const out = tab + t.out_off + (size_t)t.state0 * a.LD;
@@ -1094,3 +1080,5 @@ __global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
         }
     }
 }
+
+}  // namespace

@@ -1,0 +1,49 @@
+// kernels.hpp -- what the kernel translation units hand to the context (cafehip.hip): the ADDRESS of a kernel
+// instantiation (or nullptr when that shape is not built), launched with hipLaunchKernel and one argument struct
+// (device_types.hpp).  Splitting the instantiations over several units keeps a rebuild after a kernel edit to the
+// unit that holds the kernel, and the units compile in parallel (cafe_amd/build.py).
+#pragma once
+#include "device_types.hpp"
+
+namespace cafehip {
+
+// k1_matrices.hip
+const void* k1_kernel(bool use_lds, bool product_form);   // k1_build_matrices<USE_LDS, PRODUCT_FORM>(K1Args)
+const void* k1_rb_kernel();                               // k1_build_matrices_rb(K1Args)
+int k1_rb_columns();                                      // columns per thread of the register-blocked kernel
+int k1_rb_bpad();                                         // zeros staged in front of every B row
+const void* k1e_fold_kernel();                            // k1e_fold_error(FoldArgs)
+
+// k2_walk16.hip / k2_walk4.hip: the family walk on the matrix cores (k2_mfma.hpp), K2MfmaArgs
+constexpr int kMaxTiles16 = 8;      // NFT_W * NRT_W accumulator tiles per wave (16x16x4 shape)
+constexpr bool k2_fits16(int nft_w, int nrt_w) { return nft_w >= 1 && nft_w <= 2 && nrt_w >= 1 && nrt_w <= 7 && nft_w * nrt_w <= kMaxTiles16; }
+// (G, NRT_W) wave tiles of the 4-family kernel that compile without scratch spills at 2 waves per SIMD (256 registers
+// per lane; checked with tools/k2_regs.py after every kernel change)
+constexpr bool k2_fits4(int G, int nrt_w) { return G >= 1 && G <= 8 && nrt_w >= 1 && nrt_w <= 7 && G * nrt_w <= 18 && !(G == 8 && nrt_w == 2); }
+const void* k2_mfma16_kernel(int nft_w, int nrt_w);
+const void* k2_mfma4_kernel(int G, int nrt_w);
+
+// k2c_tables.hip: factor tables of compressed subtrees, K2cArgs.  kpf: k-steps of the matrix operand requested up
+// front (0: the short ring of the walk)
+const void* k2c_kernel(int nft_w, int nrt_w, int kpf, int kmax);
+
+// k_misc.hip
+const void* k2_v1_kernel(int nf);          // k2_prune_v1<NF>(K2Args), NF in {1, 2, 4, 8, 16}
+const void* k3_kernel(bool host_out);      // k3_score<HOST_OUT>(K3Args)
+const void* k3_cluster_kernel();           // k3_cluster_score(K3cArgs)
+const void* fetch_small_kernel();          // k_fetch_small(FetchArgs)
+const void* k4_kernel(int nf);             // k4_viterbi<NF>(K4Args), NF in {1, 2, 4, 8}
+
+// LDS behind the node-vector buffers of the walk: the walk's scratch (counts, column limits, step list) and, once
+// the walk is over, the epilogue's scratch (candidate lists + per-family maxima) share it; the launcher sizes it for
+// both.  Layout: [step list, matrix offsets, error flags: loaded once per workgroup] then, per family tile, the union
+// of [counts, column limits] (walk) and [candidate lists, per-family maxima] (epilogue).
+__host__ __device__ inline size_t k2_scratch_bytes(int nf, int n_leaves, int n_ops)
+{
+    const size_t fixed = (size_t)n_ops * (12 + 2 + 2) * 4;
+    const size_t walk = (size_t)nf * n_leaves * 4 + (size_t)nf * 4 + 8;   // + the park-slot word
+    const size_t epi = 8 * 64 * 4 + (size_t)nf * 8 + 16;
+    return fixed + (walk > epi ? walk : epi);
+}
+
+}  // namespace cafehip

@@ -63,6 +63,10 @@ class Engine:
             pass
 
     # ---- setup -------------------------------------------------------------------------
+    def set_option(self, key, value):
+        """cafehip_set_option: run-time switches (see include/cafehip.h); value is converted with str()."""
+        _lib.check(self._L.cafehip_set_option(self._h, str(key).encode(), ("" if value is None else str(value)).encode()))
+
     def set_stream(self, hip_stream_handle):
         """Run on the caller's stream; 0 is the HIP default stream (torch's default stream handle)."""
         _lib.check(self._L.cafehip_set_stream(self._h, C.c_void_p(hip_stream_handle or 0)))

@@ -35,6 +35,10 @@ class CafeShell:
         """cafe_shell_dispatch_command (cafe/cafe_commands.cpp:504-536)."""
         return self._check(self._L.cafehost_dispatch(self._h, line.encode()))
 
+    def set_option(self, key, value):
+        """cafehost_set_option: "speculate", "timing", or any switch of the device context (include/cafehip.h)."""
+        self._check(self._L.cafehost_set_option(self._h, str(key).encode(), ("" if value is None else str(value)).encode()))
+
     def run_script(self, path):
         return self._check(self._L.cafehost_run_script(self._h, path.encode()))
 

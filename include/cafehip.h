@@ -51,6 +51,30 @@ int cafehip_abi_version(void);
 int cafehip_create(cafehip_ctx **out, int device_id);
 void cafehip_destroy(cafehip_ctx *ctx);
 
+/* Run-time switches of a context (A/B runs, tuning sweeps, tests of the alternative kernels).  Every one has a
+ * default that is the product path; none changes a value beyond what DESIGN.md states for it.  key / value:
+ *   compress        0|1        subtree-state compression of the objective path (1)
+ *   compress_theta  0..1       share of the unique rows a node's distinct states may reach (by table size)
+ *   compress_min    n          unique rows below which a table is left alone (64)
+ *   errfold         0|1        error model folded into the matrices in an objective evaluation (1)
+ *   errband         0|1        banded error models as short sums of column gathers (1)
+ *   k1              auto|exact|perterm   arithmetic form of the matrix build (auto: register-blocked product form)
+ *   k1kpb           n          matrices per K1 workgroup (1)
+ *   k2              auto|v1    pruning kernel: matrix cores | row-per-thread vector FMA
+ *   mfma            auto|4|16  matrix instruction shape of the walk
+ *   k2cfg, k2cfg4   "a,b,wf,wr"  pin the wave grid of the 16x16x4 / 4x4x4 kernel (empty: measured choice)
+ *   k2tune          0|1        measure the wave grids on the first evaluations of a table (1)
+ *   k2tune_log      0|1        print the measured table to stderr
+ *   k2slots         0|1        park scratch owned per resident workgroup (1) | one region per family tile
+ *   ldspark         n          park buffers kept in LDS (empty: by residency)
+ *   vitlds          0|1        Viterbi argmax tables in LDS (0: global scratch)
+ *   k2c_prefetch    0|1        factor-table kernel requests its whole matrix operand up front (1)
+ *   batch_trim      0|1        batch mode: a tile's products stop at its largest column limit (1)
+ * The same names, upper-cased behind CAFEHIP_ (CAFEHIP_COMPRESS=0 ...), are read from the environment ONCE, by
+ * cafehip_create; nothing reads the environment during an evaluation.  Options that change the compression plan
+ * rebuild it.  No reference counterpart. */
+int cafehip_set_option(cafehip_ctx *ctx, const char *key, const char *value);
+
 /* Run all subsequent work of this context on the caller's HIP stream (a hipStream_t passed as
  * void*).  NULL is the HIP legacy default stream -- the handle torch reports for its default
  * stream -- NOT "no stream": until this is called the context uses a private non-blocking stream. */
@@ -61,7 +85,7 @@ int cafehip_get_stream(cafehip_ctx *ctx, void **hip_stream);
 
 /* Tree topology in the reference's nlist numbering (in-order: even ids are
  * leaves, odd ids internal; cafe/cafe_commands.cpp:2028-2051).  parent[root] = -1,
- * left/right = -1 for leaves.  Branch lengths are truncated to int inside, as the
+ * left/right = -1 for leaves.  Up to 4,095 nodes (2,048 taxa; a sanity bound -- every buffer is sized by the tree).  Branch lengths are truncated to int inside, as the
  * reference's cache key does (libtree/birthdeath.h:26-31, cafe/cafe_tree.c:376).
  * Replaces: cafe_tree_new + tree_build_node_list as consumed by
  * cafe_tree_set_birthdeath (cafe/cafe_tree.c:461-483). */
@@ -99,7 +123,7 @@ int cafehip_set_error_model(cafehip_ctx *ctx, int mfs, const double *errormatrix
  * max_post[F].
  * The first ~20-25 evaluations after a table / tree / error model is set run different launch shapes of the
  * pruning kernel while the library times them and keeps the fastest; every shape returns bit-identical values,
- * so those evaluations are ordinary ones (CAFEHIP_K2TUNE=0 disables the measurement). */
+ * so those evaluations are ordinary ones (option k2tune=0 disables the measurement). */
 int cafehip_eval_posterior(cafehip_ctx *ctx, const double *node_lambda, const double *node_mu,
                            const double *prior, double *score, int32_t *first_zero_family,
                            double *max_lik, int32_t *argmax_root, double *max_post);
@@ -135,7 +159,7 @@ int cafehip_launch_info(cafehip_ctx *ctx, int *k2_workgroups, int *compute_units
  * roofline accounting: `walk` = the family walk (one product per internal child edge of the walked tree and family
  * slot), `tables` = the factor tables of compressed subtrees (families that agree on the counts below a node share
  * its vector; the library builds the product with the node's edge matrix once per distinct state -- bit-identical
- * values, less work; CAFEHIP_COMPRESS=0 disables).  No reference counterpart. */
+ * values, less work; option compress=0 disables).  No reference counterpart. */
 int cafehip_last_issued_flops(cafehip_ctx *ctx, double *walk, double *tables);
 
 /* Same evaluation, but nothing is copied back and nothing synchronises: the

@@ -39,9 +39,11 @@ int cafehost_run_script(cafehost_session *s, const char *path);
 /* ---- multi-GPU (one process per GPU) ------------------------------------------------------------
  * Every rank runs the same script (same seed => same Nelder-Mead decisions); a rank scores only its
  * chunk-aligned block of the family table and the ranks exchange the per-chunk partial sums once per
- * objective call.  The collective itself stays outside this library (RCCL through torch.distributed
- * in cafe_amd/multi_gpu.py): the driver fills the caller's device buffers asynchronously and then calls
- * `exchange`, which must return the global score and set *first_zero_global (< 0 if none). */
+ * objective call.  Two ways to provide that exchange: the native communicator below (cafehost_init_comm: RCCL
+ * behind this ABI, nothing for the caller to do), or -- for a caller that already owns a process group, e.g.
+ * torch.distributed in cafe_amd/multi_gpu.py -- a callback: the driver fills the caller's device buffers
+ * asynchronously and then calls `exchange`, which must return the global score and set *first_zero_global
+ * (< 0 if none). */
 typedef double (*cafehost_exchange_fn)(void *user, int *first_zero_global);
 int cafehost_set_shard(cafehost_session *s, int rank, int world);
 int cafehost_shard_bounds(cafehost_session *s, int *lo, int *hi, int *n_chunks_local);
@@ -89,11 +91,17 @@ int cafehost_num_evaluations(cafehost_session *s);                  /* objective
 double cafehost_search_seconds(cafehost_session *s);                /* wall-clock of the last search */
 double cafehost_poisson_lambda(cafehost_session *s);
 
+/* Run-time switches: "speculate" (auto|0|1: batched candidate evaluation, below), "timing" (0|1: phase times of
+ * report / the Monte-Carlo null on stderr); every other key is handed to cafehip_set_option on the session's device
+ * context(s) (include/cafehip.h).  CAFEHOST_SPECULATE / CAFEHOST_TIMING in the environment are read once, by
+ * cafehost_create. */
+int cafehost_set_option(cafehost_session *s, const char *key, const char *value);
+
 /* Batched candidate evaluation of the searches: passes launched, points evaluated in them, and how
  * many objective calls took their value from such a pass.  A table that fills less than half of the chip has the
  * four candidates of every Nelder-Mead iteration (and the points of a `lambda -r` grid) evaluated together through
  * cafehip_eval_posterior_multi; trajectories and log lines are those of the sequential run.
- * CAFEHOST_SPECULATE=0 / 1 forces it off / on. */
+ * Option speculate=0 / 1 forces it off / on. */
 int cafehost_speculation_stats(cafehost_session *s, long *launches, long *points, long *hits);
 
 /* Trace of the last command's objective calls: row i = (params[0..num_params), score).

@@ -24,10 +24,10 @@ def _table(F, n, seed, top=9):
 
 def _run(compress, counts, t, rng_tuple, lam, mu, prior, err=None, sets=None, err_leaves=None):
     import cafe_amd
-    os.environ["CAFEHIP_COMPRESS"] = "1" if compress else "0"
-    try:
+    if True:
         eng = cafe_amd.Engine(0)
         try:
+            eng.set_option("compress", 1 if compress else 0)
             eng.set_tree(t.parent, t.left, t.right, t.branchlength)
             eng.set_families(counts, cafe_amd.FamilySizeRange(*rng_tuple))
             if err is not None:
@@ -39,8 +39,6 @@ def _run(compress, counts, t, rng_tuple, lam, mu, prior, err=None, sets=None, er
             return out, eng.describe(), eng.last_issued_flops()
         finally:
             eng.close()
-    finally:
-        os.environ.pop("CAFEHIP_COMPRESS", None)
 
 
 @pytest.mark.parametrize("model", ["lambda", "lambdamu"])
@@ -147,10 +145,10 @@ def test_plan_follows_tables_trees_and_error_models_through_one_context():
     ]
 
     def session(compress):
-        os.environ["CAFEHIP_COMPRESS"] = "1" if compress else "0"
         out = []
-        try:
+        if True:
             eng = cafe_amd.Engine(0)
+            eng.set_option("compress", 1 if compress else 0)
             try:
                 cur = (None, None, None, None)
                 for ti, rows, seed, e, lam in steps:
@@ -166,8 +164,6 @@ def test_plan_follows_tables_trees_and_error_models_through_one_context():
                     out.append((r, "used=1" in eng.describe()))
             finally:
                 eng.close()
-        finally:
-            os.environ.pop("CAFEHIP_COMPRESS", None)
         return out
 
     a, b = session(True), session(False)

@@ -125,7 +125,7 @@ def test_chunk_aligned_shards_combine_bit_exactly(problem):
 
 def test_unfolded_error_model_equals_the_folded_one(problem):
     # the objective path folds the error model into the matrices once per evaluation (k1e_fold_error); with
-    # CAFEHIP_ERRFOLD=0 every family sums its band itself (cafe/cafe_tree.c:196-203 then :213-224): the two
+    # option errfold=0 every family sums its band itself (cafe/cafe_tree.c:196-203 then :213-224): the two
     # must agree to rounding on a block of the table
     p = problem
     if p["err"] is None:
@@ -133,11 +133,11 @@ def test_unfolded_error_model_equals_the_folded_one(problem):
     sub = p["counts"][:4096]
     p["eng"].set_families(sub, p["fr"])
     folded = p["eng"].get_posterior(p["lam"], p["mu"], p["prior"], per_family=True)
-    os.environ["CAFEHIP_ERRFOLD"] = "0"
+    p["eng"].set_option("errfold", 0)
     try:
         unfolded = p["eng"].get_posterior(p["lam"], p["mu"], p["prior"], per_family=True)
     finally:
-        del os.environ["CAFEHIP_ERRFOLD"]
+        p["eng"].set_option("errfold", 1)
         p["eng"].set_families(p["counts"], p["fr"])
     assert np.max(np.abs(folded[2] - unfolded[2]) / unfolded[2]) < 1e-12
     assert np.array_equal(folded[3], unfolded[3])

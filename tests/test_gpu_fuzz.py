@@ -80,15 +80,14 @@ def test_random_shapes(case, kernel):
         lam = base * (0.5 + rs.rand(t.n_nodes))
         mu = np.where(rs.rand(t.n_nodes) < 0.5, -1.0, base * 0.7)
         mu = np.full(t.n_nodes, -1.0) if rs.rand() < 0.5 else np.abs(mu)
-    os.environ["CAFEHIP_K2"] = kernel
     eng = cafe_amd.Engine(0)
     try:
+        eng.set_option("k2", kernel)
         eng.set_tree(t.parent, t.left, t.right, t.branchlength)
         eng.set_families(counts, cafe_amd.FamilySizeRange(mn, mx, rmin, rmax))
         sg, fzg, mlg, amg, mpg = eng.get_posterior(lam, mu, prior, per_family=True)
         desc = eng.describe()
     finally:
-        os.environ.pop("CAFEHIP_K2", None)
         eng.close()
     assert ("k2:" + kernel) in desc
     so, fzo, mlo, amo, mpo = O.eval_posterior(t, counts, rng, lam, mu, prior, nthreads=os.cpu_count() or 1)
@@ -109,9 +108,7 @@ def test_k_loop_phases_and_tiny_matrices(shape):
     import cafe_amd
     t = O.PyTree("((a:7,b:11):5,(c:3,(d:9,e:2):6):4)")
     rs = np.random.RandomState(4242)
-    os.environ["CAFEHIP_MFMA"] = shape
-    os.environ["CAFEHIP_K2"] = "mfma"
-    try:
+    if True:
         for mx in list(range(3, 27)):
             rmax = max(2, mx - 1)
             F = 37
@@ -124,6 +121,8 @@ def test_k_loop_phases_and_tiny_matrices(shape):
             mu = np.full(t.n_nodes, 0.02 if mx % 2 else -1.0)
             eng = cafe_amd.Engine(0)
             try:
+                eng.set_option("mfma", shape)
+                eng.set_option("k2", "mfma")
                 eng.set_tree(t.parent, t.left, t.right, t.branchlength)
                 eng.set_families(counts, cafe_amd.FamilySizeRange(0, mx, 1, rmax))
                 sg, fzg, mlg, amg, mpg = eng.get_posterior(lam, mu, prior, per_family=True)
@@ -138,9 +137,6 @@ def test_k_loop_phases_and_tiny_matrices(shape):
             assert np.max(np.abs(mlg[nz] - mlo[nz]) / mlo[nz], initial=0) < 1e-9, (mx, desc)
             assert np.max(np.abs(mpg[nz] - mpo[nz]) / mpo[nz], initial=0) < 1e-9, (mx, desc)
             assert np.all((amg == amo) | ~nz), (mx, desc)
-    finally:
-        os.environ.pop("CAFEHIP_MFMA", None)
-        os.environ.pop("CAFEHIP_K2", None)
 
 
 @pytest.mark.parametrize("case", [2, 3, 4, 5, 8, 9, 11])
@@ -164,14 +160,13 @@ def test_random_shapes_with_compressed_subtrees(case):
     mu = np.full(t.n_nodes, base * 0.6 if model == "lambdamu" else -1.0)
     res = {}
     for comp in ("1", "0"):
-        os.environ["CAFEHIP_COMPRESS"] = comp
         eng = cafe_amd.Engine(0)
         try:
+            eng.set_option("compress", comp)
             eng.set_tree(t.parent, t.left, t.right, t.branchlength)
             eng.set_families(counts, cafe_amd.FamilySizeRange(mn, mx, rmin, rmax))
             res[comp] = (eng.get_posterior(lam, mu, prior, per_family=True), eng.describe())
         finally:
-            os.environ.pop("CAFEHIP_COMPRESS", None)
             eng.close()
     (sg, fzg, mlg, amg, mpg), desc = res["1"]
     (s0, fz0, ml0, am0, mp0), _ = res["0"]

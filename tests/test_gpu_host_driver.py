@@ -160,17 +160,13 @@ def test_report_does_not_depend_on_the_matrix_arithmetic_of_the_search(tmp_path,
     # The report phase (Monte-Carlo draws against cumulative row sums, cafe/cafe_tree.c:533-569; exact == / < in
     # viterbi_sum_probabilities, cafe/viterbi.cpp:60-67) builds ITS matrices in the reference's per-term arithmetic
     # whatever form the objective evaluations used: the golden test2 report and the example report must come out
-    # byte for byte under every CAFEHIP_K1 setting.  (Residual risk, documented in DESIGN.md: the device exp() is
+    # byte for byte under every setting of option k1.  (Residual risk, documented in DESIGN.md: the device exp() is
     # not glibc's; a 1-ulp difference in a term could still flip a comparison that is an exact tie in the reference.)
     from cafe_amd.shell import CafeShell
     g = TR["test2"]
-    old = os.environ.get("CAFEHIP_K1")
-    if k1:
-        os.environ["CAFEHIP_K1"] = k1
-    else:
-        os.environ.pop("CAFEHIP_K1", None)
-    try:
+    if True:
         sh = CafeShell(0, os.devnull)
+        sh.set_option("k1", k1 or "auto")
         out = str(tmp_path / "test2")
         for line in ("seed 10", "load -i %s -p 0.05 -max_size 20" % os.path.join(GOLD, "test2_families.txt"),
                      "tree " + g["newick"], "lambda -s", "report " + out):
@@ -181,17 +177,13 @@ def test_report_does_not_depend_on_the_matrix_arithmetic_of_the_search(tmp_path,
         assert got[:1] + got[2:] == exp[:1] + exp[2:]
         # the shipped example with a FIXED lambda (so that only the report's own arithmetic can differ)
         sh = CafeShell(0, os.devnull)
+        sh.set_option("k1", k1 or "auto")
         out2 = str(tmp_path / "example")
         for line in ("seed 10", "load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"),
                      "tree (((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)", "lambda -l 0.0017", "report " + out2):
             sh.dispatch(line)
         sh.close()
         text = open(out2 + ".cafe").read()
-    finally:
-        if old is None:
-            os.environ.pop("CAFEHIP_K1", None)
-        else:
-            os.environ["CAFEHIP_K1"] = old
     ref_path = os.path.join(str(tmp_path.parent), "example_report_reference.txt")
     if os.path.exists(ref_path):
         assert text == open(ref_path).read()

@@ -66,9 +66,9 @@ def test_multi_set_on_a_table_of_several_workgroups_with_error_model():
 
 def _search(lines, speculate):
     from cafe_amd.shell import CafeShell
-    os.environ["CAFEHOST_SPECULATE"] = "1" if speculate else "0"
-    try:
+    if True:
         sh = CafeShell(0, os.devnull)
+        sh.set_option("speculate", 1 if speculate else 0)
         t0 = time.perf_counter()
         for l in lines:
             sh.dispatch(l)
@@ -77,8 +77,6 @@ def _search(lines, speculate):
         stats = sh.speculation_stats()
         secs = sh.search_seconds
         sh.close()
-    finally:
-        del os.environ["CAFEHOST_SPECULATE"]
     return res, stats, secs, wall
 
 

@@ -82,7 +82,7 @@ def test_matrices_all_branches(eng):
     try:
         for mode, rtol in (("exact", MAT_RTOL), ("product", 5e-12)):
             # exact: the reference's per-term exp sequence; product: factored exponentials (default)
-            os.environ["CAFEHIP_K1"] = mode
+            eng.set_option("k1", "exact" if mode == "exact" else "auto")
             for lam, mu in cases:
                 eng.reset_birthdeath_cache(lam, mu)
                 for node in range(t.n_nodes):
@@ -99,7 +99,7 @@ def test_matrices_all_branches(eng):
                         assert np.all(np.abs(got[ref == 0]) < 1e-290) and np.all(ref[got == 0] < 1e-290)
                     assert got[0, 0] == 1 and np.all(got[0, 1:] == 0)
     finally:
-        os.environ.pop("CAFEHIP_K1", None)
+        eng.set_option("k1", "auto")
 
 
 def test_example_data_and_survey_pins(eng):
@@ -256,18 +256,18 @@ def test_error_model_leaves(eng):
         # (epsilon-filled, as `esterror` builds, cafe/cafe_shell.c:671-689) model
         check_families(eng, t, counts, rng, lam, mu, prior, errormatrix=E, err_mfs=mfs, leaf_has_err=has,
                        nthreads=os.cpu_count() or 1)
-        os.environ["CAFEHIP_ERRBAND"] = "0"
+        eng.set_option("errband", 0)
         eng.set_error_model(E, has)
         check_families(eng, t, counts, rng, lam, mu, prior, errormatrix=E, err_mfs=mfs, leaf_has_err=has,
                        nthreads=os.cpu_count() or 1)
-        os.environ.pop("CAFEHIP_ERRBAND")
+        eng.set_option("errband", 1)
         Ed = E + 1e-6
         Ed /= Ed.sum(axis=0, keepdims=True)
         eng.set_error_model(Ed, has)
         check_families(eng, t, counts, rng, lam, mu, prior, errormatrix=Ed, err_mfs=mfs, leaf_has_err=has,
                        nthreads=os.cpu_count() or 1)
     finally:
-        os.environ.pop("CAFEHIP_ERRBAND", None)
+        eng.set_option("errband", 1)
         eng.set_error_model(None)
 
 
@@ -325,10 +325,7 @@ def test_matrices_extreme_rates_all_k1_forms(eng, m):
     rates = [1e-14, 1e-10, 1e-7, 1e-5, 1e-3, 0.004, 0.0053, 0.005376, 0.00537634]   # 0.00537634 * 93 = 0.49999962
     try:
         for mode, rtol in (("", 5e-12), ("perterm", 5e-12), ("exact", MAT_RTOL)):
-            if mode:
-                os.environ["CAFEHIP_K1"] = mode
-            else:
-                os.environ.pop("CAFEHIP_K1", None)
+            eng.set_option("k1", mode or "auto")
             for lam_v in rates:
                 for mu_v in (-1.0, lam_v * 0.7):
                     lam = np.full(t.n_nodes, lam_v)
@@ -342,7 +339,7 @@ def test_matrices_extreme_rates_all_k1_forms(eng, m):
                         ok, worst = rel_close(got, ref, rtol, atol=1e-300)
                         assert ok, "K1=%s lambda %g mu %g node %d: worst rel err %g" % (mode or "blocked", lam_v, mu_v, node, worst)
     finally:
-        os.environ.pop("CAFEHIP_K1", None)
+        eng.set_option("k1", "auto")
 
 
 @pytest.mark.skipif(any(os.environ.get(k) for k in ("CAFEHIP_MFMA", "CAFEHIP_K2CFG", "CAFEHIP_K2CFG4", "CAFEHIP_K2")) or

@@ -53,7 +53,7 @@ def main():
         ks = []
         for _ in range(16):
             score, fz = eng.get_posterior(nl, nm, prior)
-            ks.append(eng.last_kernel_ms())
+            ks.append(eng.last_kernel_ms() + [eng.last_tables_ms()])
         eng.enable_timing(False)
         t0 = time.perf_counter()
         for _ in range(20):
@@ -61,8 +61,8 @@ def main():
         step = (time.perf_counter() - t0) / 20 * 1e3
         ks = np.array(ks)
         d = eng.describe()
-        print("%-5s F=%-7d k1 %.4f  k2 mean %.4f min %.4f  k3 %.4f  step %.4f ms  score %.9f  %s" % (
-            name, F, ks[:, 0].mean(), ks[:, 1].mean(), ks[:, 1].min(), ks[:, 2].mean(), step, score,
+        print("%-5s F=%-7d k1 %.4f  k2 mean %.4f min %.4f (tables %.4f)  k3 %.4f  step %.4f ms  score %.9f  %s" % (
+            name, F, ks[:, 0].mean(), ks[:, 1].mean(), ks[:, 1].min(), ks[:, 3].mean(), ks[:, 2].mean(), step, score,
             d[d.index("k2:"):]), flush=True)
         eng.close()
 
