@@ -22,6 +22,7 @@ SIGNATURES = {
     "cafehip_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "cafehip_set_tree": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _dp]),
     "cafehip_set_families": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "cafehip_last_setup_ms": (C.c_int, [C.c_void_p, _dp]),
     "cafehip_set_error_model": (C.c_int, [C.c_void_p, C.c_int, _dp, _u8p]),
     "cafehip_eval_posterior": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip, _dp, _ip, _dp]),
     "cafehip_eval_posterior_multi": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _ip]),
@@ -37,6 +38,13 @@ SIGNATURES = {
     "cafehip_set_exact_matrices": (C.c_int, [C.c_void_p, C.c_int]),
     "cafehip_eval_root_likelihoods": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip, _dp]),
     "cafehip_viterbi": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip, _ip]),
+    "cafehip_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "cafehip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "cafehip_comm_set_blocks": (C.c_int, [C.c_void_p, _ip, _ip]),
+    "cafehip_eval_posterior_sharded": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip]),
+    "cafehip_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "cafehip_comm_host_selftest": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "cafehip_comm_info": (C.c_int, [C.c_void_p, _ip, _ip, _ip, _dp, _dp, C.POINTER(C.c_long)]),
     "cafehip_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cafehip_fetch_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "cafehip_last_kernel_ms": (C.c_int, [C.c_void_p, _dp]),

@@ -14,7 +14,7 @@ LIB = os.path.join(LIBDIR, "libcafehip.so")
 # translation units of libcafehip.so: compiled in parallel into cafe_amd/lib/obj/, relinked when any object changes
 SOURCES = ["cafehip.hip", "k1_matrices.hip", "k2_walk16.hip", "k2_walk4.hip", "k2c_tables.hip", "k_misc.hip",
            os.path.join("host", "cafe_host.cpp")]
-HEADERS = ["device_types.hpp", "kernels.hpp", "k2_mfma.hpp", "host_math.hpp", "schedule.hpp",
+HEADERS = ["device_types.hpp", "kernels.hpp", "comm.hpp", "k2_mfma.hpp", "host_math.hpp", "schedule.hpp",
            os.path.join("..", "..", "include", "cafehip.h"), os.path.join("..", "..", "include", "cafehost.h")]
 OBJDIR = os.path.join(LIBDIR, "obj")
 PROBE_LIB = os.path.join(LIBDIR, "libcafeprobe.so")   # measured HBM / MFMA ceilings for bench.py (csrc/probe.hip)

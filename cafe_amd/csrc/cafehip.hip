@@ -35,9 +35,37 @@
 
 #include "../../include/cafehip.h"
 #include "host_math.hpp"
+#include "comm.hpp"
 #include "kernels.hpp"
 
 using namespace cafehip;
+
+// Debug aid (CAFEHIP_POISON=1 in the environment when the library is loaded): every device allocation is filled with
+// 0xFF bytes -- NaN as a double, -1 as an int -- before anything else touches it and sits between two 64 KiB guard
+// zones of the same bytes, so that a read of memory the library never wrote, or a little outside a buffer, shows up
+// in the outputs instead of depending on what the allocator handed back.
+static const bool g_poison = getenv("CAFEHIP_POISON") != nullptr;
+constexpr size_t kPoisonGuard = 64 * 1024;
+template <class T>
+static hipError_t poison_malloc(T** p, size_t bytes)
+{
+    if (!g_poison) return hipMalloc(reinterpret_cast<void**>(p), bytes);
+    char* raw = nullptr;
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&raw), bytes + 2 * kPoisonGuard);
+    if (e != hipSuccess) return e;
+    (void)hipMemset(raw, 0xFF, bytes + 2 * kPoisonGuard);
+    (void)hipDeviceSynchronize();
+    *p = reinterpret_cast<T*>(raw + kPoisonGuard);
+    return hipSuccess;
+}
+template <class T>
+static hipError_t poison_free(T* p)
+{
+    if (!g_poison || !p) return hipFree(const_cast<void*>(static_cast<const volatile void*>(p)));
+    return hipFree(reinterpret_cast<char*>(const_cast<void*>(static_cast<const volatile void*>(p))) - kPoisonGuard);
+}
+#define hipMalloc(p, n) poison_malloc(p, n)
+#define hipFree(p) poison_free(p)
 
 namespace {
 
@@ -148,7 +176,7 @@ struct cafehip_ctx {
         int k2slots = 1;              // park scratch by resident workgroup (0: one region per family tile)
         int ldspark = -1;             // park buffers kept in LDS (< 0: by residency)
         int vitlds = 0;               // Viterbi argmax tables in LDS
-        int k2c_prefetch = 0;         // k2c_nodes: k-steps of the matrix operand requested up front (0: the walk's short ring, -1: that + batched gathers)
+        int k2c_batch = 1;            // k2c_nodes: the child columns of a state gathered in one batch (round 3)
         int batch_trim = 1;           // batch mode: a tile's products stop at its largest column limit (round 3)
     } opt;
     bool walk_compressed = false;           // the MFMA launcher walks the reduced tree (set around one launch)
@@ -200,7 +228,8 @@ struct cafehip_ctx {
     int key_cap = 0;                          // KeyParam slots of a ring block: kMaxSets x (n_nodes - 1)
     size_t ring_bytes = 0;
     const EvalHeader* cur_params = nullptr;   // staged block the next K1 launch reads
-    int cur_slot = 0, cur_sets = 1;
+    int cur_slot = 0, cur_sets = 1, cur_prior_n = 0;
+    bool prior_on_device = false;             // d_prior / d_logprior hold prior_seen
     int32_t* d_node_key = nullptr;            // [kMaxSets][n_nodes] mirror of the staged node -> matrix map (K1 writes it)
     double *d_prior = nullptr, *d_logprior = nullptr;   // [kMaxPrior] the prior of the evaluations and its logarithms
     std::vector<int> node_key;
@@ -246,6 +275,22 @@ struct cafehip_ctx {
         hipEvent_t e0 = nullptr, e1 = nullptr;
     } tune;
     std::string desc;
+
+    // multi-GPU: one process per GPU of a node (comm.hpp).  Set by cafehip_comm_init / cafehip_comm_set_blocks.
+    CommLink* link = nullptr;
+    int comm_mode = 0;                          // option "comm": 0 auto (direct when every rank mapped every buffer), 1 rccl, 2 direct
+    std::vector<int32_t> blk_lo, blk_hi;        // every rank's block [lo, hi) of the global table
+    int x_slots = 0;                            // chunk slots of a rank's packed row
+    unsigned long long x_seq = 0;               // exchange sequence number (direct mode), never reused
+    double *d_packed = nullptr, *d_gathered = nullptr;   // RCCL mode: [slots + 1] and [world][slots + 1]
+    int packed_slots = 0;
+    hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;
+    bool ev_x_pending = false;
+    double last_exchange_ms = 0;                // RCCL mode with timing on: all-gather + result pick-up, events on the stream
+    double x_host_seconds = 0;                  // host time inside the exchange step (RCCL mode: launch + pick-up)
+    long x_calls = 0;
+    int x_mode_used = 0;                        // exchange mode of the last sharded evaluation (1 rccl, 2 direct)
+    double setup_ms[4] = {0, 0, 0, 0};          // last cafehip_set_families: row dedup, compression plan, uploads + allocation, total
 #ifdef CAFE_K2_STAMPS
     unsigned long long* d_stamps = nullptr;   // debug timeline of the last K2 launch (tools/k2_stamps.py)
     size_t stamps_cap = 0;
@@ -332,7 +377,9 @@ int ensure_param_ring(cafehip_ctx* c)
     hipFree(c->d_node_key);
     c->d_node_key = nullptr;
     HIP_TRY(hipMalloc(&c->d_node_key, (size_t)kMaxSets * c->n_nodes * sizeof(int32_t)));
-    HIP_TRY(hipMemset(c->d_node_key, 0, (size_t)kMaxSets * c->n_nodes * sizeof(int32_t)));
+    // (ordered on the context's stream, where K1 will write the map: a null-stream memset is not ordered with a
+    // non-blocking stream and could land AFTER the first evaluation's K1)
+    HIP_TRY(hipMemsetAsync(c->d_node_key, 0, (size_t)kMaxSets * c->n_nodes * sizeof(int32_t), c->stream));
     c->key_cap = key_cap;
     c->ring_bytes = bytes;
     return 0;
@@ -408,15 +455,20 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
         if (keys[k].mode >= 2 && !keys[k].fast_ok) c->all_keys_fast = false;
     if (prior) {
         // compute_posterior adds log(prior[j]) (cafe/lambda.cpp:681); the log is taken on the host -- once per prior:
-        // a search hands over the same prior at every evaluation, and the device copy is refreshed only when it
-        // changes (a pageable source: the copy has left the vectors when the call returns)
-        if ((int)c->prior_seen.size() != c->R || memcmp(c->prior_seen.data(), prior, sizeof(double) * c->R) != 0) {
+        // a search hands over the same prior at every evaluation: the device copy is refreshed (by K1, from this block)
+        // only in an evaluation whose prior differs from the one on the device
+        c->cur_prior_n = 0;
+        if (!c->prior_on_device || (int)c->prior_seen.size() != c->R || memcmp(c->prior_seen.data(), prior, sizeof(double) * c->R) != 0) {
             c->prior_seen.assign(prior, prior + c->R);
             c->logprior_seen.resize(c->R);
             for (int j = 0; j < c->R; ++j) c->logprior_seen[j] = std::log(prior[j]);
-            HIP_TRY(hipMemcpyAsync(c->d_prior, c->prior_seen.data(), sizeof(double) * c->R, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->d_logprior, c->logprior_seen.data(), sizeof(double) * c->R, hipMemcpyHostToDevice, c->stream));
+            double* hp = const_cast<double*>(eval_prior(h, eval_prior_offset(c->key_cap, c->n_nodes)));
+            memcpy(hp, c->prior_seen.data(), sizeof(double) * c->R);
+            memcpy(hp + kMaxPrior, c->logprior_seen.data(), sizeof(double) * c->R);
+            c->cur_prior_n = c->R;
         }
+    } else {
+        c->cur_prior_n = 0;
     }
     if (ensure_matrix_storage(c, (size_t)nk)) return -1;
     c->cur_params = h;
@@ -467,6 +519,12 @@ int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr, bool defer_ring_e
     a.n_sets = c->cur_sets;
     a.nkeys = c->nkeys;
     a.key_cap = c->key_cap;
+    a.n_prior = c->cur_prior_n;
+    a.prior_offset = eval_prior_offset(c->key_cap, c->n_nodes);
+    a.prior_dev = c->d_prior;
+    a.logprior_dev = c->d_logprior;
+    if (c->cur_prior_n > 0) c->prior_on_device = true;
+    c->cur_prior_n = 0;   // (this launch mirrors it)
     dim3 grid((c->S + 15) / 16, (c->S + 15) / 16, (c->nkeys + kpb - 1) / kpb);
     size_t lds = 2 * 16 * (size_t)c->lnc.ld * sizeof(double);
     const bool use_lds = lds <= 150 * 1024;  // bigger tables are read through L1/L2 instead
@@ -795,12 +853,7 @@ int launch_compressed_levels(cafehip_ctx* c, int n_sets)
         a.tiles = p.d_tiles + first;
         const int nft = p.level_nft[l];
         slots += (double)n_tiles * nft;
-        // one row tile per wave: the wave's whole matrix operand is requested up front (all of it up to 40 k-steps,
-        // a 32-deep ring up to 64); option k2c_prefetch=0 keeps the short ring of round 2 (A/B runs)
-        int kpf = (nft == 1 && nrt_w == 1 && a.ksteps <= 64) ? c->opt.k2c_prefetch : 0;
-        if (kpf == 40 && a.ksteps > 40) kpf = 32;
-        const int kmax = kpf == 40 ? 40 : (kpf > 0 ? 64 : 0);
-        if (launch_k2c_inst(c, k2c_kernel(nft, nrt_w, kpf, kmax), nft, a, n_tiles, n_sets, 64 * wr)) return -1;
+        if (launch_k2c_inst(c, k2c_kernel(nft, nrt_w, c->opt.k2c_batch != 0), nft, a, n_tiles, n_sets, 64 * wr)) return -1;
     }
     const double kpad = 4.0 * ((c->C + 3) / 4), rows = 16.0 * ((c->C + 15) / 16);
     c->issued_tables = 2.0 * kpad * rows * 16.0 * slots * n_sets;
@@ -1369,7 +1422,8 @@ int ensure_output_sets(cafehip_ctx* c, int n_sets)
 }
 
 int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu,
-                const double* prior, double* d_chunk_sums, int32_t* d_first_zero, bool host_out = false, int n_sets = 1)
+                const double* prior, double* d_chunk_sums, int32_t* d_first_zero, bool host_out = false, int n_sets = 1,
+                bool direct_exchange = false)
 {
     if (check_ready(c)) return -1;
     HIP_TRY(hipSetDevice(c->device));
@@ -1415,7 +1469,33 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
         c->last_compressed = use_c && c->k2_used_mfma;
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    if (c->n_chunks > 0) {
+    if (direct_exchange) {
+        // sharded evaluation, direct exchange: the score kernel stores this rank's packed row into every rank's
+        // exchange buffer and hands all rows to the host (k3_score_x)
+        CommLink& L = *c->link;
+        K3xArgs x;
+        memset(&x, 0, sizeof x);
+        x.max_post_u = c->d_max_post;
+        x.max_lik_u = c->d_max_lik;
+        x.fam2u = c->d_fam2u;
+        x.F = c->F;
+        x.Fu = c->Fu;
+        x.first_zero = d_first_zero;
+        x.host = c->h_result;
+        x.arrive = c->d_arrive;
+        x.seq = ++c->host_seq;
+        x.rank = L.rank;
+        x.world = L.world;
+        x.slots = c->x_slots;
+        x.xseq = ++c->x_seq;
+        const int parity = (int)(x.xseq & 1);
+        for (int r = 0; r < L.world; ++r) {
+            x.rows[r] = CommLink::rows_of(L.peer_xbuf[r], parity);
+            x.flags[r] = reinterpret_cast<unsigned long long*>(CommLink::flags_of(L.peer_xbuf[r], parity));
+        }
+        x.timeout_ticks = 30LL * 100000000LL;   // 30 s of the 100 MHz wall clock: a rank that died must not hang the others' GPUs
+        if (launch_kernel(k3x_kernel(), dim3(std::max(c->n_chunks, 1)), dim3(CAFEHIP_CHUNK), 0, c->stream, x)) return -1;
+    } else if (c->n_chunks > 0) {
         K3Args k3{c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, c->Fu, d_chunk_sums, d_first_zero, nullptr, nullptr, 0};
         if (host_out) {
             k3.host = c->h_result;
@@ -1456,8 +1536,8 @@ int collect_kernel_ms(cafehip_ctx* c)
 // (name, what it selects) -- cafehip_set_option; the same names upper-cased behind CAFEHIP_ are read from the
 // environment ONCE, when the context is created (tools/ sweeps), never during an evaluation
 const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
-                                    "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_prefetch",
-                                    "batch_trim"};
+                                    "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch",
+                                    "batch_trim", "comm"};
 
 int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
 {
@@ -1500,8 +1580,15 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     else if (key == "k2slots") o.k2slots = iv != 0;
     else if (key == "ldspark") o.ldspark = val.empty() ? -1 : iv;
     else if (key == "vitlds") o.vitlds = iv != 0;
-    else if (key == "k2c_prefetch") o.k2c_prefetch = iv;
+    else if (key == "k2c_batch") o.k2c_batch = iv != 0;
     else if (key == "batch_trim") o.batch_trim = iv != 0;
+    else if (key == "comm") {
+        if (val == "rccl") c->comm_mode = 1;
+        else if (val == "direct") c->comm_mode = 2;
+        else if (val.empty() || val == "auto") c->comm_mode = 0;
+        else return fail("option comm: auto | direct | rccl, got '%s'", val.c_str());
+        return 0;
+    }
     else return fail("unknown option '%s'", key.c_str());
     c->tune.n_items = -1;   // the wave grid is measured again under the new switches
     if (replan && c->M >= 0 && c->n_nodes > 0) {
@@ -1587,6 +1674,11 @@ void cafehip_destroy(cafehip_ctx* c)
     hipStreamSynchronize(c->stream);
     free_family_buffers(c);
     free_compression(c);
+    delete c->link;
+    hipFree(c->d_packed);
+    hipFree(c->d_gathered);
+    if (c->ev_x0) hipEventDestroy(c->ev_x0);
+    if (c->ev_x1) hipEventDestroy(c->ev_x1);
     hipFree(c->d_ops);
     hipFree(c->d_mops);
     hipFree(c->d_park);
@@ -1737,6 +1829,8 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
     if (R > kMaxPrior) return fail("root range %d exceeds FAMILYSIZEMAX %d", R, kMaxPrior);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const auto t_setup0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     // the reference asserts 0 <= familysize < size_of_factor (cafe/cafe_tree.c:207)
     const int sof = std::max(R, range_max + 1);
     for (size_t i = 0; i < (size_t)F * n_leaves; ++i)
@@ -1776,6 +1870,8 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
         }
     }
     const int Fu = (int)uniq_rows.size();
+    c->setup_ms[0] = ms_since(t_setup0);
+    const auto t_setup1 = std::chrono::steady_clock::now();
     std::vector<int32_t> ucounts((size_t)std::max(Fu, 1) * n_leaves, 0);
     for (int u = 0; u < Fu; ++u)
         memcpy(&ucounts[(size_t)u * n_leaves], counts + (size_t)uniq_rows[u] * n_leaves, sizeof(int32_t) * n_leaves);
@@ -1845,7 +1941,18 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
         c->have_matrices = false;
     }
     if (c->n_nodes > 0 && ensure_matrix_storage(c)) return -1;
+    c->setup_ms[2] = ms_since(t_setup1);
+    const auto t_setup2 = std::chrono::steady_clock::now();
     if (rebuild_compression(c)) return -1;
+    c->setup_ms[1] = ms_since(t_setup2);
+    c->setup_ms[3] = ms_since(t_setup0);
+    return 0;
+}
+
+int cafehip_last_setup_ms(cafehip_ctx* c, double ms[4])
+{
+    if (!c || !ms) return fail("null argument");
+    for (int i = 0; i < 4; ++i) ms[i] = c->setup_ms[i];
     return 0;
 }
 
@@ -2342,6 +2449,238 @@ int cafehip_fetch_small(cafehip_ctx* c, const void* d_src, size_t nbytes, const 
     std::atomic_thread_fence(std::memory_order_acquire);  // payload reads stay behind the flag read
     *host_ptr = c->h_fetch + 1;
     return 0;
+}
+
+// ---- multi-GPU exchange behind the ABI (comm.hpp) ---------------------------------------------------------------
+int cafehip_comm_unique_id(void* out_id)
+{
+    if (!out_id) return fail("null argument");
+    FILE* f = fopen("/dev/urandom", "rb");
+    const size_t got = f ? fread(out_id, 1, CAFEHIP_COMM_ID_BYTES, f) : 0;
+    if (f) fclose(f);
+    if (got != CAFEHIP_COMM_ID_BYTES) {
+        // no entropy source: time and pid are unique enough for a rendezvous name on one node
+        unsigned long long v[CAFEHIP_COMM_ID_BYTES / 8];
+        const unsigned long long t = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+        for (size_t i = 0; i < CAFEHIP_COMM_ID_BYTES / 8; ++i) v[i] = t * (2 * i + 1) ^ ((unsigned long long)getpid() << 17) ^ (i * 0x9E3779B97F4A7C15ull);
+        memcpy(out_id, v, CAFEHIP_COMM_ID_BYTES);
+    }
+    return 0;
+}
+
+int cafehip_comm_init(cafehip_ctx* c, int rank, int world, const void* unique_id)
+{
+    if (!c || !unique_id) return fail("null argument");
+    if (c->link) return fail("this context already belongs to a communicator");
+    HIP_TRY(hipSetDevice(c->device));
+    CommLink* L = new CommLink();
+    if (!L->init(c->device, rank, world, unique_id)) {
+        const std::string msg = L->error;
+        delete L;
+        return fail("communicator: %s", msg.c_str());
+    }
+    c->link = L;
+    c->blk_lo.clear();
+    c->blk_hi.clear();
+    return 0;
+}
+
+// exchange mode a sharded evaluation will use: 2 direct (peer buffers mapped on every rank) unless RCCL was asked for
+static int comm_pick_mode(cafehip_ctx* c)
+{
+    if (c->comm_mode == 1) return 1;
+    if (c->link->p2p_ok) return 2;
+    return c->comm_mode == 2 ? -1 : 1;
+}
+
+int cafehip_comm_set_blocks(cafehip_ctx* c, const int32_t* block_lo, const int32_t* block_hi)
+{
+    if (!c || !block_lo || !block_hi) return fail("null argument");
+    if (!c->link) return fail("cafehip_comm_init has not been called");
+    CommLink& L = *c->link;
+    HIP_TRY(hipSetDevice(c->device));
+    int slots = 1;
+    for (int r = 0; r < L.world; ++r) {
+        if (block_hi[r] < block_lo[r] || (r > 0 && block_lo[r] != block_hi[r - 1]) ||
+            (block_lo[r] % CAFEHIP_CHUNK != 0 && block_hi[r] != block_lo[r]))   // (an empty block may sit at the table's ragged end)
+            return fail("rank %d: block [%d, %d) must be contiguous with its neighbour's and start on a multiple of %d", r, block_lo[r], block_hi[r], CAFEHIP_CHUNK);
+        slots = std::max(slots, (block_hi[r] - block_lo[r] + CAFEHIP_CHUNK - 1) / CAFEHIP_CHUNK);
+    }
+    if (block_hi[L.rank] - block_lo[L.rank] != c->F)
+        return fail("this rank's block holds %d families but its table has %d", block_hi[L.rank] - block_lo[L.rank], c->F);
+    if (slots > kCommSlotCap) return fail("%d chunks per rank exceed the exchange buffer (%d)", slots, kCommSlotCap);
+    c->blk_lo.assign(block_lo, block_lo + L.world);
+    c->blk_hi.assign(block_hi, block_hi + L.world);
+    c->x_slots = slots;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // host mirror: world rows of slots + 1 doubles
+    const size_t need = (size_t)L.world * (slots + 1);
+    if (!c->h_result || need > c->h_result_chunks) {
+        hipHostFree(c->h_result);
+        c->h_result = nullptr;
+        const size_t bytes = sizeof(HostResult) + need * sizeof(double);
+        HIP_TRY(hipHostMalloc((void**)&c->h_result, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+        memset((void*)c->h_result, 0, bytes);
+        c->h_result_chunks = need;
+        c->host_seq = 0;
+    }
+    // direct mode: rows of ranks with fewer chunks must read 0 in the slots they never write.  Everybody is between
+    // evaluations here (collective call): clear my buffer between two barriers
+    if (!L.barrier()) return fail("communicator: %s", L.error.c_str());
+    if (L.xbuf) {
+        HIP_TRY(hipMemset(L.xbuf, 0, L.xbuf_bytes));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    // RCCL mode buffers
+    if (slots != c->packed_slots || !c->d_packed) {
+        hipFree(c->d_packed);
+        hipFree(c->d_gathered);
+        c->d_packed = c->d_gathered = nullptr;
+        HIP_TRY(hipMalloc(&c->d_packed, (size_t)(slots + 1) * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_gathered, need * sizeof(double)));
+        c->packed_slots = slots;
+    }
+    HIP_TRY(hipMemset(c->d_packed, 0, (size_t)(slots + 1) * sizeof(double)));   // unused chunk slots read 0 on every rank
+    HIP_TRY(hipDeviceSynchronize());
+    if (!L.barrier()) return fail("communicator: %s", L.error.c_str());
+    return 0;
+}
+
+static int wait_host_seq(cafehip_ctx* c, int32_t want, bool* peer_timeout)
+{
+    // spin on the sequence number the last score block publishes (a few microseconds after the kernel ends); fall
+    // back to a stream query now and then so that a faulted launch cannot hang us
+    unsigned long spins = 0;
+    if (peer_timeout) *peer_timeout = false;
+    for (;;) {
+        const int32_t seen = c->h_result->done_seq;
+        if (seen == want) break;
+        if (peer_timeout && seen == -want) {
+            *peer_timeout = true;
+            break;
+        }
+        if ((++spins & 0x3FFFF) == 0) {
+            hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) {
+                if (c->h_result->done_seq != want && !(peer_timeout && c->h_result->done_seq == -want)) HIP_TRY(hipStreamSynchronize(c->stream));
+                const int32_t now = c->h_result->done_seq;
+                if (peer_timeout && now == -want) *peer_timeout = true;
+                else if (now != want) return fail("score kernel finished without publishing its result");
+                break;
+            }
+            if (q != hipErrorNotReady) return fail("stream error while waiting: %s", hipGetErrorString(q));
+        }
+    }
+    // the payload was written before the sequence number (device-side system fence): order our reads after the flag read
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
+
+int cafehip_eval_posterior_sharded(cafehip_ctx* c, const double* node_lambda, const double* node_mu, const double* prior,
+                                   double* score, int32_t* first_zero_global)
+{
+    if (!c) return fail("null context");
+    if (!node_lambda || !node_mu || !prior || !score) return fail("null argument");
+    if (!c->link || c->blk_lo.empty()) return fail("cafehip_comm_init / cafehip_comm_set_blocks have not been called");
+    if (c->d_err && c->err_mfs < c->range_max)
+        return fail("error model covers sizes 0..%d but range_max is %d", c->err_mfs, c->range_max);
+    CommLink& L = *c->link;
+    if (c->blk_hi[L.rank] - c->blk_lo[L.rank] != c->F) return fail("the table changed: call cafehip_comm_set_blocks again");
+    const int mode = comm_pick_mode(c);
+    if (mode < 0) return fail("direct exchange asked for but the peer buffers could not be mapped on every rank");
+    const int slots = c->x_slots, row_len = slots + 1;
+    const double* rows = nullptr;
+    if (mode == 2) {
+        if (eval_device(c, node_lambda, node_mu, prior, nullptr, c->d_first_zero, true, 1, true)) return -1;
+        bool peer_timeout = false;
+        if (wait_host_seq(c, c->host_seq, &peer_timeout)) return -1;
+        if (peer_timeout) return fail("direct exchange: a rank did not deliver its row within 30 s");
+        rows = c->h_result->chunk_sums;
+    } else {
+        if (!L.rccl && !L.ensure_rccl()) return fail("RCCL exchange: %s", L.error.c_str());
+        int32_t* d_fz = reinterpret_cast<int32_t*>(c->d_packed + slots);
+        if (eval_device(c, node_lambda, node_mu, prior, c->d_packed, d_fz)) return -1;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (c->timing) {
+            if (!c->ev_x0) {
+                HIP_TRY(hipEventCreate(&c->ev_x0));
+                HIP_TRY(hipEventCreate(&c->ev_x1));
+            }
+            HIP_TRY(hipEventRecord(c->ev_x0, c->stream));
+        }
+        // the one exchange step: ONE ncclAllGather of the packed rows on the context's stream, picked up without a
+        // copy command or a stream synchronisation
+        const int rc = rccl_api().AllGather(c->d_packed, c->d_gathered, (size_t)row_len, ncclDouble, L.rccl, c->stream);
+        if (rc != ncclSuccess) return fail("ncclAllGather: %s", rccl_api().GetErrorString(rc));
+        const void* host = nullptr;
+        if (cafehip_fetch_small(c, c->d_gathered, (size_t)row_len * L.world * sizeof(double), &host)) return -1;
+        if (c->timing) {
+            HIP_TRY(hipEventRecord(c->ev_x1, c->stream));
+            HIP_TRY(hipEventSynchronize(c->ev_x1));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev_x0, c->ev_x1));
+            c->last_exchange_ms = ms;
+        }
+        c->x_host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        rows = static_cast<const double*>(host);
+    }
+    ++c->x_calls;
+    c->x_mode_used = mode;
+    if (collect_kernel_ms(c)) return -1;
+    // the same fixed-order sum on every rank: chunk order == family order; empty slots add 0
+    double s = 0.0;
+    int fz = -1;
+    for (int r = 0; r < L.world; ++r) {
+        const double* row = rows + (size_t)r * row_len;
+        for (int k = 0; k < slots; ++k) s += row[k];
+        long long local;
+        if (mode == 2) {
+            memcpy(&local, row + slots, sizeof local);
+        } else {
+            int32_t l32;
+            memcpy(&l32, row + slots, sizeof l32);
+            local = l32;
+        }
+        if (local >= 0 && local < c->blk_hi[r] - c->blk_lo[r] && fz < 0) fz = c->blk_lo[r] + (int)local;
+    }
+    *score = fz >= 0 ? -INFINITY : s;   // cafe/lambda.cpp:753-760
+    if (first_zero_global) *first_zero_global = fz;
+    return 0;
+}
+
+int cafehip_comm_allgather(cafehip_ctx* c, const void* mine, size_t nbytes_mine, void* all, size_t nbytes_slot)
+{
+    if (!c || !all) return fail("null argument");
+    if (!c->link) return fail("cafehip_comm_init has not been called");
+    if (nbytes_mine > nbytes_slot) return fail("block of %zu bytes does not fit its %zu-byte slot", nbytes_mine, nbytes_slot);
+    if (!c->link->host_allgather(mine, nbytes_mine, all, nbytes_slot)) return fail("communicator: %s", c->link->error.c_str());
+    return 0;
+}
+
+int cafehip_comm_info(cafehip_ctx* c, int* rank, int* world, int* mode, double* exchange_ms, double* host_seconds, long* calls)
+{
+    if (!c) return fail("null context");
+    if (rank) *rank = c->link ? c->link->rank : 0;
+    if (world) *world = c->link ? c->link->world : 1;
+    if (mode) *mode = c->link ? (c->x_mode_used ? c->x_mode_used : std::max(comm_pick_mode(c), 0)) : 0;
+    if (exchange_ms) *exchange_ms = c->last_exchange_ms;
+    if (host_seconds) *host_seconds = c->x_host_seconds;
+    if (calls) *calls = c->x_calls;
+    return 0;
+}
+
+int cafehip_comm_host_selftest(int rank, int world, const void* unique_id, const void* mine, size_t nbytes_mine, void* all,
+                               size_t nbytes_slot)
+{
+    // the host half of the communicator alone (rendezvous, mailboxes, barrier, host all-gather): no context, no
+    // device needed -- exercised by the CPU test suite with several processes
+    if (!unique_id || !all) return fail("null argument");
+    CommLink L;
+    if (!L.init(-1, rank, world, unique_id)) return fail("communicator: %s", L.error.c_str());
+    for (int round = 0; round < 3; ++round)
+        if (!L.barrier()) return fail("communicator: %s", L.error.c_str());
+    if (!L.host_allgather(mine, nbytes_mine, all, nbytes_slot)) return fail("communicator: %s", L.error.c_str());
+    return L.barrier() ? 0 : fail("communicator: %s", L.error.c_str());
 }
 
 int cafehip_enable_timing(cafehip_ctx* c, int on)

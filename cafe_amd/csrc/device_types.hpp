@@ -30,7 +30,8 @@ struct KeyParam {
 
 // Per-evaluation parameter block in PINNED, device-mapped host memory (a ring of kParamRing): K1 reads its keys
 // straight from it and mirrors the node -> matrix map into device memory for the later launches.  Flat, sized by
-// the tree: [EvalHeader][KeyParam keys[key_cap]][int32 node_key[kMaxSets][n_nodes]]
+// the tree: [EvalHeader][KeyParam keys[key_cap]][int32 node_key[kMaxSets][n_nodes]][f64 prior[kMaxPrior]][f64 logprior[kMaxPrior]]
+// (the prior arrays are filled, and mirrored by K1, only in an evaluation whose prior differs from the previous one's)
 struct EvalHeader {
     int nkeys, n_sets, n_nodes, key_cap;
 };
@@ -41,10 +42,16 @@ __host__ __device__ inline const int32_t* eval_node_key(const EvalHeader* h, int
     return reinterpret_cast<const int32_t*>(eval_keys(h) + key_cap);
 }
 __host__ __device__ inline int32_t* eval_node_key(EvalHeader* h, int key_cap) { return reinterpret_cast<int32_t*>(eval_keys(h) + key_cap); }
-inline size_t eval_block_bytes(int key_cap, int n_nodes)
+inline size_t eval_prior_offset(int key_cap, int n_nodes)
 {
-    return sizeof(EvalHeader) + (size_t)key_cap * sizeof(KeyParam) + (size_t)kMaxSets * n_nodes * sizeof(int32_t);
+    const size_t o = sizeof(EvalHeader) + (size_t)key_cap * sizeof(KeyParam) + (size_t)kMaxSets * n_nodes * sizeof(int32_t);
+    return (o + 7) & ~(size_t)7;
 }
+__host__ __device__ inline const double* eval_prior(const EvalHeader* h, size_t prior_offset)
+{
+    return reinterpret_cast<const double*>(reinterpret_cast<const char*>(h) + prior_offset);
+}
+inline size_t eval_block_bytes(int key_cap, int n_nodes) { return eval_prior_offset(key_cap, n_nodes) + 2 * (size_t)kMaxPrior * sizeof(double); }
 
 // ---- K1 ------------------------------------------------------------------------------------------------------
 struct K1Args {
@@ -58,6 +65,11 @@ struct K1Args {
     int keys_per_block;
     int32_t* node_key_dev;       // mirror target [n_sets][n_nodes], or NULL
     int n_nodes, n_sets, nkeys, key_cap;
+    // the prior changed: block (0,0,0) also mirrors prior[n_prior] and logprior[n_prior] (n_prior = 0 otherwise)
+    int n_prior;
+    size_t prior_offset;         // of the two kMaxPrior-long arrays inside the pinned block
+    double* prior_dev;
+    double* logprior_dev;
 };
 
 struct FoldArgs {   // k1e_fold_error
@@ -183,6 +195,26 @@ struct K3Args {
     HostResult* host;
     int32_t* arrive;
     int32_t seq;
+};
+
+// Score kernel of a SHARDED evaluation with the direct exchange (comm.hpp): every block stores its chunk sum into
+// EVERY rank's exchange buffer (row of this rank), the last block adds the first-zero index, raises this rank's flag
+// in every buffer, waits for the other ranks' flags in its own and hands all rows to the host.
+constexpr int kXMaxWorld = 16;
+struct K3xArgs {
+    const double* max_post_u;
+    const double* max_lik_u;
+    const int32_t* fam2u;
+    int F, Fu;
+    int32_t* first_zero;        // device word, reset by K1
+    HostResult* host;           // rows land in host->chunk_sums[world][slots + 1]
+    int32_t* arrive;
+    int32_t seq;                // host-visible sequence number of this evaluation
+    int rank, world, slots;     // row of rank r: [slots chunk sums][first-zero index as int64 bits]
+    unsigned long long xseq;    // exchange sequence number (flags), never reused
+    double* rows[kXMaxWorld];               // rank r's buffer, this parity: [world][slots + 1]
+    unsigned long long* flags[kXMaxWorld];  // rank r's flags, this parity: [kXMaxWorld]
+    long long timeout_ticks;    // wall_clock64() ticks to wait for the peers before giving up (host sees -seq)
 };
 
 struct ClusterWeights {

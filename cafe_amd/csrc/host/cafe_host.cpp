@@ -552,44 +552,6 @@ struct CdfCache {
     }
 };
 
-// RCCL entry points, resolved when a session joins a communicator (cafehost_init_comm): the library is only
-// needed by multi-GPU runs, and a process that already holds a copy (e.g. torch's) binds to that one.
-struct RcclApi {
-    void* lib = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    std::string error;
-
-    bool load()
-    {
-        if (lib) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (lib) break;
-        }
-        if (!lib) {
-            error = std::string("cannot load librccl: ") + dlerror();
-            return false;
-        }
-        GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
-        CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
-        AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
-        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
-        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !GetErrorString) {
-            error = "librccl lacks an expected entry point";
-            dlclose(lib);
-            lib = nullptr;
-            return false;
-        }
-        return true;
-    }
-};
-RcclApi g_rccl;
-
 struct cafehost_session {
     cafehip_ctx* ctx = nullptr;
     cafehip_ctx* ctx_one = nullptr;  // one-family evaluations (lambda -e), created on first use
@@ -621,28 +583,18 @@ struct cafehost_session {
     int32_t* d_exch_fz = nullptr;
     cafehost_allgather_fn allgather = nullptr;  // report / Monte-Carlo null sharding
     void* allgather_user = nullptr;
-    // native communicator (cafehost_init_comm): RCCL all-gathers on the context's stream, no callbacks
-    ncclComm_t comm = nullptr;
+    // native communicator (cafehost_init_comm): the exchange lives behind the kernel library's ABI
+    // (cafehip_comm_*, include/cafehip.h); this session only tells it every rank's block of the table
     bool native_comm = false;
-    double *d_packed = nullptr, *d_gathered = nullptr;   // [slots + 1] and [(slots + 1) * world]
-    int comm_slots = 0;
-    std::vector<int> all_lo, all_hi;                      // every rank's block of the table
-    char* d_stage = nullptr;                              // report gathers: [slot] in + [slot * world] out
-    size_t stage_cap = 0;
-    double exchange_seconds = 0;
-    long exchange_calls = 0;
+    std::vector<int32_t> all_lo, all_hi;                  // every rank's block of the table
 
-    void rccl_check(ncclResult_t r, const char* what)
-    {
-        if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + g_rccl.GetErrorString(r));
-    }
     void hipapi_check(hipError_t e, const char* what)
     {
         if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
     }
 
-    // Exchange buffers for the table now on the device: every rank knows every rank's block (same rule, same F),
-    // so nothing is communicated to size them.  Called by upload(): a `load` or `tree` re-wires automatically.
+    // Every rank knows every rank's block (same rule, same F), so nothing is communicated to size the exchange.
+    // Called by upload(): a `load` or `tree` re-wires automatically.
     void wire_native()
     {
         const int Fall = fam.F();
@@ -650,94 +602,30 @@ struct cafehost_session {
         const int base = n_chunks / shard_world, extra = n_chunks % shard_world;
         all_lo.assign(shard_world, 0);
         all_hi.assign(shard_world, 0);
-        int c0 = 0, slots = 1;
+        int c0 = 0;
         for (int r = 0; r < shard_world; ++r) {
             const int nc = base + (r < extra ? 1 : 0);
             all_lo[r] = std::min(c0 * CAFEHIP_CHUNK, Fall);
             all_hi[r] = std::min((c0 + nc) * CAFEHIP_CHUNK, Fall);
-            slots = std::max(slots, nc);
             c0 += nc;
         }
-        hipapi_check(hipSetDevice(device_id), "hipSetDevice");
-        if (slots != comm_slots || !d_packed) {
-            hipapi_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
-            hipFree(d_packed);
-            hipFree(d_gathered);
-            d_packed = d_gathered = nullptr;
-            hipapi_check(hipMalloc(&d_packed, (size_t)(slots + 1) * sizeof(double)), "hipMalloc(exchange)");
-            hipapi_check(hipMalloc(&d_gathered, (size_t)(slots + 1) * shard_world * sizeof(double)), "hipMalloc(exchange)");
-            comm_slots = slots;
-        }
-        // unused chunk slots must read 0 on every rank
-        hipapi_check(hipMemset(d_packed, 0, (size_t)(slots + 1) * sizeof(double)), "hipMemset(exchange)");
-        d_exch_chunks = d_packed;
-        d_exch_fz = reinterpret_cast<int32_t*>(d_packed + slots);
-        exchange = &cafehost_session::native_exchange;
-        exchange_user = this;
+        // (a rank whose block is empty still starts at a chunk boundary of the table's end)
+        for (int r = 1; r < shard_world; ++r)
+            if (all_lo[r] != all_hi[r - 1]) all_lo[r] = all_hi[r - 1];
+        hip_check(cafehip_comm_set_blocks(ctx, all_lo.data(), all_hi.data()));
         allgather = &cafehost_session::native_allgather;
         allgather_user = this;
     }
 
-    // The one exchange step of an objective evaluation (cafe/lambda.cpp:698-722 is a map + sum): ONE ncclAllGather
-    // of the packed (chunk sums, first-zero index) buffers on the context's stream, the result brought to the host
-    // by cafehip_fetch_small (no copy command, no stream synchronisation), then the fixed-order sum every rank
-    // repeats identically.
-    static double native_exchange(void* user, int* first_zero_global)
-    {
-        cafehost_session* s = static_cast<cafehost_session*>(user);
-        const auto t0 = std::chrono::steady_clock::now();
-        void* stream = nullptr;
-        s->hip_check(cafehip_get_stream(s->ctx, &stream));
-        const size_t n = (size_t)s->comm_slots + 1;
-        s->rccl_check(g_rccl.AllGather(s->d_packed, s->d_gathered, n, ncclDouble, s->comm, (hipStream_t)stream), "ncclAllGather");
-        const void* host = nullptr;
-        s->hip_check(cafehip_fetch_small(s->ctx, s->d_gathered, n * s->shard_world * sizeof(double), &host));
-        const double* rows = static_cast<const double*>(host);
-        double score = 0.0;
-        int fz = -1;
-        for (int r = 0; r < s->shard_world; ++r) {
-            const double* row = rows + (size_t)r * n;
-            for (int c = 0; c < s->comm_slots; ++c) score += row[c];   // chunk order == family order; empty slots add 0
-            int32_t local;
-            memcpy(&local, row + s->comm_slots, sizeof local);
-            if (local >= 0 && local < s->all_hi[r] - s->all_lo[r] && fz < 0) fz = s->all_lo[r] + local;
-        }
-        *first_zero_global = fz;
-        s->exchange_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        ++s->exchange_calls;
-        return score;
-    }
-
-    // report / Monte-Carlo null: fixed-slot all-gather of host blocks through a device staging buffer
+    // report / Monte-Carlo null: fixed-slot all-gather of host blocks
     static int native_allgather(void* user, const void* mine, long long nbytes_mine, void* all, long long nbytes_slot)
     {
         cafehost_session* s = static_cast<cafehost_session*>(user);
-        try {
-            void* stream = nullptr;
-            s->hip_check(cafehip_get_stream(s->ctx, &stream));
-            const size_t slot = (size_t)((nbytes_slot + 15) / 16 * 16);
-            const size_t need = slot * (s->shard_world + 1);
-            s->hipapi_check(hipSetDevice(s->device_id), "hipSetDevice");
-            if (need > s->stage_cap) {
-                s->hipapi_check(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
-                hipFree(s->d_stage);
-                s->d_stage = nullptr;
-                s->hipapi_check(hipMalloc(&s->d_stage, need), "hipMalloc(stage)");
-                s->stage_cap = need;
-            }
-            if (nbytes_mine)
-                s->hipapi_check(hipMemcpyAsync(s->d_stage, mine, (size_t)nbytes_mine, hipMemcpyHostToDevice, (hipStream_t)stream), "H2D");
-            s->rccl_check(g_rccl.AllGather(s->d_stage, s->d_stage + slot, slot, ncclChar, s->comm, (hipStream_t)stream), "ncclAllGather");
-            std::vector<char> tmp(slot * s->shard_world);
-            s->hipapi_check(hipMemcpyAsync(tmp.data(), s->d_stage + slot, tmp.size(), hipMemcpyDeviceToHost, (hipStream_t)stream), "D2H");
-            s->hipapi_check(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
-            for (int r = 0; r < s->shard_world; ++r)
-                memcpy(static_cast<char*>(all) + (size_t)r * nbytes_slot, tmp.data() + (size_t)r * slot, (size_t)nbytes_slot);
-            return 0;
-        } catch (const std::exception& e) {
-            fprintf(stderr, "allgather failed: %s\n", e.what());
+        if (cafehip_comm_allgather(s->ctx, mine, (size_t)nbytes_mine, all, (size_t)nbytes_slot) != 0) {
+            fprintf(stderr, "allgather failed: %s\n", cafehip_last_error());
             return -1;
         }
+        return 0;
     }
 
     bool report_sharded() const { return shard_world > 1 && allgather != nullptr; }
@@ -970,7 +858,7 @@ struct cafehost_session {
 
     bool speculation_pays()
     {
-        if (exchange) return false;   // sharded: every evaluation already ends in a collective
+        if (exchange || native_comm) return false;   // sharded: every evaluation already ends in an exchange
         if (opt_speculate >= 0) return opt_speculate != 0;
         int wg = 0, cu = 0;
         if (cafehip_launch_info(ctx, &wg, &cu) != 0) return false;
@@ -1014,7 +902,11 @@ struct cafehost_session {
     {
         double score = 0;
         zero = -1;
-        if (exchange) {
+        if (native_comm) {
+            // K1 -> tables -> walk -> score kernel with the exchange inside (or one ncclAllGather behind it): the map +
+            // sum of cafe/lambda.cpp:698-722 over every rank's block, same bits on every rank
+            hip_check(cafehip_eval_posterior_sharded(ctx, nl.data(), nm.data(), pr.data(), &score, &zero));
+        } else if (exchange) {
             hip_check(cafehip_eval_posterior_async(ctx, nl.data(), nm.data(), pr.data(), d_exch_chunks, d_exch_fz));
             int z = -1;
             score = exchange(exchange_user, &z);
@@ -1309,7 +1201,7 @@ struct cafehost_session {
     {
         // the device call scores the table that is on THIS device: a shard would give every rank a different score
         // and memberships indexed by local family
-        if (exchange || shard_world > 1)
+        if (exchange || native_comm || shard_world > 1)
             throw std::runtime_error("the k-cluster model is not sharded: run `lambda -k` / `score` of a clustered model on one rank");
         const int K = k_clusters, fix = fixcluster0 ? 1 : 0;
         const int n_lam = num_lambdas * (K - fix);
@@ -1356,7 +1248,7 @@ struct cafehost_session {
     // cafe_best_lambda_by_fminsearch with k > 0 (cafe/lambda.cpp:525-647)
     void cluster_search()
     {
-        if (exchange) throw std::runtime_error("the k-cluster search is not sharded: run it on one rank");
+        if (exchange || native_comm) throw std::runtime_error("the k-cluster search is not sharded: run it on one rank");
         const int K = k_clusters, fix = fixcluster0 ? 1 : 0, kfix = K - fix;
         const int n_lam = num_lambdas * kfix;
         const int max_runs = 10;
@@ -2764,10 +2656,6 @@ void cafehost_destroy(cafehost_session* s)
 {
     if (!s) return;
     if (s->own_log && s->flog) fclose(s->flog);
-    if (s->comm) g_rccl.CommDestroy(s->comm);
-    hipFree(s->d_packed);
-    hipFree(s->d_gathered);
-    hipFree(s->d_stage);
     cafehip_destroy(s->ctx);
     if (s->ctx_one) cafehip_destroy(s->ctx_one);
     delete s;
@@ -2835,13 +2723,8 @@ int cafehost_set_allgather(cafehost_session* s, cafehost_allgather_fn fn, void* 
 int cafehost_comm_unique_id(void* out_id)
 {
     if (!out_id) return host_fail("null id buffer");
-    if (!g_rccl.load()) return host_fail(g_rccl.error);
-    ncclUniqueId id;
-    static_assert(sizeof(ncclUniqueId) <= CAFEHOST_COMM_ID_BYTES, "id buffer too small");
-    const ncclResult_t r = g_rccl.GetUniqueId(&id);
-    if (r != ncclSuccess) return host_fail(std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
-    memset(out_id, 0, CAFEHOST_COMM_ID_BYTES);
-    memcpy(out_id, &id, sizeof id);
+    static_assert(CAFEHOST_COMM_ID_BYTES == CAFEHIP_COMM_ID_BYTES, "one id size");
+    if (cafehip_comm_unique_id(out_id) != 0) return host_fail(std::string("cafehip: ") + cafehip_last_error());
     return 0;
 }
 
@@ -2850,16 +2733,8 @@ int cafehost_init_comm(cafehost_session* s, int rank, int world, const void* uni
     if (!s) return host_fail("null session");
     if (!unique_id) return host_fail("null communicator id");
     if (world < 1 || rank < 0 || rank >= world) return host_fail("bad rank " + std::to_string(rank) + "/" + std::to_string(world));
-    if (s->comm) return host_fail("this session already has a communicator");
-    if (!g_rccl.load()) return host_fail(g_rccl.error);
-    if (hipSetDevice(s->device_id) != hipSuccess) return host_fail("hipSetDevice failed");
-    ncclUniqueId id;
-    memcpy(&id, unique_id, sizeof id);
-    const ncclResult_t r = g_rccl.CommInitRank(&s->comm, world, id, rank);
-    if (r != ncclSuccess) {
-        s->comm = nullptr;
-        return host_fail(std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
-    }
+    if (s->native_comm) return host_fail("this session already has a communicator");
+    if (cafehip_comm_init(s->ctx, rank, world, unique_id) != 0) return host_fail(std::string("cafehip: ") + cafehip_last_error());
     s->native_comm = true;
     s->shard_rank = rank;
     s->shard_world = world;
@@ -2879,8 +2754,11 @@ int cafehost_speculation_stats(cafehost_session* s, long* launches, long* points
 int cafehost_exchange_stats(cafehost_session* s, double* seconds, long* calls)
 {
     if (!s) return host_fail("null session");
-    if (seconds) *seconds = s->exchange_seconds;
-    if (calls) *calls = s->exchange_calls;
+    double sec = 0;
+    long n = 0;
+    if (cafehip_comm_info(s->ctx, nullptr, nullptr, nullptr, nullptr, &sec, &n) != 0) return host_fail(std::string("cafehip: ") + cafehip_last_error());
+    if (seconds) *seconds = sec;
+    if (calls) *calls = n;
     return 0;
 }
 

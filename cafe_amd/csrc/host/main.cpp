@@ -41,7 +41,7 @@ static int run(cafehost_session* s, const char* script)
 int main(int argc, char** argv)
 {
     int device = 0, gpus = 1, rank = -1, world = 0;
-    bool comm_one = false;
+    bool comm_one = false, same_device = false;
     const char* script = nullptr;
     const char* id_file = nullptr;
     for (int i = 1; i < argc; ++i) {
@@ -51,6 +51,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--world") && i + 1 < argc) world = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--id-file") && i + 1 < argc) id_file = argv[++i];
         else if (!strcmp(argv[i], "--comm")) comm_one = true;
+        else if (!strcmp(argv[i], "--same-device")) same_device = true;   // every rank on device 0 (functional check on a 1-GPU box)
         else script = argv[i];
     }
 
@@ -76,8 +77,8 @@ int main(int argc, char** argv)
         for (int r = 0; r < gpus; ++r) {
             const pid_t pid = fork();
             if (pid == 0) {
-                const std::string rs = std::to_string(r), ws = std::to_string(gpus);
-                execl("/proc/self/exe", argv[0], "-d", rs.c_str(), "--rank", rs.c_str(), "--world", ws.c_str(), "--id-file", path,
+                const std::string rs = std::to_string(r), ws = std::to_string(gpus), ds = std::to_string(same_device ? device : r);
+                execl("/proc/self/exe", argv[0], "-d", ds.c_str(), "--rank", rs.c_str(), "--world", ws.c_str(), "--id-file", path,
                       script, (char*)nullptr);
                 perror("cafehip: exec");
                 _exit(127);

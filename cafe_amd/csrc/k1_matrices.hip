@@ -17,6 +17,15 @@ __device__ __forceinline__ void k1_mirror_node_keys(const K1Args& a)
         for (int i = threadIdx.x; i < a.n_sets * a.n_nodes; i += 256) a.node_key_dev[i] = src[i];
     }
     if (a.first_zero && (int)threadIdx.x < a.n_sets) a.first_zero[threadIdx.x] = INT32_MAX;
+    if (a.n_prior > 0) {
+        // a new prior (once per search): mirrored by the same kernel stores as the map, so that it is ordered with
+        // the launches that read it like everything else of the evaluation (a copy command is not: round 3)
+        const double* __restrict__ pr = eval_prior(a.ep, a.prior_offset);
+        for (int i = threadIdx.x; i < a.n_prior; i += 256) {
+            a.prior_dev[i] = pr[i];
+            a.logprior_dev[i] = pr[kMaxPrior + i];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------

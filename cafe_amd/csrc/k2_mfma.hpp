@@ -926,59 +926,21 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 // 16x16x4 shape, one 16-state tile, Wr = blockDim.x / 64 wave rows of NRT_W row tiles.
 // ====================================================================================
 
-// A level is a few hundred workgroups: one or two waves per SIMD, nothing to switch to while an operand is in flight --
-// a tile is a chain of memory round trips (tile record -> matrix keys -> child columns -> matrix operand), so the
-// chain is made as short as the data dependencies allow (round 3):
-//   * the child columns of ALL the tile's states are requested in one batch (registers), not one round trip per
-//     slice of the vector;
-//   * the node's own matrix does not depend on the states at all: a wave requests its whole operand -- every k-step
-//     of its row tile, KPF of them at once, the rest as ring slots free up -- BEHIND the column gathers (loads return
-//     in order) and before the vectors are formed, so the product loop finds it in registers;
-//   * one wave per row tile up to 16 waves.  A tile holds 16 * NFT_W states; the launcher uses NFT_W = 1 (larger
-//     tiles measured slower).
-// Same matrix instructions on the same operands in the same k order as the ring loop: bit-identical tables.
+// A level is a few hundred workgroups: one or two waves per SIMD, nothing to switch to while an operand is in flight,
+// so the rings are deep and a tile's rows are spread over as many waves as it has row tiles (up to 16).  A tile holds
+// 16 * NFT_W states; the launcher uses NFT_W = 1 (larger tiles measured slower).  The child columns of a state are
+// requested in ONE batch (clamped addresses, no branches) and every index the tile needs from the evaluation's
+// node -> matrix map in one round trip behind the tile record.
+// Measured and dropped in round 3 (profiles/r03/k2c_prefetch_sweep.txt): requesting the wave's whole matrix operand
+// up front (8 ... 40 k-steps in registers, straight-line product): 19-47 % SLOWER tables at every bench shape -- a
+// level is bound by how many tiles a CU holds at once (registers) and by the matrix pipe, not by operand latency.
 #ifndef CAFE_K2C_DEPTH
 #define CAFE_K2C_DEPTH 6
 #endif
 constexpr int K2C_GATHER_MAX = 6;   // vector slices per thread kept in registers (LDv <= 6 * threads per state, else a loop)
 
-// NRT_W == 1: KPF k-steps of the wave's row tile requested up front, straight-line product over at most KMAX k-steps
-// (unconditional and branch-free: a branch around a load makes the compiler drain every outstanding load at the join
-// before the gathers can be consumed; k-steps beyond the matrix re-read the last one and are never multiplied)
-template <int KPF, int KMAX>
-__device__ __forceinline__ void k2c_issue_b(k2_gbytes sb, unsigned vo, unsigned kstride_bytes, int ksteps, double (&bq)[KPF])
-{
-#pragma unroll
-    for (int k = 0; k < KPF; ++k) {
-        const unsigned off = (unsigned)min(k, ksteps - 1) * kstride_bytes;   // scalar
-        bq[k] = *(k2_gptr)(sb + off + vo);
-    }
-}
-
-template <int KPF, int KMAX>
-__device__ __forceinline__ void k2c_product(k2_gbytes sb, unsigned vo, unsigned kstride_bytes, const double* ap, int ksteps,
-                                            double (&bq)[KPF], cafe_d4& acc)
-{
-    const k2_lptr pa = (k2_lptr)ap;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        if (k < ksteps) {
-            const double av = pa[k * 4];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bq[k % KPF], acc, 0, 0, 0);
-            if constexpr (KPF < KMAX) {
-                if (k + KPF < KMAX) {   // the slot is free: ask for k-step k + KPF (clamped, unconditional)
-                    const unsigned off = (unsigned)min(k + KPF, ksteps - 1) * kstride_bytes;
-                    bq[k % KPF] = *(k2_gptr)(sb + off + vo);
-                }
-            }
-        }
-    }
-}
-
-// (matrix sides up to 160 have at most 10 row tiles = 10 waves: the tighter bound leaves the 40-k-step variant 170
-// registers per lane instead of 128)
-template <int NFT_W, int NRT_W, int KPF, int KMAX, bool BATCH>
-__global__ __launch_bounds__(KMAX == 40 ? 640 : 1024) void k2c_nodes(K2cArgs a)
+template <int NFT_W, int NRT_W, bool BATCH>
+__global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
 {
     extern __shared__ double Lbuf[];   // [16 * NFT_W][LDv]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
@@ -992,8 +954,6 @@ __global__ __launch_bounds__(KMAX == 40 ? 640 : 1024) void k2c_nodes(K2cArgs a)
     const int ntile = rt_base + (wave < rt_rem ? 1 : 0);
     const int rt0 = wave * rt_base + min(wave, rt_rem);
     const unsigned kstride_bytes = 32u * (unsigned)a.LD;
-    constexpr bool PREFETCH = (NRT_W == 1 && NFT_W == 1 && KPF > 0);
-    double bq[PREFETCH ? KPF : 1];
     // every index this tile needs from the evaluation's node -> matrix map, requested together (no branches: one
     // round trip behind the tile record)
     const int32_t* nk = a.node_key + set * a.n_nodes;
@@ -1002,7 +962,6 @@ __global__ __launch_bounds__(KMAX == 40 ? 640 : 1024) void k2c_nodes(K2cArgs a)
     const bool err0 = lhe[t.leafcol[0]] != 0, err1 = lhe[t.leafcol[1]] != 0;
     const size_t msz = (size_t)a.KP * a.LD;
     const k2_gbytes sb = k2_uniform(a.PT + (size_t)key_node * msz);
-    const unsigned vo0 = (unsigned)(lk * a.LD + li + min(rt0, RT - 1) * 16) * 8u;   // (a wave without a tile re-reads the last one)
     {
         // L[state][k] = F_a[k] * F_b[k]
         const bool leaf0 = t.kind[0] == 0, leaf1 = t.kind[1] == 0;
@@ -1020,7 +979,7 @@ __global__ __launch_bounds__(KMAX == 40 ? 640 : 1024) void k2c_nodes(K2cArgs a)
         const double* c1 = base1 + (size_t)(live ? i1 : 0) * a.LD;
         double* L = Lbuf + (size_t)f * a.LDv;
         if (BATCH && a.LDv <= K2C_GATHER_MAX * per_state) {
-            // all slices of both columns in one batch (clamped addresses, no branches), the matrix operand behind them
+            // all slices of both columns in one batch (clamped addresses, no branches)
             double g0[K2C_GATHER_MAX], g1[K2C_GATHER_MAX];
 #pragma unroll
             for (int q = 0; q < K2C_GATHER_MAX; ++q) {
@@ -1028,14 +987,12 @@ __global__ __launch_bounds__(KMAX == 40 ? 640 : 1024) void k2c_nodes(K2cArgs a)
                 g0[q] = c0[kc];
                 g1[q] = c1[kc];
             }
-            if constexpr (PREFETCH) k2c_issue_b<KPF, KMAX>(sb, vo0, kstride_bytes, a.ksteps, bq);
 #pragma unroll
             for (int q = 0; q < K2C_GATHER_MAX; ++q) {
                 const int k = l + q * per_state;
                 if (k < a.LDv) L[k] = (live && k < a.C) ? g0[q] * g1[q] : 0.0;
             }
         } else {
-            if constexpr (PREFETCH) k2c_issue_b<KPF, KMAX>(sb, vo0, kstride_bytes, a.ksteps, bq);
             for (int k = l; k < a.LDv; k += per_state) L[k] = (live && k < a.C) ? c0[k] * c1[k] : 0.0;
         }
     }
@@ -1047,9 +1004,7 @@ __global__ __launch_bounds__(KMAX == 40 ? 640 : 1024) void k2c_nodes(K2cArgs a)
         for (int j = 0; j < NRT_W; ++j) fac[i][j] = cafe_d4{0.0, 0.0, 0.0, 0.0};
     if (ntile > 0) {
         const double* ap = Lbuf + (size_t)li * a.LDv + lk;
-        if constexpr (PREFETCH) {
-            k2c_product<KPF, KMAX>(sb, vo0, kstride_bytes, ap, a.ksteps, bq, fac[0][0]);
-        } else {
+        {
             unsigned voff[NRT_W];
 #pragma unroll
             for (int j = 0; j < NRT_W; ++j) voff[j] = (unsigned)(lk * a.LD + li + ((j < ntile) ? (rt0 + j) : rt0) * 16) * 8u;

@@ -226,6 +226,80 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(K3Args a)
 
 
 // ------------------------------------------------------------------------------------
+// K3 of a sharded evaluation, direct exchange (comm.hpp).  The packed row of a rank -- its chunk sums in family order
+// and the index of its first zero-likelihood family -- is what cafe/lambda.cpp:698-722 needs from that rank's
+// families.  Every block stores its chunk sum straight into the exchange buffer of EVERY rank (uncached device
+// memory, the peers' mapped over xGMI with hipIpc: world 8-byte stores, each followed by a system-scope fence before
+// the block counts itself in); the last block publishes the first-zero index the same way, then raises this rank's
+// flag (= the exchange sequence number) in every buffer, waits until every rank's flag stands in its own buffer and
+// copies all rows to the pinned host block the host spins on.  No collective launch, no extra kernel: the sharded
+// evaluation is the same three launches as the single-GPU one.  Buffers alternate by the parity of the sequence
+// number: a rank can be at most one evaluation ahead of another (it needs the other's row to finish).
+// A peer that never shows up ends the wait after timeout_ticks: the host reads -seq and reports the failure.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long x_load_flag(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score_x(K3xArgs a)
+{
+    __shared__ double red[CAFEHIP_CHUNK];
+    __shared__ int s_last, s_fail;
+    const int i = blockIdx.x * CAFEHIP_CHUNK + threadIdx.x;
+    double v = 0.0;
+    if (i < a.F) {
+        const int u = a.fam2u[i];
+        v = log(a.max_post_u[u]);                                     // cafe/lambda.cpp:721
+        if (a.max_lik_u[u] == 0.0) atomicMin(a.first_zero, i);        // cafe/lambda.cpp:715-720
+    }
+    red[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = CAFEHIP_CHUNK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const size_t row = (size_t)a.rank * (a.slots + 1);
+    if ((int)threadIdx.x < a.world) {
+        a.rows[threadIdx.x][row + blockIdx.x] = red[0];
+        __threadfence_system();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(a.arrive, 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) s_fail = 0;
+    const long long fz = atomicMin(a.first_zero, INT32_MAX);   // atomic read of the final value
+    if ((int)threadIdx.x < a.world) {
+        a.rows[threadIdx.x][row + a.slots] = __longlong_as_double(fz);
+        __threadfence_system();
+        __hip_atomic_store(&a.flags[threadIdx.x][a.rank], a.xseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (threadIdx.x == 0) *a.arrive = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < a.world) {
+        const unsigned long long* mine = a.flags[a.rank] + threadIdx.x;
+        const long long t0 = wall_clock64();
+        while (x_load_flag(mine) != a.xseq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > a.timeout_ticks) {
+                s_fail = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    const double* all = a.rows[a.rank];
+    const int n = a.world * (a.slots + 1);
+    for (int k = threadIdx.x; k < n; k += CAFEHIP_CHUNK) a.host->chunk_sums[k] = __builtin_nontemporal_load(all + k);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) a.host->done_seq = s_fail ? -a.seq : a.seq;
+}
+
+// ------------------------------------------------------------------------------------
 // K3 of the k-cluster model (cafe_get_clustered_posterior, cafe/cafe_main.c:165-253).  K2 has left the per-family
 // max posterior of every cluster (set) in max_post_u[k * Fu + u].  Per family, clusters ascending as the reference
 // loops them: MAP_k = max_post_k * weight_k (:196), sum (:197), membership p_z[k] = MAP_k / sum (:204),
@@ -460,6 +534,7 @@ const void* k2_v1_kernel(int nf)
     return nullptr;
 }
 const void* k3_kernel(bool host_out) { return host_out ? reinterpret_cast<const void*>(&k3_score<true>) : reinterpret_cast<const void*>(&k3_score<false>); }
+const void* k3x_kernel() { return reinterpret_cast<const void*>(&k3_score_x); }
 const void* k3_cluster_kernel() { return reinterpret_cast<const void*>(&k3_cluster_score); }
 const void* fetch_small_kernel() { return reinterpret_cast<const void*>(&k_fetch_small); }
 const void* k4_kernel(int nf)

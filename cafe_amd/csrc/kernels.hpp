@@ -23,13 +23,13 @@ constexpr bool k2_fits4(int G, int nrt_w) { return G >= 1 && G <= 8 && nrt_w >= 
 const void* k2_mfma16_kernel(int nft_w, int nrt_w);
 const void* k2_mfma4_kernel(int G, int nrt_w);
 
-// k2c_tables.hip: factor tables of compressed subtrees, K2cArgs.  kpf: k-steps of the matrix operand requested up
-// front (0: the short ring of the walk)
-const void* k2c_kernel(int nft_w, int nrt_w, int kpf, int kmax);
+// k2c_tables.hip: factor tables of compressed subtrees, K2cArgs (batch_gathers: the child columns of a state in one batch)
+const void* k2c_kernel(int nft_w, int nrt_w, bool batch_gathers);
 
 // k_misc.hip
 const void* k2_v1_kernel(int nf);          // k2_prune_v1<NF>(K2Args), NF in {1, 2, 4, 8, 16}
 const void* k3_kernel(bool host_out);      // k3_score<HOST_OUT>(K3Args)
+const void* k3x_kernel();                  // k3_score_x(K3xArgs): score + direct multi-GPU exchange
 const void* k3_cluster_kernel();           // k3_cluster_score(K3cArgs)
 const void* fetch_small_kernel();          // k_fetch_small(FetchArgs)
 const void* k4_kernel(int nf);             // k4_viterbi<NF>(K4Args), NF in {1, 2, 4, 8}

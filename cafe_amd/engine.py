@@ -92,6 +92,12 @@ class Engine:
         self.F = c.shape[0]
         self.range = rng
 
+    def last_setup_ms(self):
+        """Host milliseconds of the last set_families: dict(dedup, compression_plan, upload_alloc, total)."""
+        ms = (C.c_double * 4)()
+        _lib.check(self._L.cafehip_last_setup_ms(self._h, ms))
+        return {"dedup": ms[0], "compression_plan": ms[1], "upload_alloc": ms[2], "total": ms[3]}
+
     def set_error_model(self, errormatrix, leaf_has_model=None):
         if errormatrix is None:
             _lib.check(self._L.cafehip_set_error_model(self._h, 0, None, None))
@@ -200,6 +206,55 @@ class Engine:
         pr = np.ascontiguousarray(prior, np.float64)
         _lib.check(self._L.cafehip_eval_posterior_async(self._h, _d(nl), _d(nm), _d(pr), C.c_void_p(d_chunk_sums_ptr),
                                                         C.c_void_p(d_first_zero_ptr)))
+
+    # ---- multi-GPU (one process per GPU; include/cafehip.h) ----------------------------------------------
+    COMM_ID_BYTES = 128
+
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(self.COMM_ID_BYTES)
+        _lib.check(self._L.cafehip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        assert len(unique_id) == self.COMM_ID_BYTES
+        _lib.check(self._L.cafehip_comm_init(self._h, int(rank), int(world), C.c_char_p(unique_id)))
+
+    def comm_set_blocks(self, bounds):
+        """bounds: [(lo, hi)] of every rank's block of the global table (cafe_amd.distributed.shard_bounds)."""
+        lo = np.ascontiguousarray([b[0] for b in bounds], np.int32)
+        hi = np.ascontiguousarray([b[1] for b in bounds], np.int32)
+        _lib.check(self._L.cafehip_comm_set_blocks(self._h, _i(lo), _i(hi)))
+
+    def comm_allgather(self, mine, slot_bytes):
+        """All-gather of host blocks (bytes): returns world slots of slot_bytes each, in rank order."""
+        info = self.comm_info()
+        mine = bytes(mine)
+        out = C.create_string_buffer(slot_bytes * info["world"])
+        _lib.check(self._L.cafehip_comm_allgather(self._h, C.c_char_p(mine), len(mine), out, slot_bytes))
+        return [out.raw[r * slot_bytes:(r + 1) * slot_bytes] for r in range(info["world"])]
+
+    def get_posterior_sharded(self, node_lambda, node_mu, prior):
+        """One objective evaluation of the sharded table: (score, first_zero_global), the same on every rank."""
+        nl = np.ascontiguousarray(node_lambda, np.float64)
+        nm = np.ascontiguousarray(node_mu, np.float64)
+        pr = np.ascontiguousarray(prior, np.float64)
+        f = getattr(self, "_fast_sh", None)
+        if f is None:
+            vp = C.c_void_p
+            f = self._fast_sh = C.CFUNCTYPE(C.c_int, vp, vp, vp, vp, vp, vp)(("cafehip_eval_posterior_sharded", self._L))
+            self._sscore, self._sfz = C.c_double(), C.c_int32(-1)
+            self._sscore_ref, self._sfz_ref = C.addressof(self._sscore), C.addressof(self._sfz)
+        _lib.check(f(self._h, nl.__array_interface__["data"][0], nm.__array_interface__["data"][0],
+                     pr.__array_interface__["data"][0], self._sscore_ref, self._sfz_ref))
+        return self._sscore.value, self._sfz.value
+
+    def comm_info(self):
+        """dict(rank, world, mode, exchange_ms, host_seconds, calls); mode: 0 none, 1 rccl, 2 direct."""
+        r, w, m = C.c_int32(), C.c_int32(), C.c_int32()
+        ms, hs, n = C.c_double(), C.c_double(), C.c_long()
+        _lib.check(self._L.cafehip_comm_info(self._h, C.byref(r), C.byref(w), C.byref(m), C.byref(ms), C.byref(hs), C.byref(n)))
+        return {"rank": r.value, "world": w.value, "mode": {0: "none", 1: "rccl", 2: "direct"}[m.value],
+                "exchange_ms": ms.value, "host_seconds": hs.value, "calls": n.value}
 
     def num_chunks(self):
         return self._L.cafehip_num_chunks(self._h)

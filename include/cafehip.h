@@ -68,8 +68,9 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *   k2slots         0|1        park scratch owned per resident workgroup (1) | one region per family tile
  *   ldspark         n          park buffers kept in LDS (empty: by residency)
  *   vitlds          0|1        Viterbi argmax tables in LDS (0: global scratch)
- *   k2c_prefetch    0|1        factor-table kernel requests its whole matrix operand up front (1)
+ *   k2c_batch       0|1        factor-table kernel gathers the child columns of a state in one batch (1)
  *   batch_trim      0|1        batch mode: a tile's products stop at its largest column limit (1)
+ *   comm            auto|direct|rccl   exchange mode of sharded evaluations (multi-GPU section below)
  * The same names, upper-cased behind CAFEHIP_ (CAFEHIP_COMPRESS=0 ...), are read from the environment ONCE, by
  * cafehip_create; nothing reads the environment during an evaluation.  Options that change the compression plan
  * rebuild it.  No reference counterpart. */
@@ -101,6 +102,12 @@ int cafehip_set_tree(cafehip_ctx *ctx, int n_nodes, const int32_t *parent, const
 int cafehip_set_families(cafehip_ctx *ctx, int F, int n_leaves, const int32_t *counts,
                          const int32_t *ref, int range_min, int range_max, int root_min,
                          int root_max);
+
+/* Host wall-clock of the last cafehip_set_families call, the one-time set-up SURVEY.md section 8(d) asks to be reported
+ * apart from the evaluations: ms[0] duplicate-row detection (ref), ms[1] subtree-state compression plan (state
+ * numbering + tiles + upload), ms[2] uploads and allocations (count table, outputs, ln C tables when the matrix side
+ * changed), ms[3] the whole call. */
+int cafehip_last_setup_ms(cafehip_ctx *ctx, double ms[4]);
 
 /* Error model: errormatrix[(mfs+1) x (mfs+1)] row = observed, col = true
  * (libtree/family.h:31-38), leaf_has_model[n_nodes] marks leaves that carry it
@@ -213,6 +220,48 @@ int cafehip_eval_root_likelihoods(cafehip_ctx *ctx, int B, const int32_t *counts
  * under the per-family ranges of cafe_family_set_size_with_family_forced (cafe/cafe_family.c:236-255). */
 int cafehip_viterbi(cafehip_ctx *ctx, int B, const int32_t *counts, const int32_t *root_lo,
                     const int32_t *root_hi, const int32_t *col_max, int32_t *node_sizes);
+
+/* ---- multi-GPU: one process per GPU of ONE node, families sharded, the exchange behind this ABI ---------------------
+ * The reference's get_posterior is a map over families followed by a sum (cafe/lambda.cpp:698-722); sharded, every
+ * rank maps its contiguous, chunk-aligned block of the table and the ranks exchange ONE packed row each -- the
+ * per-chunk partial sums of the block and the index of its first zero-likelihood family -- after which every rank
+ * repeats the same fixed-order sum: the score is bit-identical for any number of GPUs, so every rank's Nelder-Mead
+ * takes the same decisions and nothing is broadcast.  Two exchange modes (option "comm" = auto | direct | rccl):
+ *   direct  the score kernel of every rank stores its row straight into an uncached buffer of every other rank
+ *           (hipIpc-mapped, over xGMI) and waits for the others' flags: no collective launch, the sharded evaluation
+ *           is the same three launches as the single-GPU one.  Used when every rank could map every buffer.
+ *   rccl    ONE ncclAllGather of the rows on the context's stream (librccl resolved with dlopen when first needed),
+ *           picked up with cafehip_fetch_small.
+ * Rendezvous, barriers and the all-gather of host blocks (report phase) run over a POSIX shared-memory segment named
+ * by the 128-byte id: rank 0 obtains one and hands it to the others by any means (file, environment, pipe).
+ * Every call below except cafehip_comm_unique_id / cafehip_comm_info is collective: all ranks make it, in the same
+ * order.  No reference counterpart (the reference is one process; its threads split the same loop). */
+#define CAFEHIP_COMM_ID_BYTES 128
+int cafehip_comm_unique_id(void *out_id /* CAFEHIP_COMM_ID_BYTES */);
+int cafehip_comm_init(cafehip_ctx *ctx, int rank, int world, const void *unique_id);
+/* After cafehip_set_families: every rank's block [block_lo[r], block_hi[r]) of the GLOBAL table (world entries each,
+ * contiguous, starting on multiples of CAFEHIP_CHUNK); this rank's table must hold its block's rows.  Sizes the
+ * exchange.  Call again whenever a table is loaded. */
+int cafehip_comm_set_blocks(cafehip_ctx *ctx, const int32_t *block_lo, const int32_t *block_hi);
+/* One objective evaluation of the sharded table == cafehip_eval_posterior of the whole table: *score and
+ * *first_zero_global (index into the global table, -1 if none) are the same on every rank and bit-identical to the
+ * single-GPU call. */
+int cafehip_eval_posterior_sharded(cafehip_ctx *ctx, const double *node_lambda, const double *node_mu,
+                                   const double *prior, double *score, int32_t *first_zero_global);
+/* All-gather of host blocks (report phase: Monte-Carlo null by root size, per-family p-values): rank r contributes
+ * nbytes_mine <= nbytes_slot bytes, `all` receives world slots of nbytes_slot bytes in rank order. */
+int cafehip_comm_allgather(cafehip_ctx *ctx, const void *mine, size_t nbytes_mine, void *all, size_t nbytes_slot);
+/* rank / world of the context (0 / 1 without a communicator), the exchange mode in use (0 none, 1 rccl, 2 direct),
+ * with timing enabled the duration of the last RCCL exchange (all-gather + pick-up, HIP events on the stream; the
+ * direct exchange is part of the score kernel: cafehip_last_kernel_ms()[2]), the host time spent inside exchange
+ * steps and the number of sharded evaluations.  Any pointer may be NULL. */
+int cafehip_comm_info(cafehip_ctx *ctx, int *rank, int *world, int *mode, double *exchange_ms, double *host_seconds,
+                      long *calls);
+
+/* Test hook: the HOST half of a communicator alone (rendezvous by id, three barriers, one all-gather of host blocks,
+ * as cafehip_comm_allgather) without a context or a device -- what the CPU test suite runs with several processes. */
+int cafehip_comm_host_selftest(int rank, int world, const void *unique_id, const void *mine, size_t nbytes_mine,
+                               void *all, size_t nbytes_slot);
 
 /* Multi-GPU exchange helper: bring `nbytes` (a multiple of 8, <= 1 MiB) of device memory -- the output of the
  * caller's collective, enqueued on the context's stream -- to the host without a copy command or a stream

@@ -60,19 +60,20 @@ typedef int (*cafehost_allgather_fn)(void *user, const void *mine, long long nby
                                      long long nbytes_slot);
 int cafehost_set_allgather(cafehost_session *s, cafehost_allgather_fn fn, void *user);
 /* ---- native communicator: the exchange behind the C ABI, no callbacks ----------------------------------------
- * Rank 0 obtains an id (ncclGetUniqueId) and hands its CAFEHOST_COMM_ID_BYTES bytes to the other ranks by any
- * means (file, pipe, environment; cafe_amd/bin/cafehip --gpus N writes it to a temporary file); every rank then
- * calls cafehost_init_comm with its rank.  From then on the session shards every table it loads (contiguous,
- * chunk-aligned blocks), leaves its per-chunk partial sums on the device and runs ONE ncclAllGather of the packed
- * (chunk sums, first-zero index) buffers per objective evaluation on the context's stream -- the map + sum of
- * cafe/lambda.cpp:698-722 -- followed by the same fixed-order sum on every rank, so every rank's Nelder-Mead takes
- * identical decisions and the score does not depend on the number of GPUs.  `report`, `pvalue` and `lhtest` run
- * sharded too (the Monte-Carlo null by root size, as cafe/conditional_distribution.cpp:88-108 splits it over
- * threads); rank 0 writes the files.  librccl is loaded when the first id is requested / communicator joined. */
+ * Rank 0 obtains an id and hands its CAFEHOST_COMM_ID_BYTES bytes to the other ranks by any means (file, pipe,
+ * environment; cafe_amd/bin/cafehip --gpus N writes it to a temporary file); every rank then calls
+ * cafehost_init_comm with its rank.  From then on the session shards every table it loads (contiguous,
+ * chunk-aligned blocks) and every objective evaluation is cafehip_eval_posterior_sharded (include/cafehip.h): the
+ * ranks exchange one packed row each -- directly between the score kernels over xGMI, or with one ncclAllGather
+ * (option "comm") -- the map + sum of cafe/lambda.cpp:698-722, followed by the same fixed-order sum on every rank,
+ * so every rank's Nelder-Mead takes identical decisions and the score does not depend on the number of GPUs.
+ * `report`, `pvalue` and `lhtest` run sharded too (the Monte-Carlo null by root size, as
+ * cafe/conditional_distribution.cpp:88-108 splits it over threads); rank 0 writes the files. */
 #define CAFEHOST_COMM_ID_BYTES 128
 int cafehost_comm_unique_id(void *out_id /* CAFEHOST_COMM_ID_BYTES */);
 int cafehost_init_comm(cafehost_session *s, int rank, int world, const void *unique_id);
-/* accumulated host time inside the exchange step (collective launch + result pick-up) and its call count */
+/* host time inside RCCL exchange steps (collective launch + result pick-up; the direct exchange has none: it is
+ * part of the score kernel) and the number of sharded evaluations */
 int cafehost_exchange_stats(cafehost_session *s, double *seconds, long *calls);
 
 int cafehost_set_stream(cafehost_session *s, void *hip_stream);

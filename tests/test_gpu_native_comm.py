@@ -29,6 +29,7 @@ def _run(lines, comm):
         sh.dispatch(l)
     res = (list(sh.params), sh.score, sh.iterations, sh.evaluations)
     stats = sh.exchange_stats()
+    _run.last_trace = sh.trace().copy()
     sh.close()
     return res, stats
 
@@ -58,8 +59,12 @@ def test_reload_rewires_the_exchange(test1_table):
     lines = ["seed 10", "tree " + g["newick"], "load -i %s -max_size 5" % test1_table, "lambda -s",
              "load -i %s -max_size 20" % test1_table, "lambda -s"]
     plain, _ = _run(lines, False)
+    tp = _run.last_trace
     comm, _ = _run(lines, True)
-    assert comm == plain
+    tc = _run.last_trace
+    import numpy as np
+    d = np.nonzero((tp != tc).any(axis=1))[0] if tp.shape == tc.shape else None
+    assert comm == plain, ("evaluations of the last search that differ", d, tp[d[:4]].tolist() if d is not None else None, tc[d[:4]].tolist() if d is not None else None)
 
 
 def test_report_through_the_communicator_equals_the_golden_file(tmp_path):
