@@ -7,6 +7,7 @@ different rates (as the optimiser does), builds all transition matrices, prunes 
 reduces the score and returns it to the host.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5] [--scaling weak|strong]
+                    [--comm native|torch] [--table synthetic|test1|turnover]
 
 Default workload = BASELINE.json configs[1] (cfg2: 10k families, 16 taxa, single lambda).  The other
 configs: cfg3 = configs[2] (100k families, 32 taxa, lambda/mu), cfg4 = one GPU's shard of configs[3]
@@ -15,10 +16,19 @@ model on every leaf; adds the Monte-Carlo-null launch, R x 1000 simulated famili
 
 --gpus N > 1: one process per GPU.  Started as a plain `python bench.py --gpus N` the script re-executes
 itself under torch.distributed.run with N ranks; started by torch.distributed.run it takes its rank from
-the environment.  Families are sharded (weak: the config's table per GPU; strong: one table split N ways),
-one RCCL all_gather of the packed per-chunk partial sums per step.
+the environment.  Families are sharded (weak: the config's table per GPU; strong: one table split N ways).
+--comm native (default): the timed step is cafehip_eval_posterior_sharded -- K1 -> factor tables -> walk -> score
+kernel with the exchange inside it (direct stores into the other ranks' buffers over xGMI) or one ncclAllGather
+behind it (cafehip option comm=rccl) -- the product's own path, one C call per step; torch.distributed is used
+before the timed region only, to hand out the communicator id.  --comm torch: the round-2 path (packed
+all_gather through torch.distributed), kept for comparison.
+Besides the headline the JSON line carries (rank 0): `roofline`, `setup_ms`, `exchange` (multi-rank),
+`strong_scaling` (configs[3]'s 500k-family table split over the ranks, same table for every N), `tables`
+(the reference's 14,787-family test1 table and a high-turnover synthetic one), `lambda_search`, `cpu_baseline`.
 """
 import argparse
+import gzip
+import hashlib
 import json
 import math
 import os
@@ -37,7 +47,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured float4 copy)
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak: 256 CUs x 4 SIMDs x 32 flop/cycle x 2.4 GHz
 MIN_KERNEL_SAMPLES = 16
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")]
+GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def algorithmic_elements_per_family(n_leaves, R, C):
@@ -74,329 +85,337 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="cfg2")
-    ap.add_argument("--families", type=int, default=None, help="families per GPU (default: the config's)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: the table per GPU is fixed; strong: ONE table (the config's F, 500k for cfg4) split over the GPUs")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-search", action="store_true", help="skip the lambda-search wall-clock leg")
-    ap.add_argument("--no-probes", action="store_true", help="skip the measured HBM / MFMA ceilings")
-    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --same-device)")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="debug: take the multi-rank code path (process group + packed all_gather) even with 1 rank")
-    ap.add_argument("--same-device", action="store_true",
-                    help="debug: all ranks share GPU 0 (functional check of the N>1 path on a 1-GPU box)")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """One rank's block of a family table + everything an evaluation needs."""
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args))
+    def __init__(self, name, tree, newick, counts_local, bounds, F_total, rng, prior, cfg, rate_fn, desc):
+        self.name, self.tree, self.newick, self.counts = name, tree, newick, counts_local
+        self.bounds, self.F_total, self.rng, self.prior, self.cfg, self.rate_fn, self.desc = bounds, F_total, rng, prior, cfg, rate_fn, desc
+        self.R = rng.root_max - rng.root_min + 1
+        self.C = rng.max - rng.min + 1
 
-    # the contract is ONE JSON line on stdout: whatever libraries print to file descriptor 1 meanwhile (the host
-    # driver echoes some commands with printf) is sent to stderr, and the line is written to the saved descriptor
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
 
-    import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if args.same_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    multi = world > 1 or args.force_dist
-    backend = args.backend or ("gloo" if args.same_device else "nccl")
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
-
+def synthetic_workload(config, rank, world, scaling, families, same_table_blocks=0):
+    """BASELINE configs[1..4] (cafe_amd/synth.py).  weak: every rank simulates its own table of
+    F_local families (seed + rank).  strong: the global table is the concatenation of `same_table_blocks` blocks
+    simulated with per-block seeds -- the SAME table for every N that divides the block count -- and a rank simulates
+    only the blocks it owns."""
     import cafe_amd
     from cafe_amd import distributed as D
     from cafe_amd import prior as cprior
     from cafe_amd import synth
     from cafe_amd import tree as ctree
-
-    # ---- workload: this rank's shard of the family table -------------------------------
-    cfg = dict(synth.CONFIGS[args.config])
-    per_gpu_default = 62500 if args.config == "cfg4" else cfg["F"]   # configs[3] is quoted on 8 GPUs
-    if args.scaling == "strong":
-        F_total = args.families or cfg["F"]
-        b = D.shard_bounds(F_total, world)
-        F_local = b[rank][1] - b[rank][0]
-    else:
-        F_local = args.families or per_gpu_default
-        F_total = F_local * world
+    cfg = dict(synth.CONFIGS[config])
     newick = synth.random_ultrametric_newick(cfg["n_taxa"], cfg.get("tree_seed", cfg["seed"]))
     tree = ctree.CafeTree(newick)
-    counts = synth.simulate_families(tree, F_local, cfg["m"], cfg["lam"], cfg["mu"], cfg["seed"] + 1 + rank)
     rng = cafe_amd.init_family_size(cfg["m"])
-    R = rng.root_max - rng.root_min + 1
-    C = rng.max - rng.min + 1
-    lam_p = cprior.poisson_lambda_mle(counts)
-    prior = cprior.prior_rfsize_poisson(rng.root_min, lam_p)
-
-    eng = cafe_amd.Engine(local_rank)
-    stream = torch.cuda.current_stream()
-    eng.set_stream(stream.cuda_stream)
-    tree.apply(eng)
-    eng.set_families(counts, rng)
-    if cfg.get("error_model"):
-        eng.set_error_model(synth.banded_error_matrix(rng.max))
-    n_chunks = eng.num_chunks()
-    eng.enable_timing(False)
-
-    if args.scaling == "strong":
-        bounds = D.shard_bounds(F_total, world)
+    if scaling == "strong":
+        F_total = families or cfg["F"]
+        nb = same_table_blocks or world
+        if nb % world:
+            raise SystemExit("strong scaling: %d ranks do not divide the table's %d blocks" % (world, nb))
+        per_block = (F_total // nb // D.CHUNK) * D.CHUNK      # chunk-aligned blocks
+        F_total = per_block * nb
+        mine = range(rank * nb // world, (rank + 1) * nb // world)
+        counts = np.concatenate([synth.simulate_families(tree, per_block, cfg["m"], cfg["lam"], cfg["mu"], cfg["seed"] + 1 + b) for b in mine])
+        bounds = [(r * (nb // world) * per_block, (r + 1) * (nb // world) * per_block) for r in range(world)]
     else:
+        per_gpu_default = 62500 if config == "cfg4" else cfg["F"]   # configs[3] is quoted on 8 GPUs
+        F_local = families or per_gpu_default
+        if world > 1:
+            F_local = (F_local // D.CHUNK) * D.CHUNK or D.CHUNK    # blocks of the global table start on chunk boundaries
+        F_total = F_local * world
+        counts = synth.simulate_families(tree, F_local, cfg["m"], cfg["lam"], cfg["mu"], cfg["seed"] + 1 + rank)
         bounds = [(r * F_local, (r + 1) * F_local) for r in range(world)]
-    slots = max(1, max((hi - lo + D.CHUNK - 1) // D.CHUNK for lo, hi in bounds))
-    packed, p_chunks, p_fz = D.packed_buffer(torch, slots, "cuda")
-    gathered = torch.zeros((slots + 1) * world, dtype=torch.float64, device="cuda")
-    gathered_host = torch.zeros((slots + 1) * world, dtype=torch.float64).pin_memory()
+    prior = cprior.prior_rfsize_poisson(rng.root_min, cprior.poisson_lambda_mle(counts))
+    rate_fn = lambda step: synth.node_rates(tree, cfg, 1.0 + 0.003 * (step % 97), 1.0 + 0.002 * (step % 89))
+    return Workload(config, tree, newick, counts, bounds, F_total, rng, prior, cfg, rate_fn, cfg["desc"])
 
-    def node_rates(step):
-        return synth.node_rates(tree, cfg, 1.0 + 0.003 * (step % 97), 1.0 + 0.002 * (step % 89))
 
-    kernel_ms = []
-    exchange_s = [0.0, 0]
+def test1_workload():
+    """The reference's own 14,787-family table (tests/integration/test1.t: `load -i test1_families.txt -max_size 20`)
+    on its 20-species tree, single lambda around the fitted value."""
+    import cafe_amd
+    from cafe_amd import prior as cprior
+    from cafe_amd import tree as ctree
+    TR = json.load(open(os.path.join(GOLD, "transcripts.json")))
+    newick = TR["test1"]["newick"]
+    tree = ctree.CafeTree(newick)
+    rows = [l.decode().rstrip("\n").split("\t") for l in gzip.open(os.path.join(GOLD, "test1_families.txt.gz"))]
+    species = rows[0][2:]
+    raw = np.array([[int(x) for x in r[2:]] for r in rows[1:]], np.int32)
+    raw = raw[raw.max(axis=1) <= 20]
+    col = {n.lower(): j for j, n in enumerate(tree.leaf_names)}
+    counts = np.zeros((len(raw), tree.n_leaves), np.int32)
+    for j, sp in enumerate(species):
+        counts[:, col[sp.lower()]] = raw[:, j]
+    rng = cafe_amd.init_family_size(int(counts.max()))
+    prior = cprior.prior_rfsize_poisson(rng.root_min, cprior.poisson_lambda_mle(counts))
+    lam0 = TR["test1"]["search_result"]["lambda"]
+    cfg = {"lam": lam0, "mu": -1.0, "m": int(counts.max()), "n_taxa": tree.n_leaves}
 
-    # HIP events around each kernel cost ~10 us of a step: they are recorded on every TIMING_EVERY-th step of the
-    # timed region and, if that leaves fewer than MIN_KERNEL_SAMPLES, on extra steps run right after it
-    TIMING_EVERY = 8
+    def rate_fn(step):
+        return np.full(tree.n_nodes, lam0 * (1.0 + 0.003 * (step % 97))), np.full(tree.n_nodes, -1.0)
+    return Workload("test1", tree, newick, counts, [(0, len(counts))], len(counts), rng, prior, cfg, rate_fn,
+                    "the reference's test1_families.txt (-max_size 20): %d families, 20 species, single lambda" % len(counts))
 
-    # the per-step rate vectors are prepared ahead of the timed region (an optimiser hands them over ready-made)
-    n_extra = MIN_KERNEL_SAMPLES
-    rates = [node_rates(s) for s in range(args.warmup + args.steps + n_extra)]
 
-    def one_step(step, timed=False):
-        nl, nm = rates[step % len(rates)]
-        timed = timed and rank == 0
-        eng.enable_timing(timed)
-        if not multi:
-            score, fz = eng.get_posterior(nl, nm, prior)
-            if timed:
-                kernel_ms.append(list(eng.last_kernel_ms()) + [eng.last_tables_ms()])
-            return score
-        eng.eval_posterior_async(nl, nm, prior, p_chunks, p_fz)
-        # the one exchange step: a single RCCL all_gather of (chunk sums, first-zero index) per rank
-        t_x = time.perf_counter()
-        score, fz = D.exchange_packed(dist, torch, packed, gathered, slots, bounds, gathered_host, engine=eng)
-        exchange_s[0] += time.perf_counter() - t_x
-        exchange_s[1] += 1
+def turnover_workload(config):
+    """The config's tree and size with families simulated at 2.5x its rate: sibling lineages diverge, far fewer rows
+    agree on the counts below a node, so subtree-state compression finds much less to share."""
+    import cafe_amd
+    from cafe_amd import prior as cprior
+    from cafe_amd import synth
+    from cafe_amd import tree as ctree
+    cfg = dict(synth.CONFIGS[config])
+    cfg["lam"] *= 2.5
+    if cfg["mu"] >= 0:
+        cfg["mu"] *= 2.5
+    newick = synth.random_ultrametric_newick(cfg["n_taxa"], cfg.get("tree_seed", cfg["seed"]))
+    tree = ctree.CafeTree(newick)
+    rng = cafe_amd.init_family_size(cfg["m"])
+    counts = synth.simulate_families(tree, cfg["F"], cfg["m"], cfg["lam"], cfg["mu"], cfg["seed"] + 501)
+    prior = cprior.prior_rfsize_poisson(rng.root_min, cprior.poisson_lambda_mle(counts))
+    rate_fn = lambda step: synth.node_rates(tree, cfg, 1.0 + 0.003 * (step % 97), 1.0 + 0.002 * (step % 89))
+    return Workload(config + "-turnover", tree, newick, counts, [(0, len(counts))], len(counts), rng, prior, cfg, rate_fn,
+                    cfg["desc"] + ", simulated at 2.5x the rate (little shared subtree state)")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one timed leg
+# ---------------------------------------------------------------------------------------------------------------------
+class Leg:
+    """Engine + workload + the timed loop of the contract (W warm-up steps, K timed steps between barriers,
+    max over ranks)."""
+
+    def __init__(self, wl, local_rank, comm, shared_engine=None):
+        import cafe_amd
+        self.wl, self.comm = wl, comm
+        self.kernel_ms = []
+        if shared_engine is None:
+            self.eng = cafe_amd.Engine(local_rank)
+        else:
+            self.eng = shared_engine
+        eng = self.eng
+        t0 = time.perf_counter()
+        wl.tree.apply(eng)
+        t1 = time.perf_counter()
+        eng.set_families(wl.counts, wl.rng)
+        t2 = time.perf_counter()
+        if wl.cfg.get("error_model"):
+            from cafe_amd import synth
+            eng.set_error_model(synth.banded_error_matrix(wl.rng.max))
+        t3 = time.perf_counter()
+        if comm and comm["kind"] == "native":
+            eng.comm_set_blocks(wl.bounds)
+        self.setup = {"set_tree_ms": 1e3 * (t1 - t0), "set_families_ms": 1e3 * (t2 - t1), "set_error_model_ms": 1e3 * (t3 - t2),
+                      "set_families_detail_ms": eng.last_setup_ms(),
+                      "what": "one-time set-up of this table (host wall-clock; SURVEY.md 8(d): reported apart from the evaluations): "
+                              "duplicate-row detection, subtree-state compression plan (state numbering, tiles, upload), uploads "
+                              "and allocations; the first evaluations after it also time the candidate wave grids (priming)"}
+        self.n_extra = MIN_KERNEL_SAMPLES
+        self.rates = None
+
+    def prepare_rates(self, n):
+        self.rates = [self.wl.rate_fn(s) for s in range(n)]
+
+    def step(self, i, timed=False):
+        nl, nm = self.rates[i % len(self.rates)]
+        eng = self.eng
         if timed:
-            kernel_ms.append(list(eng.last_kernel_ms()) + [eng.last_tables_ms()])  # the exchange has synchronised the stream
+            eng.enable_timing(True)
+        if self.comm is None:
+            score, fz = eng.get_posterior(nl, nm, self.wl.prior)
+        elif self.comm["kind"] == "native":
+            score, fz = eng.get_posterior_sharded(nl, nm, self.wl.prior)
+        else:
+            score = self.comm["torch_step"](eng, nl, nm, self.wl.prior)
+        if timed:
+            self.kernel_ms.append(list(eng.last_kernel_ms()) + [eng.last_tables_ms(), eng.comm_info()["exchange_ms"] if self.comm else 0.0])
+            eng.enable_timing(False)
         return score
 
-    def barrier():
-        if multi:
-            dist.barrier()
+    def barrier(self):
+        import torch
+        if self.comm is not None:
+            self.comm["barrier"](self.eng)
         torch.cuda.synchronize()
 
-    # engine priming (not part of the W warm-up steps the caller asked for): the first launches after set-up
-    # allocate the scratch buffers, measure the K2 wave grids (up to ~30 evaluations) and run while the GPU is still
-    # leaving its idle power state -- at least 40 evaluations and at least 0.25 s of them
-    # (with several ranks every step contains a collective, so the count must be the same everywhere: fixed)
-    PRIMING = 0
-    t_prime = time.perf_counter()
-    n_prime_multi = 1000 if F_local <= 20000 else 60
-    while (PRIMING < n_prime_multi) if multi else (PRIMING < 40 or time.perf_counter() - t_prime < 0.25):
-        one_step(PRIMING)
-        PRIMING += 1
-    last = None
-    for s in range(args.warmup):
-        last = one_step(s)
-    kernel_ms.clear()
-    exchange_s[0], exchange_s[1] = 0.0, 0
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        last = one_step(args.warmup + s, timed=(s % TIMING_EVERY == 0))
-    barrier()
-    dt = time.perf_counter() - t0
-    exchange_ms = 1000.0 * exchange_s[0] / max(exchange_s[1], 1)
-    samples_in_region = len(kernel_ms)
-    extra = 0
-    while rank == 0 and len(kernel_ms) < MIN_KERNEL_SAMPLES and not multi:
-        one_step(args.warmup + args.steps + extra, timed=True)
-        extra += 1
-    if multi:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def prime(self, fixed_count=None):
+        """Untimed evaluations before the W warm-up steps: scratch allocation, the library's measured choice of the K2
+        wave grid (up to ~30 evaluations) and the clock ramp -- at least 40 evaluations and 0.25 s of them (with several
+        ranks every step contains an exchange, so the count must be the same everywhere: fixed)."""
+        n, t0 = 0, time.perf_counter()
+        while (n < fixed_count) if fixed_count else (n < 40 or time.perf_counter() - t0 < 0.25):
+            self.step(n)
+            n += 1
+        self.priming_steps, self.priming_ms = n, 1e3 * (time.perf_counter() - t0)
+        return n
 
-    total_families = F_total
-    value = total_families * args.steps / dt
-    idx = cfg["baseline_index"]
-    shard_note = " (one GPU's shard of the 500k-family table)" if args.config == "cfg4" and args.scaling == "weak" else ""
-    out = {
-        "metric": "family-likelihood evals/sec (full tree)",
-        "value": value,
-        "unit": "family-evals/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1000.0 * dt / args.steps,
-        "higher_is_better": True,
-        "scaling": args.scaling,
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {
-            "workload": "BASELINE.json configs[%d]%s: %s; %d families per GPU, R=%d root sizes, %dx%d matrices, "
-                        "%d edges, one objective evaluation (matrix build + pruning + posterior + score) per step"
-                        % (idx, shard_note, cfg["desc"], F_local, R, C, C, 2 * tree.n_leaves - 2),
-            "baseline_config_index": idx,
-            "families_per_gpu": F_local,
-            "families_total": F_total,
-            "n_taxa": cfg["n_taxa"],
-            "max_family_size": cfg["m"],
-            "parallelism": "families sharded x%d" % world,
-            "priming_steps_before_warmup": PRIMING,
-            "priming_note": "untimed evaluations before the W warm-up steps: scratch allocation, the library's "
-                            "measured choice of the K2 wave grid (~15-20 ordinary evaluations) and the clock ramp",
-            "last_score": last,
+    def run(self, warmup, steps, timing_every=8, rank=0):
+        last = None
+        for s in range(warmup):
+            last = self.step(s)
+        self.kernel_ms.clear()
+        self.barrier()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            last = self.step(warmup + s, timed=(rank == 0 and s % timing_every == 0))
+        self.barrier()
+        dt = time.perf_counter() - t0
+        self.samples_in_region = len(self.kernel_ms)
+        return dt, last
+
+    def extra_kernel_samples(self, start):
+        extra = 0
+        while len(self.kernel_ms) < MIN_KERNEL_SAMPLES:
+            self.step(start + extra, timed=True)
+            extra += 1
+
+
+def roofline_of(leg, F_local):
+    """roofline of the dominant kernel (the family walk) + factor tables + all pruning, from the leg's HIP-event samples."""
+    wl, eng = leg.wl, leg.eng
+    km = np.array(leg.kernel_ms)  # columns: K1 matrix build, K2 pruning+posterior (tables + walk), K3 score, tables alone, exchange
+    k2_ms = float(km[:, 1].mean())
+    tables_ms = float(km[:, 3].mean())
+    walk_ms = k2_ms - tables_ms
+    desc = eng.describe()
+    nf = int(re.search(r"NF=(\d+)", desc).group(1))
+    grid = (F_local + nf - 1) // nf
+    tree, R, C = wl.tree, wl.R, wl.C
+    n_el = algorithmic_elements_per_family(tree.n_leaves, R, C)
+    issued, useful = issued_mfma_flops_per_family(tree, R, C)
+    # every workgroup issues the matrix instructions of NF family slots, filled or not.  The library reports what the
+    # last evaluation issued: the family walk (of the REDUCED tree when the table compresses) and the factor tables of
+    # the compressed subtrees (cafehip_last_issued_flops); without compression the walk figure must equal the tree formula
+    walk_fl, table_fl = eng.last_issued_flops()
+    compressed = table_fl > 0
+    if not compressed and "k2:v1" not in desc and abs(walk_fl - issued * grid * nf) > 1e-9 * walk_fl:
+        raise SystemExit("issued-flop accounting: library %.6g vs tree formula %.6g" % (walk_fl, issued * grid * nf))
+    achieved = walk_fl / (walk_ms * 1e-3) / 1e12
+    frac = achieved / FP64_PEAK_TFLOPS
+    total_frac = (walk_fl + table_fl) / (k2_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+    if not (frac <= 1.0 and total_frac <= 1.0):
+        raise SystemExit("roofline fraction %.3f / %.3f > 1: the flop accounting is wrong" % (frac, total_frac))
+    step_ms = float(km[:, 0].mean() + k2_ms + km[:, 2].mean())
+    roof = {
+        "bound": "mfma",
+        "kernel": "k2_prune_mfma4 (v_mfma_f64_4x4x4_4b)" if "mfma4x4" in desc else "k2_prune_mfma (v_mfma_f64_16x16x4)",
+        "kernel_does": "the family walk: pruning of all families + posterior in one launch" +
+                       (" over the REDUCED tree (compressed subtrees are row gathers from factor tables built by "
+                        "the k2c_nodes launches just before it: see factor_tables / pruning_total)" if compressed else ""),
+        "achieved": achieved,
+        "peak": FP64_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": frac,
+        "flops_counted": "matrix-instruction flops ISSUED by the launch, tile padding included: products on internal "
+                         "child edges only (one-hot leaf edges and compressed subtrees are gathers), roundup16(rows) x "
+                         "roundup4(C) per product, NF family slots per workgroup x %d workgroups" % grid,
+        "issued_flops_per_launch": walk_fl,
+        "avg_launch_ms": walk_ms,
+        "launch_samples": len(km),
+        "launch_samples_in_timed_region": leg.samples_in_region,
+        "launch_samples_note": "HIP events on every 8th timed step; the rest (up to %d) on extra steps right after the region"
+                               % MIN_KERNEL_SAMPLES if leg.samples_in_region < MIN_KERNEL_SAMPLES else "all inside the timed region",
+        "min_launch_ms": float((km[:, 1] - km[:, 3]).min()),
+        "max_launch_ms": float((km[:, 1] - km[:, 3]).max()),
+        "families_per_launch": F_local,
+        "factor_tables": None if not compressed else {
+            "kernel": "k2c_nodes (v_mfma_f64_16x16x4): one launch per compression level, 16 states per workgroup",
+            "launches_per_evaluation": int(re.search(r"levels=(\d+)", desc).group(1)),
+            "states": int(re.search(r"states=(\d+)", desc).group(1)),
+            "ms_per_evaluation": tables_ms,
+            "issued_flops": table_fl,
+            "achieved_TFLOP/s": table_fl / (tables_ms * 1e-3) / 1e12,
+            "frac": table_fl / (tables_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
         },
+        "pruning_total": {
+            "what": "all pruning launches of one evaluation (factor tables + walk), HIP events around them",
+            "ms": k2_ms,
+            "issued_flops": walk_fl + table_fl,
+            "achieved_TFLOP/s": (walk_fl + table_fl) / (k2_ms * 1e-3) / 1e12,
+            "frac": total_frac,
+            "uncompressed_walk_would_issue": issued * grid * nf,
+            "work_saved_by_subtree_state_compression": 1.0 - (walk_fl + table_fl) / (issued * grid * nf),
+        },
+        "whole_evaluation": {
+            "what": "K1 + all pruning + K3 (HIP events, launch gaps inside each group included): issued matrix-instruction "
+                    "flops of the evaluation over that time",
+            "ms": step_ms,
+            "frac": (walk_fl + table_fl) / (step_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+        },
+        "useful_flops_per_launch": useful * F_local,
+        "useful_flops_note": "exact rows x C for every internal edge and family, i.e. what an uncompressed walk without "
+                             "tile padding executes; with compression fewer are executed, so the two rates below are "
+                             "NOT utilisations",
+        "useful_TFLOP/s": useful * F_local / (k2_ms * 1e-3) / 1e12,
+        "useful_frac": useful * F_local / (k2_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
     }
-    if multi:
-        out["rccl_ranks"] = dist.get_world_size()
-        out["backend"] = backend
-        out["exchange_ms_per_step"] = exchange_ms
-
-    if rank == 0 and kernel_ms:
-        km = np.array(kernel_ms)  # columns: K1 matrix build, K2 pruning+posterior (tables + walk), K3 score, tables alone
-        k2_ms = float(km[:, 1].mean())
-        tables_ms = float(km[:, 3].mean())
-        walk_ms = k2_ms - tables_ms
-        desc = eng.describe()
-        nf = int(re.search(r"NF=(\d+)", desc).group(1))
-        grid = (F_local + nf - 1) // nf
-        n_el = algorithmic_elements_per_family(tree.n_leaves, R, C)
-        issued, useful = issued_mfma_flops_per_family(tree, R, C)
-        # every workgroup issues the matrix instructions of NF family slots, filled or not.  The library reports
-        # what the last evaluation issued: the family walk (of the REDUCED tree when the table compresses) and the
-        # factor tables of the compressed subtrees (cafehip_last_issued_flops); without compression the walk figure
-        # must equal the tree formula above
-        walk_fl, table_fl = eng.last_issued_flops()
-        compressed = table_fl > 0
-        if not compressed and abs(walk_fl - issued * grid * nf) > 1e-9 * walk_fl:
-            raise SystemExit("issued-flop accounting: library %.6g vs tree formula %.6g" % (walk_fl, issued * grid * nf))
-        achieved = walk_fl / (walk_ms * 1e-3) / 1e12
-        frac = achieved / FP64_PEAK_TFLOPS
-        total_frac = (walk_fl + table_fl) / (k2_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
-        if not (frac <= 1.0 and total_frac <= 1.0):
-            raise SystemExit("roofline fraction %.3f / %.3f > 1: the flop accounting is wrong" % (frac, total_frac))
-        out["roofline"] = {
-            "bound": "mfma",
-            "kernel": "k2_prune_mfma4 (v_mfma_f64_4x4x4_4b)" if "mfma4x4" in desc else "k2_prune_mfma (v_mfma_f64_16x16x4)",
-            "kernel_does": "the family walk: pruning of all families + posterior in one launch" +
-                           (" over the REDUCED tree (compressed subtrees are row gathers from factor tables built by "
-                            "the k2c_nodes launches just before it: see factor_tables / pruning_total)" if compressed else ""),
-            "achieved": achieved,
-            "peak": FP64_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": frac,
-            "flops_counted": "matrix-instruction flops ISSUED by the launch, tile padding included: products on internal "
-                             "child edges only (one-hot leaf edges and compressed subtrees are gathers), roundup16(rows) x "
-                             "roundup4(C) per product, NF family slots per workgroup x %d workgroups" % grid,
-            "issued_flops_per_launch": walk_fl,
-            "avg_launch_ms": walk_ms,
-            "launch_samples": len(kernel_ms),
-            "launch_samples_in_timed_region": samples_in_region,
-            "min_launch_ms": float((km[:, 1] - km[:, 3]).min()),
-            "max_launch_ms": float((km[:, 1] - km[:, 3]).max()),
-            "families_per_launch": F_local,
-            "factor_tables": None if not compressed else {
-                "kernel": "k2c_nodes (v_mfma_f64_16x16x4): one launch per compression level, 16 states per workgroup",
-                "launches_per_evaluation": int(re.search(r"levels=(\d+)", desc).group(1)),
-                "states": int(re.search(r"states=(\d+)", desc).group(1)),
-                "ms_per_evaluation": tables_ms,
-                "issued_flops": table_fl,
-                "achieved_TFLOP/s": table_fl / (tables_ms * 1e-3) / 1e12,
-                "frac": table_fl / (tables_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-            },
-            "pruning_total": {
-                "what": "all pruning launches of one evaluation (factor tables + walk), HIP events around them",
-                "ms": k2_ms,
-                "issued_flops": walk_fl + table_fl,
-                "achieved_TFLOP/s": (walk_fl + table_fl) / (k2_ms * 1e-3) / 1e12,
-                "frac": total_frac,
-                "uncompressed_walk_would_issue": issued * grid * nf,
-                "work_saved_by_subtree_state_compression": 1.0 - (walk_fl + table_fl) / (issued * grid * nf),
-            },
-            "useful_flops_per_launch": useful * F_local,
-            "useful_flops_note": "exact rows x C for every internal edge and family, i.e. what an uncompressed walk without "
-                                 "tile padding executes; with compression fewer are executed, so the two rates below are "
-                                 "NOT utilisations",
-            "useful_TFLOP/s": useful * F_local / (k2_ms * 1e-3) / 1e12,
-            "useful_frac": useful * F_local / (k2_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-        }
-        out["roofline"].update(pmc_traffic(args.config, F_local))
-        # SURVEY.md 8(d)'s reference-faithful accounting (a dense product on EVERY child edge, as the CPU path
-        # executes it): kept for continuity, NOT a utilisation -- most of these flops/bytes are never issued/moved
-        out["algorithmic_credit"] = {
-            "what": "SURVEY.md 8(d) F_alg = 2*N_el flops and B_alg = 8*N_el bytes per family evaluation: what the "
-                    "reference's per-family dense mat-vecs execute/stream; a rate comparable with the CPU path, "
-                    "not a fraction of any hardware peak",
-            "N_el_per_family": n_el,
-            "F_alg_TFLOP/s": 2.0 * n_el * F_local / (k2_ms * 1e-3) / 1e12,
-            "B_alg_effective_GB/s": 8.0 * n_el * F_local / (k2_ms * 1e-3) / 1e9,
-        }
-        out["kernel_ms"] = {"k1_matrix_build": float(km[:, 0].mean()), "k2_prune": k2_ms,
-                            "k3_score": float(km[:, 2].mean())}
-        out["engine"] = desc
-
-    if rank == 0 and not args.no_probes:
-        out["roofline_measured_peaks"] = measured_peaks(local_rank)
-        if "roofline" in out and out["roofline_measured_peaks"].get("mfma_f64_4x4x4_TFLOP/s"):
-            mp = out["roofline_measured_peaks"]
-            key = "mfma_f64_4x4x4_TFLOP/s" if "mfma4x4" in out["engine"] else "mfma_f64_16x16x4_TFLOP/s"
-            out["roofline"]["frac_of_measured_register_only_ceiling"] = out["roofline"]["achieved"] / mp[key]
-
-    if rank == 0 and world == 1 and args.config == "cfg5":
-        out["mc_null"] = mc_null_leg(eng, tree, cfg, rng, torch)
-
-    if rank == 0 and world == 1 and not args.no_search:
-        out["lambda_search"] = lambda_search_wallclock(newick, counts, tree, cfg, rng)
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(newick, counts, rng, prior, cfg, eng, tree)
-
-    if rank == 0:
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    eng.close()
-    if multi:
-        dist.destroy_process_group()
+    credit = {
+        "what": "SURVEY.md 8(d) F_alg = 2*N_el flops and B_alg = 8*N_el bytes per family evaluation: what the "
+                "reference's per-family dense mat-vecs execute/stream; a rate comparable with the CPU path, "
+                "not a fraction of any hardware peak",
+        "N_el_per_family": n_el,
+        "F_alg_TFLOP/s": 2.0 * n_el * F_local / (k2_ms * 1e-3) / 1e12,
+        "B_alg_effective_GB/s": 8.0 * n_el * F_local / (k2_ms * 1e-3) / 1e9,
+    }
+    kms = {"k1_matrix_build": float(km[:, 0].mean()), "k2_prune": k2_ms, "k3_score": float(km[:, 2].mean())}
+    return roof, credit, kms, desc
 
 
-def pmc_traffic(config, families, kernel="k2"):
+def minimal_traffic_bytes(wl, eng_desc, F_local, batch_rows=None):
+    """What one launch of the dominant kernel inherently has to move through HBM once: the index table of
+    the walk, ONE copy of every matrix it multiplies or gathers, the factor tables it gathers from and its outputs."""
+    tree, R, C = wl.tree, wl.R, wl.C
+    S = max(wl.rng.max, wl.rng.root_max) + 1
+    LD = 16 * ((S + 15) // 16) + 16
+    KP = 4 * ((S + 3) // 4)
+    nkeys = int(re.search(r"nkeys=(\d+)", eng_desc).group(1))
+    matrices = nkeys * KP * LD * 8
+    m = re.search(r"states=(\d+).*walk_cols=(\d+)", eng_desc)
+    if batch_rows:
+        return {"counts_index": batch_rows * (tree.n_leaves + 3) * 4, "matrices_once": matrices, "outputs": batch_rows * 8,
+                "total": batch_rows * (tree.n_leaves + 3) * 4 + matrices + batch_rows * 8}
+    if m and "used=1" in eng_desc:
+        states, cols = int(m.group(1)), int(m.group(2))
+        tables = states * LD * 8
+        idx = F_local * cols * 4
+    else:
+        tables, idx = 0, F_local * tree.n_leaves * 4
+    outputs = F_local * (8 + 8 + 4)
+    return {"counts_index": idx, "matrices_once": matrices, "factor_tables_read_once": tables, "outputs": outputs,
+            "total": idx + matrices + tables + outputs,
+            "factor_tables_build": {"write_once": tables, "matrices_once": matrices, "total": tables + matrices}}
+
+
+def pmc_traffic(config, families, kernel="k2", minimal=None):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (collected in their own runs -- the
-    counters cannot be read from inside bench.py -- by tools/collect_pmc.py; FETCH_SIZE x2 gfx950 correction,
-    /opt/skills/guides/MI355X_MICROARCH.md section HBM)."""
-    try:
-        rec = json.load(open(TRAFFIC_FILE))["%s:%d:%s" % (config, families, kernel)]
-        return {"traffic": rec["traffic_bytes"], "traffic_unit": "bytes per launch, HBM side: 2 x FETCH_SIZE + WRITE_SIZE",
-                "factor_tables_traffic": rec.get("tables_traffic_bytes"),
-                "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) + " (" + rec.get("note", "") + ")",
-                "traffic_minimal_bytes": rec.get("minimal_bytes")}
-    except Exception:
-        return {"traffic": None, "traffic_source": "no PMC record for %s with %d families per launch" % (config, families)}
+    counters cannot be read from inside bench.py -- by tools/collect_pmc.py; FETCH_SIZE x the factor calibrated on a
+    known-bytes probe with this kernel's access pattern, tools/gather_probe.hip / profiles/r03_fetch_size_calibration.txt)."""
+    for path in TRAFFIC_FILES:
+        try:
+            rec = json.load(open(path))["%s:%d:%s" % (config, families, kernel)]
+        except Exception:
+            continue
+        out = {"traffic": rec["traffic_bytes"], "traffic_unit": "bytes per launch, fabric side: %s x FETCH_SIZE + WRITE_SIZE"
+               % rec.get("fetch_factor", 2), "factor_tables_traffic": rec.get("tables_traffic_bytes"),
+               "traffic_source": os.path.relpath(path, ROOT) + " (" + rec.get("note", "") + ")"}
+        if minimal:
+            out["traffic_minimal_bytes"] = minimal["total"]
+            out["traffic_minimal_breakdown"] = minimal
+            out["traffic_over_minimal"] = rec["traffic_bytes"] / minimal["total"]
+            if rec.get("tables_traffic_bytes") and minimal.get("factor_tables_build"):
+                out["factor_tables_traffic_over_minimal"] = rec["tables_traffic_bytes"] / minimal["factor_tables_build"]["total"]
+        return out
+    out = {"traffic": None, "traffic_source": "no PMC record for %s with %d families per launch" % (config, families)}
+    if minimal:
+        out["traffic_minimal_bytes"] = minimal["total"]
+        out["traffic_minimal_breakdown"] = minimal
+    return out
 
 
 def measured_peaks(device):
@@ -425,16 +444,333 @@ def measured_peaks(device):
     return out
 
 
-def mc_null_leg(eng, tree, cfg, rng, torch):
+# ---------------------------------------------------------------------------------------------------------------------
+# main
+# ---------------------------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--table", choices=("synthetic", "test1", "turnover"), default="synthetic",
+                    help="headline table: the config's synthetic one (default), the reference's test1 table, or the "
+                         "config simulated at 2.5x the rate (1 GPU only for the last two)")
+    ap.add_argument("--families", type=int, default=None, help="families per GPU (default: the config's)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the table per GPU is fixed; strong: ONE table (the config's F, 500k for cfg4) split over the GPUs")
+    ap.add_argument("--comm", choices=("native", "torch"), default="native",
+                    help="multi-rank exchange: the library's own (cafehip_eval_posterior_sharded) or torch.distributed all_gather")
+    ap.add_argument("--comm-mode", choices=("auto", "direct", "rccl"), default="auto", help="cafehip option comm (native only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-search", action="store_true", help="skip the lambda-search wall-clock leg")
+    ap.add_argument("--no-probes", action="store_true", help="skip the measured HBM / MFMA ceilings")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (configs[3]'s 500k-family table)")
+    ap.add_argument("--no-tables", action="store_true", help="skip the test1 / high-turnover table legs")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend of --comm torch (default nccl = RCCL; gloo with --same-device)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: take the multi-rank code path (communicator + exchange) even with 1 rank")
+    ap.add_argument("--same-device", action="store_true",
+                    help="debug: all ranks share GPU 0 (functional check of the N>1 path on a 1-GPU box)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    # the contract is ONE JSON line on stdout: whatever libraries print to file descriptor 1 meanwhile (the host
+    # driver echoes some commands with printf) is sent to stderr, and the line is written to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    multi = world > 1 or args.force_dist
+    if args.table != "synthetic" and multi:
+        raise SystemExit("--table %s is a 1-GPU leg" % args.table)
+
+    import cafe_amd
+    from cafe_amd import distributed as D
+    from cafe_amd import synth
+
+    comm = None
+    comm_id = None
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if args.comm == "native":
+            # torch.distributed only hands out the communicator id, BEFORE the timed region (gloo: no device involved);
+            # everything inside it -- exchange, barriers, the max over ranks -- is the library's own
+            dist.init_process_group(backend="gloo")
+            box = [os.urandom(128) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm_id = box[0]
+
+            def native_barrier(eng):
+                eng.comm_allgather(b"\0" * 8, 8)
+            comm = {"kind": "native", "barrier": native_barrier}
+        else:
+            backend = args.backend or ("gloo" if args.same_device else "nccl")
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend=backend)
+            comm = {"kind": "torch", "backend": backend, "barrier": lambda eng: dist.barrier()}
+
+    # ---- headline workload ----------------------------------------------------------------------------------------
+    if args.table == "test1":
+        wl = test1_workload()
+    elif args.table == "turnover":
+        wl = turnover_workload(args.config)
+    else:
+        wl = synthetic_workload(args.config, rank, world, args.scaling, args.families,
+                                same_table_blocks=8 if (args.scaling == "strong" and 8 % world == 0) else 0)
+    F_local = len(wl.counts)
+    eng = cafe_amd.Engine(local_rank)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+    if multi and args.comm == "native":
+        eng.set_option("comm", args.comm_mode)
+        eng.comm_init(rank, world, comm_id)
+    leg = Leg(wl, local_rank, comm, shared_engine=eng)
+    if multi and args.comm == "torch":
+        slots = max(1, max((hi - lo + D.CHUNK - 1) // D.CHUNK for lo, hi in wl.bounds))
+        packed, p_chunks, p_fz = D.packed_buffer(torch, slots, "cuda")
+        gathered = torch.zeros((slots + 1) * world, dtype=torch.float64, device="cuda")
+
+        def torch_step(e, nl, nm, prior):
+            e.eval_posterior_async(nl, nm, prior, p_chunks, p_fz)
+            score, fz = D.exchange_packed(dist, torch, packed, gathered, slots, wl.bounds, None, engine=e)
+            return score
+        comm["torch_step"] = torch_step
+
+    leg.prepare_rates(args.warmup + args.steps + MIN_KERNEL_SAMPLES)
+    priming = leg.prime(fixed_count=(1000 if F_local <= 20000 else 60) if multi else None)
+    dt, last = leg.run(args.warmup, args.steps, rank=rank)
+    if multi:
+        if args.comm == "native":
+            slots8 = eng.comm_allgather(np.float64(dt).tobytes(), 8)
+            dt = max(float(np.frombuffer(b, np.float64)[0]) for b in slots8)
+        else:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+    if rank == 0 and not multi:
+        leg.extra_kernel_samples(args.warmup + args.steps)
+
+    idx = wl.cfg.get("baseline_index")
+    shard_note = " (one GPU's shard of the 500k-family table)" if args.config == "cfg4" and args.scaling == "weak" and args.table == "synthetic" else ""
+    out = {
+        "metric": "family-likelihood evals/sec (full tree)",
+        "value": wl.F_total * args.steps / dt,
+        "unit": "family-evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic" if args.table != "test1" else "reference test table (tests/golden/test1_families.txt.gz)",
+        "config": {
+            "workload": ("BASELINE.json configs[%d]%s: " % (idx, shard_note) if idx is not None and args.table == "synthetic" else "") +
+                        "%s; %d families per GPU, R=%d root sizes, %dx%d matrices, %d edges, one objective evaluation "
+                        "(matrix build + pruning + posterior + score) per step"
+                        % (wl.desc, F_local, wl.R, wl.C, wl.C, 2 * wl.tree.n_leaves - 2),
+            "baseline_config_index": idx,
+            "table": args.table,
+            "families_per_gpu": F_local,
+            "families_total": wl.F_total,
+            "n_taxa": wl.tree.n_leaves,
+            "max_family_size": wl.cfg["m"],
+            "parallelism": "families sharded x%d" % world,
+            "priming_steps_before_warmup": priming,
+            "priming_note": "untimed evaluations before the W warm-up steps: scratch allocation, the library's "
+                            "measured choice of the K2 wave grid (~15-20 ordinary evaluations) and the clock ramp",
+            "last_score": last,
+        },
+    }
+    if rank == 0:
+        setup = dict(leg.setup)
+        setup["priming_evaluations"] = priming
+        setup["priming_ms"] = leg.priming_ms
+        out["setup_ms"] = setup
+    if multi:
+        info = eng.comm_info() if args.comm == "native" else {}
+        out["rccl_ranks"] = world
+        out["comm"] = args.comm
+        if rank == 0:
+            out["exchange"] = exchange_report(args, leg, eng, info, wl, rank, world) if args.comm == "native" else \
+                {"mode": "torch.distributed " + comm["backend"], "note": "round-2 path: packed all_gather through torch + cafehip_fetch_small"}
+        elif args.comm == "native":
+            exchange_report(args, leg, eng, info, wl, rank, world)   # the RCCL comparison steps are collective
+
+    if rank == 0 and leg.kernel_ms:
+        roof, credit, kms, desc = roofline_of(leg, F_local)
+        minimal = minimal_traffic_bytes(wl, desc, F_local)
+        roof.update(pmc_traffic(args.config if args.table == "synthetic" else wl.name, F_local, minimal=minimal))
+        out["roofline"] = roof
+        out["algorithmic_credit"] = credit
+        out["kernel_ms"] = kms
+        out["engine"] = desc
+
+    if rank == 0 and not args.no_probes:
+        out["roofline_measured_peaks"] = measured_peaks(local_rank)
+        if "roofline" in out and out["roofline_measured_peaks"].get("mfma_f64_4x4x4_TFLOP/s"):
+            mp = out["roofline_measured_peaks"]
+            key = "mfma_f64_4x4x4_TFLOP/s" if "mfma4x4" in out["engine"] else "mfma_f64_16x16x4_TFLOP/s"
+            out["roofline"]["frac_of_measured_register_only_ceiling"] = out["roofline"]["achieved"] / mp[key]
+
+    # ---- strong scaling on configs[3]'s table: the SAME 8-block table for every N (all ranks take part) ----------------
+    if not args.no_strong and args.table == "synthetic" and args.config == "cfg2" and 8 % world == 0:
+        out_strong = strong_leg(args, eng, comm, rank, world, local_rank)
+        if rank == 0:
+            out["strong_scaling"] = out_strong
+
+    if rank == 0 and world == 1 and not multi and args.table == "synthetic" and args.config == "cfg5":
+        out["mc_null"] = mc_null_leg(eng, wl)
+
+    if rank == 0 and world == 1 and not multi and not args.no_tables and args.table == "synthetic" and args.config == "cfg2":
+        out["tables"] = {"what": "the same measurement on tables whose compressibility is not the generator's: headline robustness "
+                                 "(VERDICT r02: 61-72 % of the matrix work of the bench tables disappears by subtree-state compression)"}
+        for name, w2 in (("test1", test1_workload()), ("turnover", turnover_workload(args.config))):
+            out["tables"][name] = table_leg(w2, local_rank)
+
+    if rank == 0 and world == 1 and not multi and not args.no_search and args.table == "synthetic":
+        out["lambda_search"] = lambda_search_wallclock(wl)
+
+    if rank == 0 and world == 1 and not multi and not args.no_cpu_baseline and args.table == "synthetic":
+        out["cpu_baseline"] = cpu_baseline(wl, eng)
+
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    eng.close()
+    if multi:
+        dist.destroy_process_group()
+
+
+def exchange_report(args, leg, eng, info, wl, rank, world):
+    """The exchange step on its own (all ranks run this: the comparison steps are collective).  direct mode: the exchange is
+    part of the score kernel, so its cost is that kernel's HIP-event duration minus the plain score kernel's (measured on
+    this rank's block without a communicator path: cafehip_eval_posterior).  Then the same steps with one
+    ncclAllGather behind the score kernel (option comm=rccl), exchange timed with HIP events on the stream."""
+    km = np.array(leg.kernel_ms) if leg.kernel_ms else None
+    rep = {"mode": info.get("mode"), "ranks": world}
+    # plain score kernel on this block
+    eng.enable_timing(True)
+    plain = []
+    for s in range(8):
+        nl, nm = leg.rates[s]
+        eng.get_posterior(nl, nm, wl.prior)
+        plain.append(eng.last_kernel_ms()[2])
+    eng.enable_timing(False)
+    k3_plain = float(np.mean(plain[2:]))
+    if km is not None:
+        rep["score_kernel_ms"] = float(km[:, 2].mean())
+        rep["score_kernel_single_gpu_ms"] = k3_plain
+        if info.get("mode") == "direct":
+            rep["exchange_ms_per_step"] = max(0.0, rep["score_kernel_ms"] - k3_plain)
+            rep["how"] = "direct: every rank's score kernel stores its packed row into the other ranks' buffers over xGMI and waits " \
+                         "for theirs; exchange = that kernel's HIP-event duration minus the plain score kernel's on the same block " \
+                         "(includes the skew between ranks)"
+        else:
+            rep["exchange_ms_per_step"] = float(km[:, 4].mean())
+            rep["how"] = "rccl: one ncclAllGather of the packed rows on the context's stream + pick-up kernel, HIP events around them"
+    # the other mode, same steps (RCCL needs one device per rank: skipped with --same-device)
+    if info.get("mode") == "direct" and not args.same_device:
+        try:
+            eng.set_option("comm", "rccl")
+            for s in range(10):
+                leg.step(s)
+            n, t0 = 50, None
+            ex = []
+            leg.barrier()
+            t0 = time.perf_counter()
+            for s in range(n):
+                nl, nm = leg.rates[s]
+                if s % 5 == 0:
+                    eng.enable_timing(True)
+                eng.get_posterior_sharded(nl, nm, wl.prior)
+                if s % 5 == 0:
+                    ex.append(eng.comm_info()["exchange_ms"])
+                    eng.enable_timing(False)
+            leg.barrier()
+            rep["rccl"] = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / n, "exchange_ms_per_step": float(np.mean(ex)),
+                           "how": "the same steps with option comm=rccl: ncclAllGather + pick-up kernel behind the score kernel, "
+                                  "HIP events on the stream (every 5th of 50 steps)"}
+        except Exception as e:   # RCCL unavailable on this box: the direct mode does not need it
+            rep["rccl"] = {"error": str(e)[:200]}
+        finally:
+            eng.set_option("comm", args.comm_mode)
+    return rep
+
+
+def strong_leg(args, eng, comm, rank, world, local_rank):
+    """BASELINE configs[3] at its stated size: ONE 500k-family table (64 taxa, three lambda classes), the concatenation of 8
+    blocks simulated with per-block seeds -- the same table for N = 1, 2, 4, 8 -- split over the ranks.  Timed like the
+    headline; the driver can compute strong-scaling efficiency from `value` across its N = 1, 2, 4, 8 runs."""
+    w = synthetic_workload("cfg4", rank, world, "strong", None, same_table_blocks=8)
+    leg = Leg(w, local_rank, comm, shared_engine=eng)
+    steps, warm = 30, 3
+    leg.prepare_rates(warm + steps)
+    leg.prime(fixed_count=45 if comm else None)
+    dt, last = leg.run(warm, steps, rank=rank)
+    if comm is not None and comm["kind"] == "native":
+        dt = max(float(np.frombuffer(b, np.float64)[0]) for b in eng.comm_allgather(np.float64(dt).tobytes(), 8))
+    elif comm is not None:
+        import torch
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return {"what": "BASELINE.json configs[3]: 500k families (8 seeded blocks of 62,464; the same table for every N), 64 taxa, "
+                    "3 lambda classes, split over %d GPU(s); one objective evaluation per step" % world,
+            "scaling": "strong", "families_total": w.F_total, "families_per_gpu": len(w.counts), "n_gpus": world,
+            "steps": steps, "ms_per_step": 1e3 * dt / steps, "value": w.F_total * steps / dt, "unit": "family-evals/s",
+            "last_score": last, "setup_ms": leg.setup["set_families_ms"]}
+
+
+def table_leg(w, local_rank):
+    """Headline measurement on another table: evaluations/s, kernel times, roofline with work saved."""
+    leg = Leg(w, local_rank, None)
+    steps, warm = 100, 5
+    leg.prepare_rates(warm + steps + MIN_KERNEL_SAMPLES)
+    priming = leg.prime()
+    dt, last = leg.run(warm, steps)
+    leg.extra_kernel_samples(warm + steps)
+    roof, credit, kms, desc = roofline_of(leg, len(w.counts))
+    res = {"table": w.desc, "families": len(w.counts), "value": len(w.counts) * steps / dt, "unit": "family-evals/s",
+           "ms_per_step": 1e3 * dt / steps, "steps": steps, "kernel_ms": kms,
+           "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "factor_tables", "pruning_total", "whole_evaluation")},
+           "setup_ms": leg.setup["set_families_ms"], "engine": desc, "last_score": last}
+    leg.eng.close()
+    return res
+
+
+def mc_null_leg(eng, wl):
     """BASELINE configs[4] tail: the Monte-Carlo null of the report -- R root sizes x 1000 simulated families
     (get_random_probabilities, cafe/conditional_distribution.cpp:10-44), every one scored with a one-row root
     in ONE batched launch of the pruning kernel (cafehip_eval_root_likelihoods).  Families are simulated here
     with numpy from the device-built matrices (workload generation; the product's host driver draws them in the
     reference's rand() order)."""
-    R = rng.root_max - rng.root_min + 1
-    C = rng.max + 1
-    trials = 1000
     from cafe_amd import synth
+    tree, cfg, rng = wl.tree, wl.cfg, wl.rng
+    R, C = wl.R, rng.max + 1
+    trials = 1000
     nl, nm = synth.node_rates(tree, cfg)
     eng.reset_birthdeath_cache(nl, nm)
     mats = {v: eng.get_matrix(v) for v in range(tree.n_nodes) if v != tree.root}
@@ -451,10 +787,11 @@ def mc_null_leg(eng, tree, cfg, rng, torch):
     eng.enable_timing(False)
     k_ms = float(np.mean(ms[1:]))
     desc = eng.describe()
+    walk_fl, _ = eng.last_issued_flops()
     nf = int(re.search(r"NF=(\d+)", desc).group(1))
     grid = (B + nf - 1) // nf
-    issued, useful = issued_mfma_flops_per_family(tree, R, C)   # the kernel computes all R root rows of a row's tile
-    achieved = issued * grid * nf / (k_ms * 1e-3) / 1e12
+    issued_full, useful = issued_mfma_flops_per_family(tree, R, C)   # an untrimmed launch computes all R root rows of a row's tile
+    achieved = walk_fl / (k_ms * 1e-3) / 1e12
     frac = achieved / FP64_PEAK_TFLOPS
     if not frac <= 1.0:
         raise SystemExit("MC-null roofline fraction %.3f > 1: the flop accounting is wrong" % frac)
@@ -468,48 +805,75 @@ def mc_null_leg(eng, tree, cfg, rng, torch):
         "finite_likelihoods": int(np.isfinite(like).sum()),
         "roofline": {"bound": "mfma", "kernel": "k2_prune_mfma (batch mode)", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": frac, "avg_launch_ms": k_ms, "launch_samples": len(ms) - 1,
-                     "issued_flops_per_launch": issued * grid * nf},
+                     "issued_flops_per_launch": walk_fl,
+                     "untrimmed_launch_would_issue": issued_full * grid * nf,
+                     "work_saved_by_trimming_to_the_column_limits": 1.0 - walk_fl / (issued_full * grid * nf)},
         "engine": desc,
     }
-    out["roofline"].update(pmc_traffic("cfg5", B, "mcnull"))
+    out["roofline"].update(pmc_traffic("cfg5", B, "mcnull", minimal=minimal_traffic_bytes(wl, desc, B, batch_rows=B)))
     return out
 
 
-def lambda_search_wallclock(newick, counts, tree, cfg, rng):
+def lambda_search_wallclock(wl):
     """Second metric of BASELINE.json: wall-clock of the complete `lambda -s` (or `lambdamu -s`) command on
     the bench table through the host driver -- prior fit + Nelder-Mead, every objective call on the GPU
-    (cafe/lambda.cpp:369-515)."""
+    (cafe/lambda.cpp:369-515).  Two runs where the reference's prior fit degenerates (configs[2]/[4]: the forced
+    count == m row underflows poisspdf, cafe/lambda.cpp:771-838, and the fit stalls at its random start): the
+    reference-faithful one, and one whose Poisson prior is fitted WITHOUT that row, so that the search walks to the
+    simulated rates."""
     import tempfile
     from cafe_amd import synth
     from cafe_amd.shell import CafeShell
+    tree, cfg, rng, counts, newick = wl.tree, wl.cfg, wl.rng, wl.counts, wl.newick
     has_mu = cfg["mu"] >= 0
-    with tempfile.TemporaryDirectory() as d:
-        path = os.path.join(d, "families.tab")
-        with open(path, "w") as f:
-            f.write("Desc\tFamily ID\t" + "\t".join(tree.leaf_names) + "\n")
-            for i, row in enumerate(counts):
-                f.write("NA\tF%06d\t" % i + "\t".join(str(int(x)) for x in row) + "\n")
-        sh = CafeShell(0, os.path.join(d, "log.txt"))
-        sh.dispatch("seed 10")
-        sh.dispatch("tree " + newick)
-        sh.dispatch("load -i " + path)
-        if cfg.get("error_model"):
-            em = os.path.join(d, "errormodel.txt")
-            synth.write_error_model_file(em, rng.max)
-            sh.dispatch("errormodel -model %s -all" % em)
-        if has_mu:
-            command = "lambdamu -s"
-        elif cfg.get("n_classes"):
-            command = "lambda -s -t " + synth.clade_classes(tree, cfg["n_classes"])[1]
-        else:
-            command = "lambda -s"
-        t0 = time.perf_counter()
-        sh.dispatch(command)
-        wall = time.perf_counter() - t0
-        res = {"command": command if len(command) < 40 else command[:24] + "<lambda tree>", "wall_s": wall,
-               "search_s": sh.search_seconds, "iterations": sh.iterations, "evaluations": sh.evaluations,
-               "fitted": [float(x) for x in sh.params], "score": sh.score, "poisson_lambda": sh.poisson_lambda}
-        sh.close()
+
+    def run(rows, label):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "families.tab")
+            with open(path, "w") as f:
+                f.write("Desc\tFamily ID\t" + "\t".join(tree.leaf_names) + "\n")
+                for i, row in enumerate(rows):
+                    f.write("NA\tF%06d\t" % i + "\t".join(str(int(x)) for x in row) + "\n")
+            sh = CafeShell(0, os.path.join(d, "log.txt"))
+            sh.dispatch("seed 10")
+            sh.dispatch("tree " + newick)
+            sh.dispatch("load -i " + path)
+            if cfg.get("error_model"):
+                em = os.path.join(d, "errormodel.txt")
+                synth.write_error_model_file(em, rng.max)
+                sh.dispatch("errormodel -model %s -all" % em)
+            if has_mu:
+                command = "lambdamu -s"
+            elif cfg.get("n_classes"):
+                command = "lambda -s -t " + synth.clade_classes(tree, cfg["n_classes"])[1]
+            else:
+                command = "lambda -s"
+            t0 = time.perf_counter()
+            sh.dispatch(command)
+            wall = time.perf_counter() - t0
+            res = {"what": label, "command": command if len(command) < 40 else command[:24] + "<lambda tree>", "wall_s": wall,
+                   "search_s": sh.search_seconds, "prior_fit_and_setup_s": wall - sh.search_seconds,
+                   "iterations": sh.iterations, "evaluations": sh.evaluations,
+                   "fitted": [float(x) for x in sh.params], "score": sh.score, "poisson_lambda": sh.poisson_lambda,
+                   "simulated_rates": [cfg["lam"]] + ([cfg["mu"]] if has_mu else [])}
+            sh.close()
+        return res
+    res = run(counts, "reference-faithful: the table as generated (one forced count == m row pins the ranges)")
+    mle = float((counts[counts > 0] - 1).mean())
+    if abs(res["poisson_lambda"] - mle) > 0.05 * mle:
+        # The prior fit stalled: poisspdf(count - 1, lambda_p) underflows for counts above ~170 at any start in (0, 1), so the
+        # objective is infinite where the search begins.  Same table capped at 150 (rows with a larger count dropped, one
+        # count of 150 forced): max family size 150 instead of %d -- the largest round size the reference's fit survives
+        cap = 150
+        rows = counts[counts.max(axis=1) <= cap].copy()
+        if rows.max() < cap:
+            rows[0, 0] = cap
+        res2 = run(rows, "meaningful prior: rows with a count above %d dropped (%d of %d) and one count of %d forced, so that the "
+                         "reference's Poisson fit converges (mean count - 1 of the table = %.3f); matrices %d wide instead of %d"
+                         % (cap, len(counts) - len(rows), len(counts), cap, mle, cap + max(50, cap // 5) + 1, wl.C))
+        return {"faithful": res, "meaningful_prior": res2,
+                "note": "`faithful` times a search under the prior the reference's fit stalls at; `meaningful_prior` is the "
+                        "wall-clock of a search that converges to the simulated rates"}
     return res
 
 
@@ -524,14 +888,16 @@ def physical_cores():
         return n, n
 
 
-def cpu_baseline(newick, counts, rng, prior, cfg, eng, tree):
+def cpu_baseline(wl, eng):
     """The oracle (CPU restatement of the reference algorithm, dense mat-vec on every edge) built on THIS box
     with -O3 -march=native (SURVEY.md 8d) and timed on its host cores on a bounded sample of the same table;
-    also used to cross-check the GPU values of that sample."""
+    also used to cross-check the GPU values of that sample.  The matrix build (once per evaluation, shared by
+    every family) and the per-family loop are timed separately."""
     os.environ["CAFE_ORACLE_NATIVE"] = "1"   # before the first import of the oracle binding
     from cafe_amd import synth
     from tests import _orc as O
-    t = O.PyTree(newick)
+    tree, cfg, rng, counts, prior = wl.tree, wl.cfg, wl.rng, wl.counts, wl.prior
+    t = O.PyTree(wl.newick)
     orng = O.make_range(rng.min, rng.max, rng.root_min, rng.root_max)
     lam, mu = synth.node_rates(tree, cfg)
     err = synth.banded_error_matrix(rng.max) if cfg.get("error_model") else None
@@ -541,35 +907,44 @@ def cpu_baseline(newick, counts, rng, prior, cfg, eng, tree):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = hw
-    probe = counts[:32]
-    t0 = time.perf_counter()
-    O.eval_posterior(t, probe, orng, lam, mu, prior, nthreads=1, **ekw)
-    per_fam_1t = (time.perf_counter() - t0) / len(probe)
+    # matrix build alone: an evaluation of ONE family is the build + one family; of two, the build + two
+    def timed(n, nt):
+        t0 = time.perf_counter()
+        r = O.eval_posterior(t, counts[:n], orng, lam, mu, prior, nthreads=nt, **ekw)
+        return time.perf_counter() - t0, r
+    t1, _ = timed(1, 1)
+    t33, _ = timed(33, 1)
+    per_fam_1t = max((t33 - t1) / 32.0, 1e-9)
+    build_s = max(t1 - per_fam_1t, 0.0)
     n_1t = int(max(32, min(len(counts), 4.0 / per_fam_1t)))
-    t0 = time.perf_counter()
-    O.eval_posterior(t, counts[:n_1t], orng, lam, mu, prior, nthreads=1, **ekw)
-    rate_1t = n_1t / (time.perf_counter() - t0)
+    tn, _ = timed(n_1t, 1)
+    rate_1t_loop = n_1t / max(tn - build_s, 1e-9)
     # one team per physical core is the stated configuration; the box may cap the process below that
     # (cgroup quota), so smaller teams are tried too and the fastest is reported with its size
     tried = {}
-    n_try = int(max(256, min(len(counts), 2.0 * rate_1t * min(phys, avail) * 0.5)))
+    n_try = int(max(256, min(len(counts), 2.0 * rate_1t_loop * min(phys, avail) * 0.5)))
     for nt in sorted({min(phys, avail), min(hw, avail), 128, 64, 32, 16, 8}, reverse=True):
         if nt > avail or nt < 2:
             continue
-        O.eval_posterior(t, counts[:256], orng, lam, mu, prior, nthreads=nt, **ekw)  # spin the team up, untimed
-        t0 = time.perf_counter()
-        O.eval_posterior(t, counts[:n_try], orng, lam, mu, prior, nthreads=nt, **ekw)
-        tried[nt] = n_try / (time.perf_counter() - t0)
+        timed(256, nt)  # spin the team up, untimed
+        tt, _ = timed(n_try, nt)
+        tried[nt] = n_try / tt
     best_threads = max(tried, key=tried.get) if tried else 1
-    best_rate = tried.get(best_threads, rate_1t)
+    best_rate = tried.get(best_threads, rate_1t_loop)
     n_mt = int(max(256, min(len(counts), 6.0 * best_rate)))
-    rate_mt = 0.0
+    rate_mt, best_t = 0.0, None
     for _ in range(2):
-        t0 = time.perf_counter()
-        so, fzo, mlo, amo, mpo = O.eval_posterior(t, counts[:n_mt], orng, lam, mu, prior, nthreads=best_threads, **ekw)
-        rate_mt = max(rate_mt, n_mt / (time.perf_counter() - t0))
+        tt, r = timed(n_mt, best_threads)
+        if n_mt / tt > rate_mt:
+            rate_mt, best_t = n_mt / tt, tt
+        so, fzo, mlo, amo, mpo = r
+    # the team builds the matrices too (one key per thread): its build time is an evaluation of ONE family
+    build_mt = min(timed(1, best_threads)[0] for _ in range(3))
     # parity of the same sample on the GPU
+    tree.apply(eng)   # (another leg may have left its tree on the engine)
     eng.set_families(counts[:n_mt], rng)
+    if err is not None:
+        eng.set_error_model(err)
     sg, fzg, mlg, amg, mpg = eng.get_posterior(lam, mu, prior, per_family=True)
     rel = float(np.max(np.abs(np.log(mpg) - np.log(mpo)) / np.abs(np.log(mpo))))
     return {
@@ -582,10 +957,15 @@ def cpu_baseline(newick, counts, rng, prior, cfg, eng, tree):
         "kind": "port",
         "build": "oracle/cafe_oracle.c, gcc -O3 -march=native -ffp-contract=off -fopenmp, built on this box",
         "sample": "one objective evaluation of the first %d families of the bench table, OpenMP over families on "
-                  "%d threads (fastest of the team sizes tried: %s; includes the matrix build)"
-                  % (n_mt, best_threads, ", ".join("%d: %.0f/s" % kv for kv in sorted(tried.items()))),
-        "single_thread_value": rate_1t,
-        "single_thread_sample": "first %d families, 1 thread" % n_1t,
+                  "%d threads (fastest of the team sizes tried: %s; includes the matrix build, %.3f s of the %.3f s)"
+                  % (n_mt, best_threads, ", ".join("%d: %.0f/s" % kv for kv in sorted(tried.items())), build_mt, best_t),
+        "matrix_build_s": build_mt,
+        "matrix_build_single_thread_s": build_s,
+        "matrix_build_note": "all transition matrices of one evaluation = an evaluation of ONE family, on the team / on one thread",
+        "family_loop_value": n_mt / max(best_t - build_mt, 1e-9),
+        "family_loop_note": "the same sample without the matrix build: what a table large enough to amortise the build approaches",
+        "single_thread_family_loop_value": rate_1t_loop,
+        "single_thread_sample": "first %d families, 1 thread, matrix build (%.3f s) subtracted" % (n_1t, build_s),
         "gpu_vs_oracle_max_rel_err_log_posterior": rel,
     }
 

@@ -45,18 +45,38 @@ def bd_matrix(t, lam, mu, M):
         beta = lam * (e - 1) / (lam * e - mu)
     coeff = 1 - alpha - beta
     P = np.zeros((M + 1, M + 1))
-    P[0, 0] = 1.0
     la, lb, lc = math.log(alpha), math.log(beta), math.log(coeff)
-    c = np.arange(M + 1)
-    for s in range(1, M + 1):
-        acc = np.zeros(M + 1)
-        for j in range(0, s + 1):
-            ok = c >= j
-            cc = c[ok]
-            t_ = lnc(s, j) + lnc(s + cc - 1 - j, s - 1) + (s - j) * la + (cc - j) * lb + j * lc
-            acc[ok] += np.exp(t_)
-        P[s] = np.clip(acc, 0, 1)
+    # acc[s, c] += term(s, c, j), j ascending -- the same additions per entry, in the same order, as a loop over s with
+    # an inner loop over j (tests/golden/synth_table_hashes.json pins the tables), vectorised over (s, c)
+    sv = np.arange(1, M + 1)[:, None]            # rows s = 1..M
+    cv = np.arange(M + 1)[None, :]
+    acc = np.zeros((M, M + 1))
+    for j in range(0, M + 1):
+        ok = (sv >= j) & (cv >= j)
+        if not ok.any():
+            break
+        ss, cc = np.broadcast_to(sv, ok.shape)[ok], np.broadcast_to(cv, ok.shape)[ok]
+        t_ = lnc(ss, j) + lnc(ss + cc - 1 - j, ss - 1) + (ss - j) * la + (cc - j) * lb + j * lc
+        acc[ok] += np.exp(t_)
+    P[0, 0] = 1.0
+    P[1:] = np.clip(acc, 0, 1)
     return P
+
+
+def _count_below(cdf, ps, u):
+    """(cdf[ps] < u[:, None]).sum(axis=1) -- the number of entries of the parent's cumulative row strictly below the
+    uniform draw -- without materialising the B x S comparison: rows of a cumulative sum are non-decreasing, so the
+    count is the left insertion point, taken group by group of equal parent size.  Same integers (the tables of
+    tests/golden/synth_table_hashes.json, recorded with the dense form, pin that)."""
+    out = np.empty(len(ps), np.int64)
+    order = np.argsort(ps, kind="stable")
+    sp = ps[order]
+    starts = np.flatnonzero(np.r_[True, sp[1:] != sp[:-1]])
+    ends = np.r_[starts[1:], len(sp)]
+    for a, b in zip(starts, ends):
+        idx = order[a:b]
+        out[idx] = np.searchsorted(cdf[sp[a]], u[idx], side="left")
+    return out
 
 
 def simulate_families(tree, F, m, lam, mu, seed, root_cap=None):
@@ -95,7 +115,7 @@ def simulate_families(tree, F, m, lam, mu, seed, root_cap=None):
             cdf = mats[int(tree.branchlength[v])]
             ps = sizes[:, tree.parent[v]]
             u = rng.random(B)
-            sizes[:, v] = np.minimum((cdf[ps] < u[:, None]).sum(axis=1), M)
+            sizes[:, v] = np.minimum(_count_below(cdf, ps, u), M)
         leaves = sizes[:, 0::2]
         ok = (leaves.max(axis=1) <= m)
         for row in leaves[ok]:
