@@ -1276,6 +1276,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     a.col_max = v1.col_max;
     a.out_off = v1.out_off;
     a.out_root = v1.out_root;
+    a.trim = (v1.col_max != nullptr && c->opt.batch_trim) ? 1 : 0;
     a.max_lik = v1.max_lik;
     a.argmax = v1.argmax;
     a.max_post = v1.max_post;
@@ -2289,6 +2290,25 @@ int cafehip_eval_root_likelihoods(cafehip_ctx* c, int B, const int32_t* counts, 
     rc = launch_k2(c, a, B);
     c->d_err = saved_err;
     if (rc) { cleanup(); return -1; }
+    if (c->k2_used_mfma && c->opt.batch_trim && c->k2_nf > 0) {
+        // matrix-instruction flops this launch issues with every tile trimmed to its largest column limit / its root sizes
+        // (the same rule as the kernel's prologue)
+        const int nf = c->k2_nf, ks_full = (c->C + 3) / 4;
+        double issued = 0;
+        for (int b0 = 0; b0 < B; b0 += nf) {
+            int kmax = 0, rlo = INT_MAX, rhi = 0;
+            for (int b = b0; b < std::min(B, b0 + nf); ++b) {
+                kmax = std::max(kmax, (int)col_max[b]);
+                rlo = std::min(rlo, root_lo[b] - c->root_min);
+                rhi = std::max(rhi, root_hi[b] - c->root_min);
+            }
+            const int ks = std::min(ks_full, (kmax + 4) >> 2), rt = std::min((c->C + 15) / 16, (kmax + 16) >> 4);
+            const int rt_root = std::min(rhi >> 4, (c->R + 15) / 16 - 1) + 1 - (std::min(rlo, rhi) >> 4);
+            for (const auto& op : c->msched.ops)
+                issued += 2.0 * 4.0 * ks * 16.0 * (op.is_root ? rt_root : rt) * ((op.kind[0] == 1) + (op.kind[1] == 1)) * nf;
+        }
+        c->issued_walk = issued;
+    }
     if (c->timing) TRY2(hipEventRecord(c->ev[2], c->stream));
     TRY2(hipMemcpyAsync(out, d_out, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TRY2(hipStreamSynchronize(c->stream));

@@ -148,6 +148,7 @@ struct K2MfmaArgs {
     const int32_t* col_max;
     const int64_t* out_off;
     double* out_root;
+    int trim;              // batch mode: a tile's products stop at its largest column limit, its root step at its root sizes
     // posterior outputs
     double* max_lik;
     int32_t* argmax;

@@ -499,9 +499,30 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     }
     for (int f = tid; f < a.NF; f += blockDim.x) {
         const int u = fam0 + f;
-        s_colmax[f] = (batch && u < a.Fu) ? a.col_max[u] : (a.C - 1);
+        // (batch mode: slots behind the last row carry limit 0, so that they do not widen the tile's trimmed extent)
+        s_colmax[f] = batch ? ((u < a.Fu) ? a.col_max[u] : 0) : (a.C - 1);
     }
     __syncthreads();
+    // Batch mode (per-row column limits, cafe/conditional_distribution.cpp:16-32): rows beyond a family's limit are
+    // zero in every node vector, so a product over k-steps or row tiles beyond the tile's LARGEST limit multiplies and
+    // produces zeros only.  The tile's products stop there (same values: the skipped matrix instructions add exact
+    // zeros), and its root step covers only the row tiles that hold a root size some family of the tile asks for.
+    int t_ksteps = a.ksteps, t_rt = INT_MAX, t_root_first = 0, t_root_last = INT_MAX;
+    if (batch && a.trim) {
+        int kmax = 0, rlo = INT_MAX, rhi = 0;
+        for (int f = 0; f < a.NF; ++f) {
+            kmax = max(kmax, s_colmax[f]);
+            const int u = fam0 + f;
+            if (u < a.Fu) {
+                rlo = min(rlo, a.root_lo[u] - a.root_min);
+                rhi = max(rhi, a.root_hi[u] - a.root_min);
+            }
+        }
+        t_ksteps = min(a.ksteps, (kmax + 4) >> 2);
+        t_rt = (kmax + 16) >> 4;
+        t_root_first = min(rlo, rhi) >> 4;
+        t_root_last = rhi >> 4;
+    }
     K2_STAMP(1);
     double* my_park = a.park + (size_t)(my_slot >= 0 ? s_colmax[a.NF] : (int)(blockIdx.y * gridDim.x + blockIdx.x)) * a.n_parks * park_stride;
 
@@ -516,10 +537,12 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
         const cafehip::MfmaOp op = *reinterpret_cast<const cafehip::MfmaOp*>(s_ops + oi * 12);
         const int rows = op.is_root ? a.R : a.C;
         const int row_lo = op.is_root ? a.root_min : 0;
-        const int RT = (rows + 15) >> 4;           // row tiles of this step, dealt evenly to the Wr wave rows
+        // row tiles of this step (trimmed in batch mode), dealt evenly to the Wr wave rows
+        const int rt_first = op.is_root ? t_root_first : 0;
+        const int RT = op.is_root ? (min(t_root_last, ((rows + 15) >> 4) - 1) + 1 - rt_first) : min((rows + 15) >> 4, t_rt);
         const int rt_base = RT / a.Wr, rt_rem = RT - rt_base * a.Wr;
         const int ntile = rt_base + (wr < rt_rem ? 1 : 0);  // <= NRT_W
-        const int rt0 = wr * rt_base + min(wr, rt_rem);
+        const int rt0 = rt_first + wr * rt_base + min(wr, rt_rem);
         const bool wave_active = ntile > 0;
 
         cafe_d4 hold[NFT_W][NRT_W];   // declared per step: nothing of it is live across steps
@@ -605,11 +628,11 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                     const unsigned kstride_bytes = 32u * (unsigned)a.LD;
                     if constexpr (NRT_W > 1) {
                         if (ntile == NRT_W - 1)
-                            mfma_edge_p<NFT_W, NRT_W, NRT_W - 1, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+                            mfma_edge_p<NFT_W, NRT_W, NRT_W - 1, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, t_ksteps, fac);
                         else
-                            mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+                            mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, t_ksteps, fac);
                     } else {
-                        mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+                        mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, t_ksteps, fac);
                     }
                 }
             }
@@ -734,9 +757,30 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     }
     for (int f = tid; f < a.NF; f += blockDim.x) {
         const int u = fam0 + f;
-        s_colmax[f] = (batch && u < a.Fu) ? a.col_max[u] : (a.C - 1);
+        // (batch mode: slots behind the last row carry limit 0, so that they do not widen the tile's trimmed extent)
+        s_colmax[f] = batch ? ((u < a.Fu) ? a.col_max[u] : 0) : (a.C - 1);
     }
     __syncthreads();
+    // Batch mode (per-row column limits, cafe/conditional_distribution.cpp:16-32): rows beyond a family's limit are
+    // zero in every node vector, so a product over k-steps or row tiles beyond the tile's LARGEST limit multiplies and
+    // produces zeros only.  The tile's products stop there (same values: the skipped matrix instructions add exact
+    // zeros), and its root step covers only the row tiles that hold a root size some family of the tile asks for.
+    int t_ksteps = a.ksteps, t_rt = INT_MAX, t_root_first = 0, t_root_last = INT_MAX;
+    if (batch && a.trim) {
+        int kmax = 0, rlo = INT_MAX, rhi = 0;
+        for (int f = 0; f < a.NF; ++f) {
+            kmax = max(kmax, s_colmax[f]);
+            const int u = fam0 + f;
+            if (u < a.Fu) {
+                rlo = min(rlo, a.root_lo[u] - a.root_min);
+                rhi = max(rhi, a.root_hi[u] - a.root_min);
+            }
+        }
+        t_ksteps = min(a.ksteps, (kmax + 4) >> 2);
+        t_rt = (kmax + 16) >> 4;
+        t_root_first = min(rlo, rhi) >> 4;
+        t_root_last = rhi >> 4;
+    }
     K2_STAMP(1);
     double* my_park = a.park + (size_t)(my_slot >= 0 ? s_colmax[a.NF] : (int)(blockIdx.y * gridDim.x + blockIdx.x)) * a.n_parks * park_stride;
 
@@ -749,10 +793,11 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
         const cafehip::MfmaOp op = *reinterpret_cast<const cafehip::MfmaOp*>(s_ops + oi * 12);
         const int rows = op.is_root ? a.R : a.C;
         const int row_lo = op.is_root ? a.root_min : 0;
-        const int RT = (rows + 15) >> 4;
+        const int rt_first = op.is_root ? t_root_first : 0;   // (batch mode: trimmed extents, see the prologue)
+        const int RT = op.is_root ? (min(t_root_last, ((rows + 15) >> 4) - 1) + 1 - rt_first) : min((rows + 15) >> 4, t_rt);
         const int rt_base = RT / a.Wr, rt_rem = RT - rt_base * a.Wr;
         const int ntile = rt_base + (wr < rt_rem ? 1 : 0);
-        const int rt0 = wr * rt_base + min(wr, rt_rem);
+        const int rt0 = rt_first + wr * rt_base + min(wr, rt_rem);
         const bool wave_active = ntile > 0;
 
         // one-hot leaf child next to a child that needs the matrix cores: issue its column gathers first so
@@ -856,11 +901,11 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                     const unsigned kstride_bytes = 32u * (unsigned)a.LD;
                     if constexpr (NRT_W > 1) {
                         if (ntile == NRT_W - 1)
-                            mfma4_edge_p<G, NRT_W, NRT_W - 1, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, a.ksteps, fac);
+                            mfma4_edge_p<G, NRT_W, NRT_W - 1, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, t_ksteps, fac);
                         else
-                            mfma4_edge_p<G, NRT_W, NRT_W, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, a.ksteps, fac);
+                            mfma4_edge_p<G, NRT_W, NRT_W, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, t_ksteps, fac);
                     } else {
-                        mfma4_edge_p<G, NRT_W, NRT_W, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, a.ksteps, fac);
+                        mfma4_edge_p<G, NRT_W, NRT_W, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, t_ksteps, fac);
                     }
                 }
             }

@@ -277,4 +277,13 @@ def test_cfg5_null_sharded_by_root_size_recombines_bit_exactly():
             parts.append(eng.eval_root_likelihoods(rows[a:b], lo[a:b], lo[a:b], cm[a:b]))
             r0 = r1
         assert np.array_equal(np.concatenate(parts), whole)
+    # round 3: a tile's products stop at its largest column limit and its root step at its root sizes (option batch_trim);
+    # the untrimmed launch of round 2 must give the same 250,000 values bit for bit, and trimming must save work
+    trimmed_flops = eng.last_issued_flops()[0]
+    eng.set_option("batch_trim", 0)
+    untrimmed = eng.eval_root_likelihoods(rows, lo, lo, cm)
+    untrimmed_flops = eng.last_issued_flops()[0]
+    eng.set_option("batch_trim", 1)
+    assert np.array_equal(untrimmed, whole)
+    assert trimmed_flops < 0.75 * untrimmed_flops, (trimmed_flops, untrimmed_flops)
     eng.close()
