@@ -38,3 +38,30 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and 0 < c["value"] < d["value"]
     # the parity gate recorded with the timing: per-family log posterior vs the oracle
     assert c["gpu_vs_oracle_max_rel_err_log_posterior"] < 1e-6
+    # round 3 additions: set-up reported apart, traffic next to what the launch inherently needs, other tables
+    assert d["setup_ms"]["set_families_detail_ms"]["total"] > 0
+    assert r["traffic_minimal_bytes"] > 0 and "whole_evaluation" in r
+    assert d["strong_scaling"]["families_total"] == 8 * 62464 and d["strong_scaling"]["value"] > 1e6
+    assert d["tables"]["test1"]["families"] == 14787 and d["tables"]["turnover"]["value"] > 1e6
+    assert c["matrix_build_s"] > 0 and c["family_loop_value"] > c["value"]
+
+
+def test_forced_one_rank_run_goes_through_the_native_exchange():
+    # exactly what the driver starts for N > 1, with one rank: the timed step is cafehip_eval_posterior_sharded (direct
+    # exchange inside the score kernel), RCCL timed beside it; the score must carry the same bits as the plain run
+    def run(extra):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "24", "--warmup", "2",
+                              "--no-cpu-baseline", "--no-search", "--no-probes", "--no-strong", "--no-tables"] + extra,
+                             cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+    plain = run([])
+    forced = run(["--force-dist", "--comm", "native"])
+    assert forced["rccl_ranks"] == 1 and forced["comm"] == "native" and forced["n_gpus"] == 1
+    x = forced["exchange"]
+    assert x["mode"] == "direct" and x["exchange_ms_per_step"] < 0.020        # <= 20 us with one rank
+    assert "rccl" in x and ("error" in x["rccl"] or x["rccl"]["exchange_ms_per_step"] > 0)
+    assert forced["config"]["last_score"] == plain["config"]["last_score"]     # same step, same table: same bits
+    assert forced["ms_per_step"] < 1.25 * plain["ms_per_step"]

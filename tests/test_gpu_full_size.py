@@ -65,6 +65,28 @@ def test_family_values_do_not_depend_on_the_batch(problem):
     p["eng"].set_families(p["counts"], p["fr"])
 
 
+def test_compressed_walk_equals_the_uncompressed_one_at_full_size(problem):
+    # subtree-state compression at the BASELINE shapes (not only on small trees): every per-family output of the whole
+    # table, bit for bit, against the same library walking the full tree (option compress=0)
+    import cafe_amd
+    p = problem
+    score, fz, ml, am, mp = p["full"]
+    assert "used=1" in p["eng"].describe(), p["eng"].describe()
+    eng = cafe_amd.Engine(0)
+    try:
+        eng.set_option("compress", 0)
+        eng.set_tree(p["t"].parent, p["t"].left, p["t"].right, p["t"].branchlength)
+        eng.set_families(p["counts"], p["fr"])
+        if p["err"] is not None:
+            eng.set_error_model(p["err"])
+        s0, fz0, ml0, am0, mp0 = eng.get_posterior(p["lam"], p["mu"], p["prior"], per_family=True)
+        assert "used=1" not in eng.describe()
+    finally:
+        eng.close()
+    assert s0 == score and fz0 == fz
+    assert np.array_equal(ml0, ml) and np.array_equal(mp0, mp) and np.array_equal(am0, am)
+
+
 def test_oracle_spot_check_on_a_sample(problem):
     p = problem
     score, fz, ml, am, mp = p["full"]
@@ -287,3 +309,72 @@ def test_cfg5_null_sharded_by_root_size_recombines_bit_exactly():
     assert np.array_equal(untrimmed, whole)
     assert trimmed_flops < 0.75 * untrimmed_flops, (trimmed_flops, untrimmed_flops)
     eng.close()
+
+
+# ---- BASELINE configs[3] at its stated size: 500 k families, 64 taxa, three lambda classes -------------------------
+
+@pytest.fixture(scope="module")
+def cfg4_500k(tmp_path_factory):
+    """The 500k-family table as bench.py's strong-scaling leg builds it: 8 seeded blocks of 62,464 rows (generated once
+    per test session and kept on disk)."""
+    import torch
+    torch.cuda.init()
+    import cafe_amd
+    from cafe_amd import synth
+    from cafe_amd import tree as ctree
+    cfg = dict(synth.CONFIGS["cfg4"])
+    newick = synth.random_ultrametric_newick(cfg["n_taxa"], cfg["seed"])
+    tree = ctree.CafeTree(newick)
+    path = tmp_path_factory.getbasetemp() / "cfg4_500k.npy"
+    if path.exists():
+        counts = np.load(path)
+    else:
+        counts = np.concatenate([synth.simulate_families(tree, 62464, cfg["m"], cfg["lam"], cfg["mu"], cfg["seed"] + 1 + b)
+                                 for b in range(8)])
+        np.save(path, counts)
+    rng = O.range_from_max(cfg["m"])
+    lam, mu = synth.node_rates(tree, cfg)
+    assert len(set(lam.tolist())) == 3
+    return dict(tree=tree, t=O.PyTree(newick), counts=counts, rng=rng, lam=lam, mu=mu, cfg=cfg,
+                fr=cafe_amd.FamilySizeRange(rng.min, rng.max, rng.root_min, rng.root_max), prior=O.prior_poisson(1000, rng.root_min, 8.0))
+
+
+def test_configs3_500k_whole_table_8_way_split_and_oracle_sample(cfg4_500k):
+    # the whole table on one context; the same table as 8 chunk-aligned blocks through the asynchronous entry point
+    # (what 8 ranks compute), recombined with the fixed-order sum: bit-exact; per-family values of a block equal the
+    # whole-table ones; 160 sampled families against the oracle under the three lambda classes
+    import torch
+    import cafe_amd
+    from cafe_amd import distributed as D
+    p = cfg4_500k
+    F = len(p["counts"])
+    assert F == 8 * 62464
+    eng = cafe_amd.Engine(0)
+    try:
+        p["tree"].apply(eng)
+        eng.set_families(p["counts"], p["fr"])
+        score, fz, ml, am, mp = eng.get_posterior(p["lam"], p["mu"], p["prior"], per_family=True)
+        assert fz == -1 and math.isfinite(score)
+        assert score == pytest.approx(float(np.log(mp).sum()), rel=1e-12)
+        bounds = D.shard_bounds(F, 8)
+        slots = D.max_chunks_per_rank(F, 8)
+        rows = []
+        for r, (lo, hi) in enumerate(bounds):
+            eng.set_families(p["counts"][lo:hi], p["fr"])
+            packed, pc, pf = D.packed_buffer(torch, slots, "cuda")
+            eng.eval_posterior_async(p["lam"], p["mu"], p["prior"], pc, pf)
+            torch.cuda.synchronize()
+            rows.append(packed.cpu().numpy())
+            if r in (0, 5):
+                s_b, fz_b, ml_b, am_b, mp_b = eng.get_posterior(p["lam"], p["mu"], p["prior"], per_family=True)
+                assert np.array_equal(ml_b, ml[lo:hi]) and np.array_equal(mp_b, mp[lo:hi]) and np.array_equal(am_b, am[lo:hi])
+        host = np.stack(rows)
+        assert D.final_score(host[:, :slots].reshape(-1), D.NO_ZERO) == score
+    finally:
+        eng.close()
+    rs = np.random.RandomState(17)
+    idx = np.sort(rs.choice(F, 160, replace=False))
+    so, fzo, mlo, amo, mpo = O.eval_posterior(p["t"], p["counts"][idx], p["rng"], p["lam"], p["mu"], p["prior"], nthreads=os.cpu_count() or 1)
+    assert np.max(np.abs(ml[idx] - mlo) / mlo) < 1e-9
+    assert np.max(np.abs(mp[idx] - mpo) / mpo) < 1e-9
+    assert np.array_equal(am[idx], amo)
