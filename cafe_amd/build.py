@@ -56,7 +56,7 @@ def build(force=False, verbose=False):
         path = os.path.join(CSRC, src)
         obj = os.path.join(OBJDIR, os.path.basename(src).rsplit(".", 1)[0] + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header):
-            jobs.append([hipcc()] + CFLAGS + ["-c", "-o", obj, path])
+            jobs.append([hipcc()] + CFLAGS + os.environ.get("CAFEHIP_EXTRA_CFLAGS", "").split() + ["-c", "-o", obj, path])
     if verbose:
         for j in jobs:
             print(" ".join(j))

@@ -1478,7 +1478,7 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
         memset(&x, 0, sizeof x);
         x.max_post_u = c->d_max_post;
         x.max_lik_u = c->d_max_lik;
-        x.fam2u = c->d_fam2u;
+        x.fam2u = c->F == c->Fu ? nullptr : c->d_fam2u;   // (no duplicate rows: family i is unique row i)
         x.F = c->F;
         x.Fu = c->Fu;
         x.first_zero = d_first_zero;
@@ -1497,7 +1497,7 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
         x.timeout_ticks = 30LL * 100000000LL;   // 30 s of the 100 MHz wall clock: a rank that died must not hang the others' GPUs
         if (launch_kernel(k3x_kernel(), dim3(std::max(c->n_chunks, 1)), dim3(CAFEHIP_CHUNK), 0, c->stream, x)) return -1;
     } else if (c->n_chunks > 0) {
-        K3Args k3{c->d_max_post, c->d_max_lik, c->d_fam2u, c->F, c->Fu, d_chunk_sums, d_first_zero, nullptr, nullptr, 0};
+        K3Args k3{c->d_max_post, c->d_max_lik, c->F == c->Fu ? nullptr : c->d_fam2u, c->F, c->Fu, d_chunk_sums, d_first_zero, nullptr, nullptr, 0};
         if (host_out) {
             k3.host = c->h_result;
             k3.arrive = c->d_arrive;

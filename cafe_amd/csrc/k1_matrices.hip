@@ -229,6 +229,8 @@ __global__ __launch_bounds__(256) void k1_build_matrices_rb(K1Args ka)
             for (int u = 0; u < 8; ++u)
                 if (i0 + 16 * u < nB) db[i0 + 16 * u] = v[u];
         }
+        // (requesting both runs of a round together -- half the round trips -- measured SLOWER in round 3: K1 17.2 -> 19.2 us
+        // at configs[1], 50 -> 55 us at configs[2]; profiles/r03/k1_k3_k2c_micro_sweeps.txt)
         for (int i = l; i < K1_BPAD; i += 16) sB[r * ldB + i] = 0.0;
     }
     __syncthreads();

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(K3Args a)
     const int i = blockIdx.x * CAFEHIP_CHUNK + threadIdx.x;
     double v = 0.0;
     if (i < F) {
-        const int u = fam2u[i];
+        const int u = fam2u ? fam2u[i] : i;   // (NULL: no duplicate rows, family i is unique row i -- one round trip less)
         v = log(max_post_u[u]);                                   // cafe/lambda.cpp:721
         if (max_lik_u[u] == 0.0) atomicMin(first_zero + set, i);  // cafe/lambda.cpp:715-720
     }
@@ -217,10 +217,17 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(K3Args a)
     __syncthreads();
     if (s_last && threadIdx.x == 0) {
         __threadfence();
-        for (int q = 0; q < (int)gridDim.y; ++q) host->first_zero[q] = atomicMin(first_zero + q, INT32_MAX);  // atomic read of the final value
+        // (every other block's chunk sum was fenced system-wide before it counted itself in)
+        const int32_t fz0 = atomicMin(first_zero, INT32_MAX);   // atomic read of the final value
+        if (gridDim.y > 1) {
+            for (int q = 1; q < (int)gridDim.y; ++q) host->first_zero[q] = atomicMin(first_zero + q, INT32_MAX);
+            __threadfence_system();
+        }
         *arrive = 0;
-        __threadfence_system();
-        host->done_seq = seq;
+        // the sequence number and set 0's first-zero index share one aligned 8-byte word: a single store publishes
+        // both, no fence in between (the host reads the index after it has seen the number)
+        static_assert(offsetof(HostResult, first_zero) == 4 && offsetof(HostResult, done_seq) == 0, "one 8-byte word");
+        *reinterpret_cast<volatile unsigned long long*>(host) = ((unsigned long long)(unsigned)fz0 << 32) | (unsigned)seq;
     }
 }
 
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score_x(K3xArgs a)
     const int i = blockIdx.x * CAFEHIP_CHUNK + threadIdx.x;
     double v = 0.0;
     if (i < a.F) {
-        const int u = a.fam2u[i];
+        const int u = a.fam2u ? a.fam2u[i] : i;
         v = log(a.max_post_u[u]);                                     // cafe/lambda.cpp:721
         if (a.max_lik_u[u] == 0.0) atomicMin(a.first_zero, i);        // cafe/lambda.cpp:715-720
     }

@@ -2,8 +2,9 @@
 """HBM-side traffic of the dominant kernel of every bench workload, for bench.py's roofline.traffic:
 two rocprofv3 passes per workload (FETCH_SIZE and WRITE_SIZE cannot share a pass), each in its own run with
 --kernel-trace only (the PMC guidance of /opt/skills/guides/MI355X_MICROARCH.md).  On gfx950 FETCH_SIZE tallies
-128-byte requests at 64 bytes: it is doubled; WRITE_SIZE is taken as reported.  Writes
-profiles/r02_pmc_traffic.json (keys "<config>:<families per launch>:<k2|mcnull>") and a text summary.
+128-byte requests at 64 bytes: it is doubled; WRITE_SIZE is taken as reported -- both factors measured on known-bytes
+kernels with this walk's access patterns (profiles/r03_fetch_size_calibration.txt: x2.000 / x1.000).  Writes
+<out>/r03_pmc_traffic.json (keys "<config>:<families per launch>:<k2|mcnull>") and a text summary.
 
     python tools/collect_pmc.py [out_dir]          (on the GPU box; needs rocprofv3)"""
 import glob
@@ -67,9 +68,9 @@ def main():
         tables = (2.0 * t_fetch + t_write) * 1024.0
         res["%s:%d:%s" % (cfg, F, kind)] = {
             "kernel": kname, "launches_seen": n, "fetch_kib_raw": fetch_kib, "fetch_kib_x2": 2.0 * fetch_kib,
-            "write_kib": write_kib, "traffic_bytes": traffic,
+            "write_kib": write_kib, "traffic_bytes": traffic, "fetch_factor": 2,
             "tables_traffic_bytes": tables, "tables_fetch_kib_raw": t_fetch, "tables_write_kib": t_write,
-            "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate runs), FETCH_SIZE x2 (gfx950), "
+            "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate runs), FETCH_SIZE x2 / WRITE_SIZE x1 (calibrated: profiles/r03_fetch_size_calibration.txt), "
                     "mean over the second half of the kernel's launches; tables_* = the k2c_nodes launches of one "
                     "evaluation (factor tables of compressed subtrees), 0 where the table does not compress",
         }
@@ -78,8 +79,8 @@ def main():
                      % ("%s:%d:%s" % (cfg, F, kind), kname[:60], n, fetch_kib, 2 * fetch_kib, write_kib, traffic / 1e6,
                         t_fetch, t_write, tables / 1e6))
         print(lines[-1], flush=True)
-    json.dump(res, open(os.path.join(out_dir, "r02_pmc_traffic.json"), "w"), indent=1)
-    open(os.path.join(out_dir, "r02_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
+    json.dump(res, open(os.path.join(out_dir, "r03_pmc_traffic.json"), "w"), indent=1)
+    open(os.path.join(out_dir, "r03_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
 
 
 if __name__ == "__main__":
