@@ -436,156 +436,6 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
     }
 }
 
-// Round 3: the same epilogue with SEVERAL families per wave pass.  A family's root scan is a chain of dependent wave
-// reductions, and a wave had one family in flight at a time (5 families = 5 chains per wave at configs[1]); here a group
-// of LPF lanes (16: one row of the wave, R <= 128; 32: two rows, R <= 256) owns a family, so a pass carries 64 / LPF
-// families through ONE instruction stream -- the row reductions are the first four steps of the wave reductions above
-// (they never leave a 16-lane row).  Same values: max over the same elements, first maximum by lowest index, the
-// same candidates through the same exp(log + log).
-__device__ __forceinline__ double k2_row_max(double v)
-{
-#define CAFE_DPP_MAX(ctrl)                                                                                     \
-    {                                                                                                          \
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);              \
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);              \
-        v = fmax(v, __hiloint2double(hi, lo));                                                                 \
-    }
-    CAFE_DPP_MAX(0xB1) CAFE_DPP_MAX(0x4E) CAFE_DPP_MAX(0x141) CAFE_DPP_MAX(0x140)
-#undef CAFE_DPP_MAX
-    return v;
-}
-__device__ __forceinline__ int k2_row_min(int v)
-{
-#define CAFE_DPP_MIN(ctrl) v = min(v, __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false));
-    CAFE_DPP_MIN(0xB1) CAFE_DPP_MIN(0x4E) CAFE_DPP_MIN(0x141) CAFE_DPP_MIN(0x140)
-#undef CAFE_DPP_MIN
-    return v;
-}
-template <int LPF>
-__device__ __forceinline__ double k2_group_max(double v)
-{
-    v = k2_row_max(v);
-    if (LPF == 32) v = fmax(v, __shfl_xor(v, 16));
-    return v;
-}
-template <int LPF>
-__device__ __forceinline__ int k2_group_min(int v)
-{
-    v = k2_row_min(v);
-    if (LPF == 32) v = min(v, __shfl_xor(v, 16));
-    return v;
-}
-
-template <int LPF>
-__device__ __forceinline__ void k2_epilogue_groups(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0,
-                                                   size_t out_off, int wave, int lane, int nwaves)
-{
-    constexpr int PR = 8;            // root sizes per lane: R <= LPF * PR
-    constexpr int NG = 64 / LPF;     // families per pass
-    double* const max_lik = a.max_lik + out_off;       // this parameter set's block of the outputs
-    double* const max_post = a.max_post + out_off;
-    int32_t* const argmax = a.argmax + out_off;
-    unsigned* cand = reinterpret_cast<unsigned*>(scratch) + wave * 64;                        // (family << 16) | root index
-    unsigned long long* fmaxbits = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(scratch) + 8 * 64);   // [NF]
-    const double* prior = a.prior;
-    const double* logprior = a.logprior;
-    const int grp = lane / LPF, lg = lane % LPF;
-    double pr[PR];
-#pragma unroll
-    for (int q = 0; q < PR; ++q) {
-        const int i = lg + LPF * q;
-        pr[q] = (i < a.R) ? prior[i] : 0.0;
-    }
-    int n_cand = 0;
-    unsigned long long fastmask = 0;   // bit t: the wave's t-th family took the filtered path (wave-uniform)
-
-    auto flush = [&]() {
-        __threadfence_block();
-        if (lane < n_cand) {
-            const unsigned c = cand[lane];
-            const int f = (int)(c >> 16), i = (int)(c & 0xFFFFu);
-            const double p = exp(log(Lbuf[(size_t)f * a.LDv + i]) + logprior[i]);
-            atomicMax(&fmaxbits[f], (unsigned long long)__double_as_longlong(p));   // p >= 0: the bit pattern orders like the value
-        }
-        __threadfence_block();
-        n_cand = 0;
-    };
-
-    const int n_mine = (a.NF - wave + nwaves - 1) / nwaves;   // this wave's families: f = wave + t * nwaves, t < n_mine
-    for (int t0 = 0; t0 < n_mine; t0 += NG) {
-        const int t = t0 + grp;
-        const int f = wave + t * nwaves;
-        const int u = fam0 + f;
-        const bool live = t < n_mine && u < a.Fu;              // uniform over the group
-        const double* L = Lbuf + (size_t)(live ? f : wave) * a.LDv;
-        double best = -INFINITY, qmax = 0.0;
-        int bi = INT_MAX;  // INT_MAX = this lane has seen no element yet
-        double vq[PR];
-#pragma unroll
-        for (int q = 0; q < PR; ++q) {
-            const int i = lg + LPF * q;
-            vq[q] = 0.0;
-            if (i < a.R) {
-                const double v = L[i];
-                vq[q] = v;
-                if (bi == INT_MAX || v > best) {
-                    best = v;
-                    bi = i;
-                }
-                qmax = fmax(qmax, v * pr[q]);
-            }
-        }
-        // first maximum wins (libcommon/mathfunc.c:9-24): the largest value, then the lowest index holding it
-        {
-            const double lane_best = best;
-            best = k2_group_max<LPF>(lane_best);
-            bi = k2_group_min<LPF>(lane_best == best ? bi : INT_MAX);
-            qmax = k2_group_max<LPF>(qmax);
-        }
-        if (live && lg == 0) {
-            max_lik[u] = best;
-            argmax[u] = bi;
-        }
-        const bool slow = live && (!(qmax >= 1e-290) || t >= 64);
-        if (__ballot(slow) != 0) {
-            // plain form for the groups that need it: every root size through log and exp (all lanes take part in the reduction)
-            double bestp = -INFINITY;
-            if (slow)
-                for (int i = lg; i < a.R; i += LPF) bestp = fmax(bestp, exp(log(L[i]) + logprior[i]));
-            bestp = k2_group_max<LPF>(bestp);
-            if (slow && lg == 0) max_post[u] = bestp;
-        }
-        const bool fast = live && !slow;
-        if (fast && lg == 0) fmaxbits[f] = 0ull;
-        {
-            const unsigned long long m = __ballot(fast && lg == 0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-                if ((m >> (g * LPF)) & 1ull) fastmask |= 1ull << (t0 + g);
-        }
-        const double thr = qmax * (1.0 - 1e-9);
-#pragma unroll
-        for (int q = 0; q < PR; ++q) {
-            const int i = lg + LPF * q;
-            const bool is_c = fast && i < a.R && vq[q] * pr[q] >= thr;
-            const unsigned long long m = __ballot(is_c);
-            if (m != 0) {
-                const int cnt = __popcll(m);
-                if (n_cand + cnt > 64) flush();
-                if (is_c) cand[n_cand + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)f << 16) | (unsigned)i;
-                n_cand += cnt;
-            }
-        }
-    }
-    if (n_cand) flush();
-    // lane t writes the maximum of the wave's t-th family
-    {
-        const int f = wave + lane * nwaves;
-        if (f < a.NF && fam0 + f < a.Fu && ((fastmask >> lane) & 1ull))
-            max_post[fam0 + f] = __longlong_as_double((long long)fmaxbits[f]);
-    }
-}
-
 __device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0, size_t out_off,
                                             bool batch, int wave, int lane, int nwaves)
 {
@@ -600,8 +450,10 @@ __device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* L
         }
         return;
     }
-    if (a.R <= 128) k2_epilogue_groups<16>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
-    else if (a.R <= 256) k2_epilogue_groups<32>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
+    // (round 3: a variant carrying four families per wave pass, one per 16-lane row, was bit-identical and SLOWER --
+    // walk 56.4 -> 57.9 us at configs[1]: the epilogue is bound by instruction fetch, and the variant is more code)
+    if (a.R <= 128) k2_epilogue_impl<true, 2>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
+    else if (a.R <= 256) k2_epilogue_impl<true, 4>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
     else k2_epilogue_impl<false, 1>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
 }
 
