@@ -178,6 +178,9 @@ struct cafehip_ctx {
         int vitlds = 0;               // Viterbi argmax tables in LDS
         int k2c_batch = 1;            // k2c_nodes: the child columns of a state gathered in one batch (round 3)
         int batch_trim = 1;           // batch mode: a tile's products stop at its largest column limit (round 3)
+        int batch_lockstep = 1;       // batch mode: workgroups start generation by generation (L2 reuse of the edge matrices)
+        int walk_lockstep = 0;        // the same pacing for the family walk of an objective evaluation
+        int batch_lockstep_slack = 0; // ... a generation starts when all but this percentage of the previous ones have finished
     } opt;
     bool walk_compressed = false;           // the MFMA launcher walks the reduced tree (set around one launch)
     bool last_compressed = false;           // ... and the last objective evaluation did
@@ -212,6 +215,7 @@ struct cafehip_ctx {
     std::map<std::tuple<const void*, int, size_t>, int> k2_occ;   // resident workgroups per CU of a K2 launch shape
     int k2_grid = 0, k2_park_slots = 0;                          // workgroups / park slots of the last MFMA K2 launch
     int32_t* d_park_flags = nullptr;                             // park-slot ownership flags (0 = free)
+    int32_t* d_gen_done = nullptr;                               // batch mode: workgroups finished (lock-step generations)
     int park_flags_cap = 0;
     double* d_PT = nullptr;
     unsigned short* d_vit = nullptr;   // Viterbi argmax tables (global scratch, grow-only)
@@ -901,6 +905,24 @@ int k2_fit_grid(cafehip_ctx* c, const void* fn, K2MfmaArgs& a, int* grid, int bl
     a.park = c->d_park;
     a.park_flags = c->d_park_flags;
     a.n_park_slots = slots;
+    a.gen_done = nullptr;
+    if ((a.col_max != nullptr && c->opt.batch_lockstep > 0) || (a.col_max == nullptr && c->opt.walk_lockstep > 0 && a.n_sets == 1)) {
+        // lock-step generations of a batch launch: as many workgroups as the chip holds at once
+        auto it = c->k2_occ.find({fn, block, lds});
+        if (it == c->k2_occ.end()) {
+            int nb = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, block, lds));
+            it = c->k2_occ.emplace(std::make_tuple(fn, block, lds), std::max(nb, 1)).first;
+        }
+        const int gen = it->second * std::max(c->n_cu, 1);
+        if (*grid > gen) {
+            if (!c->d_gen_done) HIP_TRY(hipMalloc(&c->d_gen_done, sizeof(int32_t)));
+            HIP_TRY(hipMemsetAsync(c->d_gen_done, 0, sizeof(int32_t), c->stream));
+            a.gen_done = c->d_gen_done;
+            a.gen_size = gen;
+            a.gen_slack = (int)((long long)gen * c->opt.batch_lockstep_slack / 100);
+        }
+    }
     c->k2_grid = *grid;
     c->k2_park_slots = slots;
     return 0;
@@ -1538,7 +1560,7 @@ int collect_kernel_ms(cafehip_ctx* c)
 // environment ONCE, when the context is created (tools/ sweeps), never during an evaluation
 const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
                                     "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch",
-                                    "batch_trim", "comm"};
+                                    "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "comm"};
 
 int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
 {
@@ -1583,6 +1605,9 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     else if (key == "vitlds") o.vitlds = iv != 0;
     else if (key == "k2c_batch") o.k2c_batch = iv != 0;
     else if (key == "batch_trim") o.batch_trim = iv != 0;
+    else if (key == "batch_lockstep") o.batch_lockstep = iv != 0;
+    else if (key == "walk_lockstep") o.walk_lockstep = iv != 0;
+    else if (key == "batch_lockstep_slack") o.batch_lockstep_slack = std::min(std::max(iv, 0), 100);
     else if (key == "comm") {
         if (val == "rccl") c->comm_mode = 1;
         else if (val == "direct") c->comm_mode = 2;
@@ -1684,6 +1709,7 @@ void cafehip_destroy(cafehip_ctx* c)
     hipFree(c->d_mops);
     hipFree(c->d_park);
     hipFree(c->d_park_flags);
+    hipFree(c->d_gen_done);
     hipFree(c->d_parent);
     hipFree(c->d_prefix);
     hipFree(c->d_vit_slot);

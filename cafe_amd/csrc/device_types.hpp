@@ -149,6 +149,8 @@ struct K2MfmaArgs {
     const int64_t* out_off;
     double* out_root;
     int trim;              // batch mode: a tile's products stop at its largest column limit, its root step at its root sizes
+    int32_t* gen_done;     // batch mode, lock-step generations: workgroups finished so far (device counter), or NULL
+    int gen_size, gen_slack;   // workgroup b starts once (b / gen_size) * gen_size - gen_slack workgroups have finished
     // posterior outputs
     double* max_lik;
     int32_t* argmax;

@@ -254,6 +254,30 @@ __device__ __forceinline__ void k2_release_park_slot(const K2MfmaArgs& a, const 
     if (a.n_park_slots > 0 && tid == 0) atomicExch(&a.park_flags[*s_slot], 0);
 }
 
+// Batch mode, lock-step generations.  A batch launch is tens of resident-chip-fulls of workgroups, each streaming every
+// edge matrix of the tree (tens of MB in all) through a 4 MB L2: left alone, the resident workgroups drift apart until
+// every one is on a different edge and nothing is reused (85 GB of fabric traffic for 70 MB of inputs, round 2).
+// Workgroup b therefore starts only when the generations before its own -- blocks of `gen_size` = as many workgroups
+// as the chip holds -- have (all but gen_slack) finished: a generation starts together, its tiles are neighbours in
+// the row order (similar extents: similar pace), so the workgroups of an XCD are on the same one or two edges at any
+// time and the hot matrix stays in L2.  Only a pace-maker: nothing is communicated, and a workgroup that has waited
+// 2 ms goes ahead anyway (dispatch order is not guaranteed).
+__device__ __forceinline__ void k2_wait_for_generation(const K2MfmaArgs& a, int tid)
+{
+    if (!a.gen_done) return;
+    if (tid == 0) {
+        const int need = (int)(blockIdx.x / (unsigned)a.gen_size) * a.gen_size - a.gen_slack;
+        if (need > 0) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(a.gen_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > 200000) break;   // 2 ms of the 100 MHz counter
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // Root vectors (in Lbuf) -> per-family posterior (cafe/lambda.cpp:657-689) or packed root rows (batch mode).
 // max_posterior = max_i exp(log L_i + log prior_i) as the reference writes it (:681).  Evaluating log and exp for
 // every root size is most of the epilogue's time, and all but one or two of those values lose the max by orders of
@@ -484,6 +508,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     const bool fold = (a.PTfold != nullptr) && !batch;
     const size_t park_stride = (size_t)a.NF * a.LDv;
     const int fam0 = blockIdx.x * a.NF;
+    k2_wait_for_generation(a, tid);
     const int my_slot = k2_acquire_park_slot(a, s_colmax + a.NF, tid);   // (the word behind the column limits)
 
     for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
@@ -696,6 +721,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 
     // ---- root vector (in Lbuf) -> posterior (cafe/lambda.cpp:657-689) or packed root rows ----
     k2_release_park_slot(a, s_colmax + a.NF, tid);
+    if (a.gen_done && tid == 0) atomicAdd(a.gen_done, 1);
     k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
 }
@@ -742,6 +768,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     const bool fold = (a.PTfold != nullptr) && !batch;
     const size_t park_stride = (size_t)a.NF * a.LDv;
     const int fam0 = blockIdx.x * a.NF;
+    k2_wait_for_generation(a, tid);
     const int my_slot = k2_acquire_park_slot(a, s_colmax + a.NF, tid);   // (the word behind the column limits)
 
     for (int i = tid; i < a.n_ops * 12; i += blockDim.x) s_ops[i] = reinterpret_cast<const int*>(a.ops)[i];
@@ -958,6 +985,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     }
 
     k2_release_park_slot(a, s_colmax + a.NF, tid);
+    if (a.gen_done && tid == 0) atomicAdd(a.gen_done, 1);
     k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
 }
