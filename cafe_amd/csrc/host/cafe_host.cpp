@@ -779,6 +779,20 @@ struct cafehost_session {
     void set_prior_rfsize_empirical()
     {
         spec.clear();   // ... and to the prior they were computed under
+        if (!opt_prior_file.empty()) {
+            // Not in the reference (its searches always fit the Poisson below): a root-size prior given by the caller,
+            // one probability per line for root sizes root_min, root_min + 1, ... -- e.g. the distribution a simulated
+            // table was drawn from (bench.py's `generator_prior` search leg)
+            std::ifstream in(opt_prior_file);
+            if (!in) throw std::runtime_error("ERROR(prior_file): Cannot open " + opt_prior_file + " in read mode.");
+            prior.assign(1000, 0.0);
+            double v;
+            int n = 0;
+            while (n < 1000 && (in >> v)) prior[n++] = v;
+            if (n == 0) throw std::runtime_error("ERROR(prior_file): no values in " + opt_prior_file);
+            log("Root size prior read from %s (%d values)\n", opt_prior_file.c_str(), n);
+            return;
+        }
         std::vector<int> leaf_sizes;  // collect_leaf_sizes :789-806
         const int ns = (int)fam.species.size();
         for (int idx = 0; idx < fam.F(); ++idx)
@@ -855,6 +869,7 @@ struct cafehost_session {
     long spec_launches = 0, spec_points = 0, spec_hits = 0;
     int opt_speculate = -1;      // cafehost_set_option "speculate": -1 by how full the chip is, 0 off, 1 on
     bool opt_timing = false;     // "timing": phase times of report / the Monte-Carlo null on stderr
+    std::string opt_prior_file;  // "prior_file": root-size prior of the searches read from a file instead of fitted
 
     bool speculation_pays()
     {
@@ -2643,6 +2658,11 @@ int cafehost_set_option(cafehost_session* s, const char* key, const char* value)
     }
     if (k == "timing") {
         s->opt_timing = atoi(v.c_str()) != 0;
+        return 0;
+    }
+    if (k == "prior_file") {
+        s->opt_prior_file = v;
+        s->spec.clear();
         return 0;
     }
     // everything else is a switch of the device context(s)

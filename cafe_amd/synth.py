@@ -137,6 +137,20 @@ def simulate_families(tree, F, m, lam, mu, seed, root_cap=None):
     return rows
 
 
+def root_size_distribution(m, n=1000, root_cap=None):
+    """P(root = 1 + i), i < n, of the root draw in simulate_families: 1 + Poisson(8) with probability 0.9, uniform
+    on [1, cap] with probability 0.1, clipped to m."""
+    cap = root_cap if root_cap is not None else max(1, int(0.6 * m))
+    p = np.zeros(max(n, m + 1))
+    k = np.arange(len(p))
+    pois = np.exp(k * math.log(8.0) - 8.0 - np.array([math.lgamma(i + 1.0) for i in k]))
+    p += 0.9 * pois                      # index i <-> root 1 + i
+    p[:cap] += 0.1 / cap
+    p[m - 1] += p[m:].sum()              # np.minimum(root, m)
+    p[m:] = 0.0
+    return p[:n]
+
+
 def clade_classes(tree, n_classes):
     """Lambda classes by clade (the `lambda -t` tree of cafe/cafe_shell.c:334-393): the two subtrees below
     the root are split, largest first, until there are n_classes clades; every node of a clade (its top

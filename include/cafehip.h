@@ -70,6 +70,10 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *   vitlds          0|1        Viterbi argmax tables in LDS (0: global scratch)
  *   k2c_batch       0|1        factor-table kernel gathers the child columns of a state in one batch (1)
  *   batch_trim      0|1        batch mode: a tile's products stop at its largest column limit (1)
+ *   batch_lockstep  0|1        batch mode: workgroups start generation by generation, a generation = as many as the
+ *                              chip holds at once, so that co-resident tiles stream the same edge matrix through L2 (1)
+ *   batch_lockstep_slack 0..100  ... a generation starts when all but this percentage of the earlier ones finished (0)
+ *   walk_lockstep   0|1        the same pacing for the family walk of an objective evaluation (0: measured slower)
  *   comm            auto|direct|rccl   exchange mode of sharded evaluations (multi-GPU section below)
  * The same names, upper-cased behind CAFEHIP_ (CAFEHIP_COMPRESS=0 ...), are read from the environment ONCE, by
  * cafehip_create; nothing reads the environment during an evaluation.  Options that change the compression plan
@@ -86,8 +90,8 @@ int cafehip_get_stream(cafehip_ctx *ctx, void **hip_stream);
 
 /* Tree topology in the reference's nlist numbering (in-order: even ids are
  * leaves, odd ids internal; cafe/cafe_commands.cpp:2028-2051).  parent[root] = -1,
- * left/right = -1 for leaves.  Up to 4,095 nodes (2,048 taxa; a sanity bound -- every buffer is sized by the tree).  Branch lengths are truncated to int inside, as the
- * reference's cache key does (libtree/birthdeath.h:26-31, cafe/cafe_tree.c:376).
+ * left/right = -1 for leaves.  Up to 4,095 nodes (2,048 taxa; a sanity bound -- every buffer is sized by the
+ * tree).  Branch lengths are truncated to int inside, as the reference's cache key does (libtree/birthdeath.h:26-31, cafe/cafe_tree.c:376).
  * Replaces: cafe_tree_new + tree_build_node_list as consumed by
  * cafe_tree_set_birthdeath (cafe/cafe_tree.c:461-483). */
 int cafehip_set_tree(cafehip_ctx *ctx, int n_nodes, const int32_t *parent, const int32_t *left,

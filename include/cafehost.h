@@ -93,7 +93,10 @@ double cafehost_search_seconds(cafehost_session *s);                /* wall-cloc
 double cafehost_poisson_lambda(cafehost_session *s);
 
 /* Run-time switches: "speculate" (auto|0|1: batched candidate evaluation, below), "timing" (0|1: phase times of
- * report / the Monte-Carlo null on stderr); every other key is handed to cafehip_set_option on the session's device
+ * report / the Monte-Carlo null on stderr), "prior_file" (path, "" = off: the searches take the root-size prior from
+ * this file -- one probability per line for root sizes root_min, root_min + 1, ... -- instead of fitting the
+ * reference's empirical Poisson, cafe/lambda.cpp:808-870; an extension for tables whose root distribution is known);
+ * every other key is handed to cafehip_set_option on the session's device
  * context(s) (include/cafehip.h).  CAFEHOST_SPECULATE / CAFEHOST_TIMING in the environment are read once, by
  * cafehost_create. */
 int cafehost_set_option(cafehost_session *s, const char *key, const char *value);
