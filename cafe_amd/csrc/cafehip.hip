@@ -1171,6 +1171,12 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
                     }
                 }
             }
+            // A large batch runs better with two family groups of waves per workgroup: the second group shares the
+            // matrix operand through the CU's L1 and the trimmed tiles keep twice the waves busy (cfg 5 null on the
+            // table's 1,4,1,4: 11.7 ms, on 1,4,2,4: 11.1 ms; profiles/r03/mcnull_trimmed_counts_grids_mixing.txt)
+            if (!use4 && k.wf == 1 && 2 * k.wr <= 8 && n_items >= 8L * 32 * k.nft_w * std::max(c->n_cu, 1) &&
+                mfma_lds_bytes(c, 32 * k.nft_w, n_items) <= (size_t)c->lds_limit)
+                k.wf = 2;
         } else if (!enabled) {
             t.n_items = -1;
         } else {

@@ -221,6 +221,28 @@ __device__ __forceinline__ void mfma4_edge_p(k2_gbytes sb, const unsigned (&voff
 #undef CAFE_K2_REGION_L
 #undef CAFE_K2_REGION_N
 
+// Batch mode trims a tile's row tiles (the walk's prologue), so a wave can be dealt anything from 1 to NRT_W of them:
+// one instantiation of the product per live count -- a wave must not issue matrix instructions for columns it does
+// not own (round 3's first trimmed launch issued NRT_W columns whatever the count: trimming saved k-steps only).
+template <int NFT_W, int NRT_W, int NT, int D>
+__device__ __forceinline__ void mfma_edge_few(int ntile, k2_gbytes sb, const unsigned (&voff)[NRT_W], unsigned kstride_bytes,
+                                              const double* ap, int astride, int ksteps, cafe_d4 (&acc)[NFT_W][NRT_W])
+{
+    if constexpr (NT >= 1) {
+        if (ntile == NT) mfma_edge_p<NFT_W, NRT_W, NT, D>(sb, voff, kstride_bytes, ap, astride, ksteps, acc);
+        else mfma_edge_few<NFT_W, NRT_W, NT - 1, D>(ntile, sb, voff, kstride_bytes, ap, astride, ksteps, acc);
+    }
+}
+template <int G, int NRT_W, int NT, int D>
+__device__ __forceinline__ void mfma4_edge_few(int ntile, k2_gbytes sb, const unsigned (&voff)[NRT_W], unsigned kstride_bytes,
+                                               const double* ap4, int LDv, int ksteps, double (&acc)[G][NRT_W])
+{
+    if constexpr (NT >= 1) {
+        if (ntile == NT) mfma4_edge_p<G, NRT_W, NT, D>(sb, voff, kstride_bytes, ap4, LDv, ksteps, acc);
+        else mfma4_edge_few<G, NRT_W, NT - 1, D>(ntile, sb, voff, kstride_bytes, ap4, LDv, ksteps, acc);
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------------
 // Pieces shared by the two kernels
@@ -253,6 +275,7 @@ __device__ __forceinline__ void k2_release_park_slot(const K2MfmaArgs& a, const 
     // the root step ended with a workgroup barrier behind every read of the parks
     if (a.n_park_slots > 0 && tid == 0) atomicExch(&a.park_flags[*s_slot], 0);
 }
+
 
 // Batch mode, lock-step generations.  A batch launch is tens of resident-chip-fulls of workgroups, each streaming every
 // edge matrix of the tree (tens of MB in all) through a 4 MB L2: left alone, the resident workgroups drift apart until
@@ -654,10 +677,12 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                     const double* ap = Lsrc + (size_t)(ft0 * 16 + li) * a.LDv + lk;
                     const unsigned kstride_bytes = 32u * (unsigned)a.LD;
                     if constexpr (NRT_W > 1) {
-                        if (ntile == NRT_W - 1)
-                            mfma_edge_p<NFT_W, NRT_W, NRT_W - 1, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, t_ksteps, fac);
-                        else
+                        if (ntile == NRT_W)
                             mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, t_ksteps, fac);
+                        else if (ntile == NRT_W - 1)
+                            mfma_edge_p<NFT_W, NRT_W, NRT_W - 1, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, t_ksteps, fac);
+                        else   // a trimmed tile of a batch launch
+                            mfma_edge_few<NFT_W, NRT_W, NRT_W - 2, CAFE_K2_DEPTH16>(ntile, sb, voff, kstride_bytes, ap, 16 * a.LDv, t_ksteps, fac);
                     } else {
                         mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, t_ksteps, fac);
                     }
@@ -929,10 +954,12 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                     const double* ap4 = Lsrc + (size_t)(fbase + (lane & 3)) * a.LDv + lk;
                     const unsigned kstride_bytes = 32u * (unsigned)a.LD;
                     if constexpr (NRT_W > 1) {
-                        if (ntile == NRT_W - 1)
-                            mfma4_edge_p<G, NRT_W, NRT_W - 1, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, t_ksteps, fac);
-                        else
+                        if (ntile == NRT_W)
                             mfma4_edge_p<G, NRT_W, NRT_W, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, t_ksteps, fac);
+                        else if (ntile == NRT_W - 1)
+                            mfma4_edge_p<G, NRT_W, NRT_W - 1, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, t_ksteps, fac);
+                        else   // a trimmed tile of a batch launch
+                            mfma4_edge_few<G, NRT_W, NRT_W - 2, CAFE_K2_DEPTH4>(ntile, sb, voff, kstride_bytes, ap4, a.LDv, t_ksteps, fac);
                     } else {
                         mfma4_edge_p<G, NRT_W, NRT_W, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, t_ksteps, fac);
                     }

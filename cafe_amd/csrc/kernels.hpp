@@ -19,7 +19,7 @@ constexpr int kMaxTiles16 = 8;      // NFT_W * NRT_W accumulator tiles per wave 
 constexpr bool k2_fits16(int nft_w, int nrt_w) { return nft_w >= 1 && nft_w <= 2 && nrt_w >= 1 && nrt_w <= 7 && nft_w * nrt_w <= kMaxTiles16; }
 // (G, NRT_W) wave tiles of the 4-family kernel that compile without scratch spills at 2 waves per SIMD (256 registers
 // per lane; checked with tools/k2_regs.py after every kernel change)
-constexpr bool k2_fits4(int G, int nrt_w) { return G >= 1 && G <= 8 && nrt_w >= 1 && nrt_w <= 7 && G * nrt_w <= 18 && !(G == 8 && nrt_w == 2); }
+constexpr bool k2_fits4(int G, int nrt_w) { return G >= 1 && G <= 7 && nrt_w >= 1 && nrt_w <= 7 && G * nrt_w <= 18; }   // (8, 1): 20 B of scratch
 const void* k2_mfma16_kernel(int nft_w, int nrt_w);
 const void* k2_mfma4_kernel(int G, int nrt_w);
 

@@ -410,10 +410,12 @@ static void prune_node(prune_ctx *cx, int node)
     for (int i = 0; i < size; i++) Lv[i] = cx->left_factor[i] * cx->right_factor[i];
 }
 
-void orc_compute_tree_likelihoods(const orc_tree *t, const orc_range *range,
-                                  const orc_matrices *mats, const int *familysize,
-                                  const double *errormatrix, int err_mfs,
-                                  const unsigned char *leaf_has_err, double *L, int sof)
+/* the walk with the caller's two factor buffers (size_of_factor doubles each): the family loops below keep one pair per
+ * thread, so that a family costs no allocator call (the reference allocates its factors once per tree, cafe/cafe_tree.c:46-67) */
+static void tree_likelihoods_ws(const orc_tree *t, const orc_range *range, const orc_matrices *mats,
+                                const int *familysize, const double *errormatrix, int err_mfs,
+                                const unsigned char *leaf_has_err, double *L, int sof, double *left_factor,
+                                double *right_factor)
 {
     prune_ctx cx;
     cx.t = t;
@@ -425,11 +427,23 @@ void orc_compute_tree_likelihoods(const orc_tree *t, const orc_range *range,
     cx.leaf_has_err = leaf_has_err;
     cx.L = L;
     cx.sof = sof;
-    cx.left_factor = (double *)calloc(sof, sizeof(double));
-    cx.right_factor = (double *)calloc(sof, sizeof(double));
+    cx.left_factor = left_factor;
+    cx.right_factor = right_factor;
+    memset(left_factor, 0, sizeof(double) * (size_t)sof);
+    memset(right_factor, 0, sizeof(double) * (size_t)sof);
     prune_node(&cx, t->root);
-    free(cx.left_factor);
-    free(cx.right_factor);
+}
+
+void orc_compute_tree_likelihoods(const orc_tree *t, const orc_range *range,
+                                  const orc_matrices *mats, const int *familysize,
+                                  const double *errormatrix, int err_mfs,
+                                  const unsigned char *leaf_has_err, double *L, int sof)
+{
+    double *lf = (double *)malloc(sizeof(double) * (size_t)sof);
+    double *rf = (double *)malloc(sizeof(double) * (size_t)sof);
+    tree_likelihoods_ws(t, range, mats, familysize, errormatrix, err_mfs, leaf_has_err, L, sof, lf, rf);
+    free(lf);
+    free(rf);
 }
 
 /* cafe/lambda.cpp:657-689 */
@@ -478,6 +492,7 @@ double orc_eval_posterior(const orc_tree *t, int F, int n_leaves, const int *cou
 #endif
     {
         double *L = (double *)malloc(sizeof(double) * (size_t)t->n_nodes * sof);
+        double *lf = (double *)malloc(sizeof(double) * (size_t)sof * 2), *rf = lf + sof;
         int *fs = (int *)malloc(sizeof(int) * t->n_nodes);
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 16)
@@ -487,12 +502,12 @@ double orc_eval_posterior(const orc_tree *t, int F, int n_leaves, const int *cou
             if (ref && ref[i] >= 0 && ref[i] != i) continue;
             for (int k = 0; k < t->n_nodes; k++) fs[k] = -1;
             for (int j = 0; j < n_leaves; j++) fs[2 * j] = counts[(size_t)i * n_leaves + j];
-            orc_compute_tree_likelihoods(t, range, mats, fs, errormatrix, err_mfs, leaf_has_err,
-                                         L, sof);
+            tree_likelihoods_ws(t, range, mats, fs, errormatrix, err_mfs, leaf_has_err, L, sof, lf, rf);
             orc_compute_posterior(L + (size_t)t->root * sof, rfsize, prior, &fml[i], &fam[i],
                                   &fmp[i]);
         }
         free(L);
+        free(lf);
         free(fs);
     }
     double score = 0;

@@ -18,11 +18,19 @@ from cafe_amd import build as B  # noqa: E402
 def main():
     name, flags = sys.argv[1], sys.argv[2:]
     out_dir = os.path.join(ROOT, "tools", "_variants", name)
-    os.makedirs(out_dir, exist_ok=True)
+    obj_dir = os.path.join(out_dir, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
     out = os.path.join(out_dir, "libcafehip.so")
-    cmd = [B.hipcc()] + B.FLAGS + flags + ["-o", out] + [os.path.join(B.CSRC, s) for s in B.SOURCES]
-    print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    jobs, objs = [], []
+    for src in B.SOURCES:   # the translation units side by side, as cafe_amd/build.py compiles them
+        obj = os.path.join(obj_dir, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        jobs.append([B.hipcc()] + B.CFLAGS + flags + ["-c", "-o", obj, os.path.join(B.CSRC, src)])
+    print(" ".join(jobs[0]), "... (%d units)" % len(jobs), flush=True)
+    procs = [subprocess.Popen(j) for j in jobs]
+    if any(p.wait() != 0 for p in procs):
+        raise SystemExit("hipcc failed")
+    subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
     print(out)
 
 

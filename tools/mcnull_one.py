@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """The Monte-Carlo-null launch of BASELINE configs[4] on its own (for profiling): the table first (45 evaluations, no
-error model), then R x 1000 simulated rows through cafehip_eval_root_likelihoods, `reps` times.  Usage: python tools/mcnull_one.py [reps]"""
+error model), then R x 1000 simulated rows through cafehip_eval_root_likelihoods, `reps` times.
+Usage: python tools/mcnull_one.py [reps] [16:nftw,nrtw,wf,wr | 4:G,nrtw,wf,wr | key=value[;key=value] ...]
+(pinned wave grids / options of cafehip_set_option, applied cumulatively; one timing line per argument)"""
 import os
 import sys
 
@@ -31,11 +33,29 @@ def main():
     mats = {v: eng.get_matrix(v) for v in range(tree.n_nodes) if v != tree.root}
     rows, lo, cm = synth.simulate_null_rows(tree, mats, rng, 1000, cfg["seed"] + 77)
     eng.enable_timing(True)
-    ms = []
-    for _ in range(reps):
-        like = eng.eval_root_likelihoods(rows, lo, lo, cm)
-        ms.append(eng.last_batch_ms())
-    print("mcnull rows %d  launch ms %s  %s" % (len(lo), " ".join("%.3f" % x for x in ms), eng.describe()))
+    ref = None
+    for grid in [None] + sys.argv[2:]:
+        if grid and "=" in grid:
+            for kv in grid.split(";"):
+                eng.set_option(*kv.split("=", 1))
+        elif grid:
+            shape, cfg_ = grid.split(":")
+            eng.set_option("mfma", shape)
+            eng.set_option("k2cfg" if shape == "16" else "k2cfg4", cfg_)
+        ms = []
+        try:
+            for _ in range(reps):
+                like = eng.eval_root_likelihoods(rows, lo, lo, cm)
+                ms.append(eng.last_batch_ms())
+        except Exception as e:
+            print("mcnull %s: %s" % (grid, e))
+            continue
+        if ref is None:
+            ref = like
+        same = all(np.array_equal(a, b) for a, b in zip(ref, like)) if isinstance(like, (list, tuple)) else np.array_equal(ref, like)
+        d = eng.describe()
+        print("mcnull %s rows %d  launch ms %s  same=%s  %s" % (grid or "default", len(lo), " ".join("%.3f" % x for x in ms), same,
+                                                              d if grid is None else d[d.index("k2:"):d.index("grid=") + 12]))
     eng.close()
 
 
