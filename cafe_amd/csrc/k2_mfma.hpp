@@ -224,22 +224,25 @@ __device__ __forceinline__ void mfma4_edge_p(k2_gbytes sb, const unsigned (&voff
 // Batch mode trims a tile's row tiles (the walk's prologue), so a wave can be dealt anything from 1 to NRT_W of them:
 // one instantiation of the product per live count -- a wave must not issue matrix instructions for columns it does
 // not own (round 3's first trimmed launch issued NRT_W columns whatever the count: trimming saved k-steps only).
-template <int NFT_W, int NRT_W, int NT, int D>
+// (Deeper operand rings for the short regions of these products -- as deep as the registers of the NRT_W-tile product
+// allow -- changed nothing for the Monte-Carlo-null launch and cost the objective walk at configs[2] 2.5 %: same box,
+// profiles/r03/mcnull_trimmed_counts_grids_mixing.txt.)
+template <int NFT_W, int NRT_W, int NT>
 __device__ __forceinline__ void mfma_edge_few(int ntile, k2_gbytes sb, const unsigned (&voff)[NRT_W], unsigned kstride_bytes,
                                               const double* ap, int astride, int ksteps, cafe_d4 (&acc)[NFT_W][NRT_W])
 {
     if constexpr (NT >= 1) {
-        if (ntile == NT) mfma_edge_p<NFT_W, NRT_W, NT, D>(sb, voff, kstride_bytes, ap, astride, ksteps, acc);
-        else mfma_edge_few<NFT_W, NRT_W, NT - 1, D>(ntile, sb, voff, kstride_bytes, ap, astride, ksteps, acc);
+        if (ntile == NT) mfma_edge_p<NFT_W, NRT_W, NT, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, astride, ksteps, acc);
+        else mfma_edge_few<NFT_W, NRT_W, NT - 1>(ntile, sb, voff, kstride_bytes, ap, astride, ksteps, acc);
     }
 }
-template <int G, int NRT_W, int NT, int D>
+template <int G, int NRT_W, int NT>
 __device__ __forceinline__ void mfma4_edge_few(int ntile, k2_gbytes sb, const unsigned (&voff)[NRT_W], unsigned kstride_bytes,
                                                const double* ap4, int LDv, int ksteps, double (&acc)[G][NRT_W])
 {
     if constexpr (NT >= 1) {
-        if (ntile == NT) mfma4_edge_p<G, NRT_W, NT, D>(sb, voff, kstride_bytes, ap4, LDv, ksteps, acc);
-        else mfma4_edge_few<G, NRT_W, NT - 1, D>(ntile, sb, voff, kstride_bytes, ap4, LDv, ksteps, acc);
+        if (ntile == NT) mfma4_edge_p<G, NRT_W, NT, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, LDv, ksteps, acc);
+        else mfma4_edge_few<G, NRT_W, NT - 1>(ntile, sb, voff, kstride_bytes, ap4, LDv, ksteps, acc);
     }
 }
 
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                         else if (ntile == NRT_W - 1)
                             mfma_edge_p<NFT_W, NRT_W, NRT_W - 1, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, t_ksteps, fac);
                         else   // a trimmed tile of a batch launch
-                            mfma_edge_few<NFT_W, NRT_W, NRT_W - 2, CAFE_K2_DEPTH16>(ntile, sb, voff, kstride_bytes, ap, 16 * a.LDv, t_ksteps, fac);
+                            mfma_edge_few<NFT_W, NRT_W, NRT_W - 2>(ntile, sb, voff, kstride_bytes, ap, 16 * a.LDv, t_ksteps, fac);
                     } else {
                         mfma_edge_p<NFT_W, NRT_W, NRT_W, CAFE_K2_DEPTH16>(sb, voff, kstride_bytes, ap, 16 * a.LDv, t_ksteps, fac);
                     }
@@ -959,7 +962,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                         else if (ntile == NRT_W - 1)
                             mfma4_edge_p<G, NRT_W, NRT_W - 1, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, t_ksteps, fac);
                         else   // a trimmed tile of a batch launch
-                            mfma4_edge_few<G, NRT_W, NRT_W - 2, CAFE_K2_DEPTH4>(ntile, sb, voff, kstride_bytes, ap4, a.LDv, t_ksteps, fac);
+                            mfma4_edge_few<G, NRT_W, NRT_W - 2>(ntile, sb, voff, kstride_bytes, ap4, a.LDv, t_ksteps, fac);
                     } else {
                         mfma4_edge_p<G, NRT_W, NRT_W, CAFE_K2_DEPTH4>(sb, voff, kstride_bytes, ap4, a.LDv, t_ksteps, fac);
                     }
