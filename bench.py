@@ -211,6 +211,7 @@ class Leg:
         t3 = time.perf_counter()
         if comm and comm["kind"] == "native":
             eng.comm_set_blocks(wl.bounds)
+        self.torch_step = comm["make_step"](wl) if comm and comm.get("make_step") else None
         self.setup = {"set_tree_ms": 1e3 * (t1 - t0), "set_families_ms": 1e3 * (t2 - t1), "set_error_model_ms": 1e3 * (t3 - t2),
                       "set_families_detail_ms": eng.last_setup_ms(),
                       "what": "one-time set-up of this table (host wall-clock; SURVEY.md 8(d): reported apart from the evaluations): "
@@ -232,7 +233,7 @@ class Leg:
         elif self.comm["kind"] == "native":
             score, fz = eng.get_posterior_sharded(nl, nm, self.wl.prior)
         else:
-            score = self.comm["torch_step"](eng, nl, nm, self.wl.prior)
+            score = self.torch_step(eng, nl, nm, self.wl.prior)
         if timed:
             self.kernel_ms.append(list(eng.last_kernel_ms()) + [eng.last_tables_ms(), eng.comm_info()["exchange_ms"] if self.comm else 0.0])
             eng.enable_timing(False)
@@ -542,21 +543,45 @@ def main():
     eng = cafe_amd.Engine(local_rank)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
+    native_error = None
     if multi and args.comm == "native":
-        eng.set_option("comm", args.comm_mode)
-        eng.comm_init(rank, world, comm_id)
-    leg = Leg(wl, local_rank, comm, shared_engine=eng)
+        # the library's own exchange; if it cannot be set up on this node (no shared memory, peer mapping AND librccl
+        # refused) every rank falls back to the torch.distributed path together, and the line says so
+        try:
+            if os.environ.get("BENCH_FORCE_NATIVE_FAILURE") == str(rank):
+                raise RuntimeError("forced by BENCH_FORCE_NATIVE_FAILURE (test of the fallback)")
+            eng.set_option("comm", args.comm_mode)
+            eng.comm_init(rank, world, comm_id)
+        except Exception as e:   # noqa: BLE001 -- whatever it is, the other ranks must hear about it
+            native_error = "%s: %s" % (type(e).__name__, e)
+        errs = [None] * world
+        dist.all_gather_object(errs, native_error)
+        if any(errs):
+            native_error = "; ".join("rank %d: %s" % (r, e) for r, e in enumerate(errs) if e)
+            sys.stderr.write("bench.py: native exchange unavailable (%s) -- falling back to --comm torch\n" % native_error)
+            args.comm = "torch"
+            dist.destroy_process_group()
+            backend = args.backend or ("gloo" if args.same_device else "nccl")
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend=backend)
+            comm = {"kind": "torch", "backend": backend, "barrier": lambda eng: dist.barrier()}
+        else:
+            native_error = None
     if multi and args.comm == "torch":
-        slots = max(1, max((hi - lo + D.CHUNK - 1) // D.CHUNK for lo, hi in wl.bounds))
-        packed, p_chunks, p_fz = D.packed_buffer(torch, slots, "cuda")
-        gathered = torch.zeros((slots + 1) * world, dtype=torch.float64, device="cuda")
+        def make_torch_step(w):   # per workload: the packed buffers are sized by its blocks
+            slots = max(1, max((hi - lo + D.CHUNK - 1) // D.CHUNK for lo, hi in w.bounds))
+            packed, p_chunks, p_fz = D.packed_buffer(torch, slots, "cuda")
+            gathered = torch.zeros((slots + 1) * world, dtype=torch.float64, device="cuda")
 
-        def torch_step(e, nl, nm, prior):
-            e.eval_posterior_async(nl, nm, prior, p_chunks, p_fz)
-            score, fz = D.exchange_packed(dist, torch, packed, gathered, slots, wl.bounds, None, engine=e)
-            return score
-        comm["torch_step"] = torch_step
-
+            def torch_step(e, nl, nm, prior):
+                e.eval_posterior_async(nl, nm, prior, p_chunks, p_fz)
+                score, fz = D.exchange_packed(dist, torch, packed, gathered, slots, w.bounds, None, engine=e)
+                return score
+            return torch_step
+        comm["make_step"] = make_torch_step
+    leg = Leg(wl, local_rank, comm, shared_engine=eng)
     leg.prepare_rates(args.warmup + args.steps + MIN_KERNEL_SAMPLES)
     priming = leg.prime(fixed_count=(1000 if F_local <= 20000 else 60) if multi else None)
     dt, last = leg.run(args.warmup, args.steps, rank=rank)
@@ -613,6 +638,8 @@ def main():
         info = eng.comm_info() if args.comm == "native" else {}
         out["rccl_ranks"] = world
         out["comm"] = args.comm
+        if native_error:
+            out["comm_fallback"] = "the native exchange could not be set up: " + native_error
         if rank == 0:
             out["exchange"] = exchange_report(args, leg, eng, info, wl, rank, world) if args.comm == "native" else \
                 {"mode": "torch.distributed " + comm["backend"], "note": "round-2 path: packed all_gather through torch + cafehip_fetch_small"}

@@ -65,3 +65,16 @@ def test_forced_one_rank_run_goes_through_the_native_exchange():
     assert "rccl" in x and ("error" in x["rccl"] or x["rccl"]["exchange_ms_per_step"] > 0)
     assert forced["config"]["last_score"] == plain["config"]["last_score"]     # same step, same table: same bits
     assert forced["ms_per_step"] < 1.25 * plain["ms_per_step"]
+
+
+def test_native_exchange_failure_falls_back_to_the_torch_path_on_every_rank(monkeypatch):
+    # a node where the library's exchange cannot be set up must still produce the line (through torch.distributed),
+    # and say so: the failure is injected on rank 0 of a forced one-rank run
+    env = dict(os.environ, BENCH_FORCE_NATIVE_FAILURE="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "16", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-search", "--no-probes", "--no-strong", "--no-tables"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    assert d["comm"] == "torch" and "forced by BENCH_FORCE_NATIVE_FAILURE" in d["comm_fallback"]
+    assert d["value"] > 1e6 and d["exchange"]["mode"].startswith("torch.distributed")
