@@ -449,6 +449,7 @@ def measured_peaks(device):
 # main
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
+    t_bench0 = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -684,6 +685,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(wl, eng)
 
     if rank == 0:
+        out["bench_wall_s"] = time.perf_counter() - t_bench0   # the whole script: table generation, all legs, CPU baseline
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     eng.close()
     if multi:

@@ -791,6 +791,7 @@ struct cafehost_session {
             while (n < 1000 && (in >> v)) prior[n++] = v;
             if (n == 0) throw std::runtime_error("ERROR(prior_file): no values in " + opt_prior_file);
             log("Root size prior read from %s (%d values)\n", opt_prior_file.c_str(), n);
+            (void)unifrnd();   // the fit's random start: the stream stays where the reference's flow would leave it
             return;
         }
         std::vector<int> leaf_sizes;  // collect_leaf_sizes :789-806

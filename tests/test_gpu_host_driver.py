@@ -554,3 +554,45 @@ def test_score_command(shell, tmp_path):
         s2.close()
     txt = open(str(tmp_path / "log2.txt")).read()
     assert ("Lambda : %15.14f Mu : %15.14f & Score: %f" % (0.0017, 0.0012, sc)) in txt
+
+
+def test_prior_file_option_replaces_the_fitted_poisson(tmp_path):
+    """cafehost_set_option("prior_file", path) -- an extension, the reference always fits its Poisson -- : (1) a file that
+    holds exactly the prior the fit would have produced leaves a whole search unchanged, evaluation by evaluation;
+    (2) any other prior gives the score the oracle computes under it."""
+    from cafe_amd.shell import CafeShell
+    newick, path, ids, counts, t = _example()
+
+    def session(prior_path, commands):
+        s = CafeShell(0, str(tmp_path / "log.txt"))
+        try:
+            if prior_path:
+                s.set_option("prior_file", prior_path)
+            s.dispatch("seed 10")
+            s.dispatch("load -i %s -t 1" % path)
+            s.dispatch("tree " + newick)
+            for c in commands:
+                s.dispatch(c)
+            return s.poisson_lambda, s.score, list(s.params), s.iterations, s.trace()
+        finally:
+            s.close()
+
+    lam_p, score, params, iters, trace = session(None, ["lambda -s"])
+    rng = O.range_from_max(int(counts.max()))
+    same = tmp_path / "fitted_prior.txt"
+    np.savetxt(same, O.prior_poisson(1000, rng.root_min, lam_p), fmt="%.17g")
+    _, score2, params2, iters2, trace2 = session(str(same), ["lambda -s"])
+    assert iters2 == iters and len(trace2) == len(trace)
+    assert all(a[0] == b[0] for a, b in zip(trace, trace2))                       # the same lambdas were asked for
+    assert np.allclose([a[1] for a in trace], [b[1] for b in trace2], rtol=1e-12, atol=0)
+    assert params2 == pytest.approx(params, rel=1e-12) and score2 == pytest.approx(score, rel=1e-12)
+
+    other = tmp_path / "flat_prior.txt"
+    flat = np.zeros(1000)
+    flat[:60] = 1.0 / 60
+    np.savetxt(other, flat, fmt="%.17g")
+    _, score3, *_ = session(str(other), ["lambda -l 0.0017 -score"])
+    so, *_ = O.eval_posterior(t, counts, rng, np.full(t.n_nodes, 0.0017), np.full(t.n_nodes, -1.0), flat)
+    assert score3 == pytest.approx(-so, rel=1e-12)
+    with pytest.raises(Exception):
+        session(str(tmp_path / "missing.txt"), ["lambda -l 0.0017"])

@@ -1,0 +1,20 @@
+#!/bin/bash
+# round 3, call v (final numbers of the round): whole GPU suite, then the round's measurements: bench lines (cfg2..cfg5, one-rank native, 2 ranks on one device),
+# rocprofv3 kernel stats + timeline of the default bench command, PMC traffic of every workload
+mkdir -p gpurun_out/r03v; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r03v; R=$GRAFT_REPO_ROOT
+(timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log); tail -2 $O/smoke.log
+(timeout 2700 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log); tail -6 $O/pytest_gpu.log | cut -c1-200
+(timeout 900 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err; echo "rc=$?" >> $O/bench_cfg2.err); head -c 300 $O/bench_cfg2.json; echo
+for c in cfg3 cfg4 cfg5; do
+  (timeout 900 python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; echo "rc=$?" >> $O/bench_$c.err); head -c 300 $O/bench_$c.json; echo
+done
+(timeout 600 python bench.py --gpus 1 --force-dist --no-cpu-baseline --no-search --no-probes > $O/bench_cfg2_one_rank_native.json 2> $O/bench_forcedist.err; echo "rc=$?" >> $O/bench_forcedist.err)
+(timeout 900 python bench.py --gpus 2 --same-device --no-cpu-baseline --no-search --no-probes > $O/bench_cfg2_2rank_same_device.json 2> $O/bench_2rank.err; echo "rc=$?" >> $O/bench_2rank.err)
+cd /tmp && (timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -o r -- python $R/bench.py --no-cpu-baseline --no-search --no-probes --no-strong --no-tables > $O/kt_bench_line.json 2>$O/kt.err); cd $R
+DB=$(find /tmp/kt -name "*.db" | head -1)
+python tools/rocpd_stats.py $DB > $O/kernel_stats_cfg2.txt 2>&1; python tools/step_timeline.py $DB 150 > $O/timeline_cfg2.txt 2>&1; cat $O/timeline_cfg2.txt
+for c in cfg3 cfg4; do
+cd /tmp && rm -rf /tmp/kt2 && (timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o r -- python $R/bench.py --config $c --steps 60 --no-cpu-baseline --no-search --no-probes > $O/kt_bench_line_$c.json 2>$O/kt_$c.err); cd $R
+python tools/rocpd_stats.py $(find /tmp/kt2 -name "*.db" | head -1) > $O/kernel_stats_$c.txt 2>&1; python tools/step_timeline.py $(find /tmp/kt2 -name "*.db" | head -1) 40 > $O/timeline_$c.txt 2>&1
+done
+(timeout 2400 python tools/collect_pmc.py $O/pmc > $O/pmc.log 2>&1; echo "rc=$?" >> $O/pmc.log); tail -7 $O/pmc.log | cut -c1-300
