@@ -59,6 +59,7 @@ HOST_SIGNATURES = {
     "cafehost_destroy": (None, [C.c_void_p]),
     "cafehost_dispatch": (C.c_int, [C.c_void_p, C.c_char_p]),
     "cafehost_run_script": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "cafehost_rng_selftest": (C.c_int, [C.c_uint, C.c_int, C.c_int, C.c_int]),
     "cafehost_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "cafehost_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "cafehost_shard_bounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

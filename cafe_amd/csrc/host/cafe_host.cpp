@@ -430,6 +430,34 @@ struct GlibcRand {
         random_r(&rd, &r);
         return r / (RAND_MAX + 1.0);
     }
+    static double to_unit(int32_t r) { return r / (RAND_MAX + 1.0); }
+    // The next n values of rand() in one tight loop (the Monte-Carlo null draws 15 million of them): the additive
+    // feedback step of glibc's random_r for its default TYPE_3 generator -- *fptr += *rptr, result = *fptr >> 1,
+    // both pointers advance and wrap -- on the generator's own state, so single draws before and after continue
+    // the same stream.  Any other generator type falls back to random_r.
+    void fill_raw(int32_t* out, size_t n)
+    {
+        if (rd.rand_type != 3 || !rd.fptr || !rd.rptr || !rd.end_ptr || !rd.state) {
+            for (size_t i = 0; i < n; ++i) random_r(&rd, &out[i]);
+            return;
+        }
+        int32_t *f = rd.fptr, *r = rd.rptr, *const end = rd.end_ptr, *const st = rd.state;
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t val = (uint32_t)*f + (uint32_t)*r;
+            *f = (int32_t)val;
+            out[i] = (int32_t)(val >> 1);
+            ++f;
+            if (f >= end) {
+                f = st;
+                ++r;
+            } else {
+                ++r;
+                if (r >= end) r = st;
+            }
+        }
+        rd.fptr = f;
+        rd.rptr = r;
+    }
 };
 
 // poisspdf, libcommon/mathfunc.c:352-355
@@ -1725,25 +1753,35 @@ struct cafehost_session {
         // order); root sizes are then independent of each other (the running-minimum column limit is per root
         // size), so worker threads take whole root sizes -- the reference threads split them the same way
         // (cafe/conditional_distribution.cpp:88-108) -- and the result does not depend on the thread count.
+        const bool show_times = opt_timing;
+        auto t_phase = std::chrono::steady_clock::now();
+        auto phase = [&](const char* what) {
+            if (!show_times) return;
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "null: %-44s %.3f s\n", what, std::chrono::duration<double>(now - t_phase).count());
+            t_phase = now;
+        };
         const size_t per_family = prefix.size() - 1;
-        std::vector<double> rnd((size_t)R * trials * per_family);
-        for (double& x : rnd) x = unifrnd();
+        std::vector<int32_t> rnd((size_t)R * trials * per_family);
+        rng.fill_raw(rnd.data(), rnd.size());
+        phase("random numbers in the reference's order");
         CdfCache cdf;
         cdf.reset(mats, S);
         cdf.build_all();  // read-only afterwards
+        phase("cumulative rows of the matrices");
         auto sample_root_size = [&](int si) {
             const int s = range.root_min + si;
             const int maxFamilySize = std::max(s, range.max);  // get_random_probabilities :20
             int rmax = range.max;
             std::vector<int> fs(tree.n);
             size_t row = (size_t)si * trials;
-            const double* r = rnd.data() + row * per_family;
+            const int32_t* r = rnd.data() + row * per_family;
             for (int t = 0; t < trials; ++t, ++row) {
                 int mx = 0;
                 fs[tree.root] = s;
                 for (int v : prefix) {
                     if (v == tree.root) continue;
-                    const int c = cdf.draw(v, fs[tree.parent[v]], *r++, maxFamilySize);
+                    const int c = cdf.draw(v, fs[tree.parent[v]], GlibcRand::to_unit(*r++), maxFamilySize);
                     fs[v] = c;
                     if (mx < c) mx = c;
                 }
@@ -1763,7 +1801,7 @@ struct cafehost_session {
                 });
             for (auto& th : pool) th.join();
         }
-        const bool show_times = opt_timing;
+        phase("inverse-CDF draws (threads by root size)");
         const auto t_sampled = std::chrono::steady_clock::now();
         std::vector<double> probs((size_t)R * trials);
         if (report_sharded()) {
@@ -1792,6 +1830,8 @@ struct cafehost_session {
             std::copy(probs.begin() + (size_t)i * trials, probs.begin() + (size_t)(i + 1) * trials, cond_dist[i].begin());
             std::sort(cond_dist[i].begin(), cond_dist[i].end());  // :41
         }
+        t_phase = std::chrono::steady_clock::now() - (std::chrono::steady_clock::now() - t_phase);
+        phase("likelihoods (GPU) + sorting the samples");
     }
 
     int cmd_report(const std::vector<std::string>& tokens)
@@ -2670,6 +2710,25 @@ int cafehost_set_option(cafehost_session* s, const char* key, const char* value)
     if (cafehip_set_option(s->ctx, key, v.c_str()) != 0) return host_fail(std::string("cafehip: ") + cafehip_last_error());
     if (s->ctx_one && cafehip_set_option(s->ctx_one, key, v.c_str()) != 0) return host_fail(std::string("cafehip: ") + cafehip_last_error());
     s->spec.clear();
+    return 0;
+}
+
+int cafehost_rng_selftest(unsigned seed, int n_before, int n_bulk, int n_after)
+{
+    // the bulk draw of the Monte-Carlo null against glibc's own random_r, single draws on either side of it
+    GlibcRand a, b;
+    a.seed(seed);
+    b.seed(seed);
+    const int n = std::max(n_before, 0) + std::max(n_bulk, 0) + std::max(n_after, 0);
+    std::vector<int32_t> want(n), got(n);
+    for (int i = 0; i < n; ++i) random_r(&a.rd, &want[i]);
+    int k = 0;
+    for (int i = 0; i < n_before; ++i) random_r(&b.rd, &got[k++]);
+    if (n_bulk > 0) b.fill_raw(got.data() + k, (size_t)n_bulk);
+    k += std::max(n_bulk, 0);
+    for (int i = 0; i < n_after; ++i) random_r(&b.rd, &got[k++]);
+    for (int i = 0; i < n; ++i)
+        if (want[i] != got[i]) return host_fail("bulk random stream differs from random_r at draw " + std::to_string(i));
     return 0;
 }
 

@@ -36,6 +36,12 @@ int cafehost_dispatch(cafehost_session *s, const char *command_line);
 /* Run a script file (main.cpp:43 `source`): one command per line, '#' lines ignored. */
 int cafehost_run_script(cafehost_session *s, const char *path);
 
+/* Test hook (no session, no GPU): the Monte-Carlo null draws its ~15 million uniforms in one loop over the state of
+ * glibc's default generator instead of 15 million random_r calls; returns 0 when n_before single draws, n_bulk bulk
+ * draws and n_after single draws after srandom(seed) reproduce random_r's own stream (the reference's rand(),
+ * libcommon/mathfunc.c unifrnd). */
+int cafehost_rng_selftest(unsigned seed, int n_before, int n_bulk, int n_after);
+
 /* ---- multi-GPU (one process per GPU) ------------------------------------------------------------
  * Every rank runs the same script (same seed => same Nelder-Mead decisions); a rank scores only its
  * chunk-aligned block of the family table and the ranks exchange the per-chunk partial sums once per

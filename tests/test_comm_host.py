@@ -38,3 +38,12 @@ def test_a_missing_rank_fails_the_call_instead_of_hanging(tmp_path, monkeypatch)
     assert p.returncode == 0
     res = json.load(open(out))
     assert not res["ok"] and "rendezvous timed out" in res["err"], res
+
+
+def test_bulk_random_draws_continue_glibc_random_r_stream():
+    # the Monte-Carlo null draws its uniforms in one loop over the generator's state (cafe_host.cpp GlibcRand::fill_raw):
+    # the same values as random_r, whatever is drawn singly before and after, across several wraps of the 31-word state
+    from cafe_amd import _lib
+    L = _lib.load()
+    for seed, before, bulk, after in ((10, 0, 1000, 5), (10, 7, 100003, 64), (1, 33, 31, 2), (12345, 1, 0, 3), (7, 0, 1, 0)):
+        assert L.cafehost_rng_selftest(seed, before, bulk, after) == 0, L.cafehost_last_error()
