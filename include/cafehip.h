@@ -233,7 +233,7 @@ int cafehip_viterbi(cafehip_ctx *ctx, int B, const int32_t *counts, const int32_
  * takes the same decisions and nothing is broadcast.  Two exchange modes (option "comm" = auto | direct | rccl):
  *   direct  the score kernel of every rank stores its row straight into an uncached buffer of every other rank
  *           (hipIpc-mapped, over xGMI) and waits for the others' flags: no collective launch, the sharded evaluation
- *           is the same three launches as the single-GPU one.  Used when every rank could map every buffer.
+ *           is the same launches as the single-GPU one.  Used when every rank could map every buffer.
  *   rccl    ONE ncclAllGather of the rows on the context's stream (librccl resolved with dlopen when first needed),
  *           picked up with cafehip_fetch_small.
  * Rendezvous, barriers and the all-gather of host blocks (report phase) run over a POSIX shared-memory segment named
