@@ -249,6 +249,9 @@ class Leg:
         """Untimed evaluations before the W warm-up steps: scratch allocation, the library's measured choice of the K2
         wave grid (up to ~30 evaluations) and the clock ramp -- at least 40 evaluations and 0.25 s of them (with several
         ranks every step contains an exchange, so the count must be the same everywhere: fixed)."""
+        if self.comm is not None:
+            self.barrier()   # ranks arrive here seconds apart (table generation, rank 0's probes): align them on the HOST
+                             # before the first evaluation, whose exchange waits inside a kernel
         n, t0 = 0, time.perf_counter()
         while (n < fixed_count) if fixed_count else (n < 40 or time.perf_counter() - t0 < 0.25):
             self.step(n)

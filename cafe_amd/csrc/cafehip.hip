@@ -1552,7 +1552,10 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
             x.rows[r] = CommLink::rows_of(L.peer_xbuf[r], parity);
             x.flags[r] = reinterpret_cast<unsigned long long*>(CommLink::flags_of(L.peer_xbuf[r], parity));
         }
-        x.timeout_ticks = 30LL * 100000000LL;   // 30 s of the 100 MHz wall clock: a rank that died must not hang the others' GPUs
+        // a rank that died must not hang the others' GPUs; a rank that is merely late (it wrote a report, loaded a table)
+        // must not be mistaken for one: the same patience as the host-side barriers (comm_timeout_s, 120 s), in ticks
+        // of the 100 MHz wall clock.  Each rank decides alone when to give up -- nothing here needs the ranks to agree.
+        x.timeout_ticks = (long long)(comm_timeout_s() * 1e8);
         if (launch_kernel(k3x_kernel(), dim3(std::max(c->n_chunks, 1)), dim3(CAFEHIP_CHUNK), 0, c->stream, x)) return -1;
     } else if (c->n_chunks > 0) {
         K3Args k3{c->d_max_post, c->d_max_lik, c->F == c->Fu ? nullptr : c->d_fam2u, c->F, c->Fu, d_chunk_sums, d_first_zero, nullptr, nullptr, 0};
@@ -2692,7 +2695,7 @@ int cafehip_eval_posterior_sharded(cafehip_ctx* c, const double* node_lambda, co
         if (eval_device(c, node_lambda, node_mu, prior, nullptr, c->d_first_zero, true, 1, true)) return -1;
         bool peer_timeout = false;
         if (wait_host_seq(c, c->host_seq, &peer_timeout)) return -1;
-        if (peer_timeout) return fail("direct exchange: a rank did not deliver its row within 30 s");
+        if (peer_timeout) return fail("direct exchange: a rank did not deliver its row within %.0f s", comm_timeout_s());
         rows = c->h_result->chunk_sums;
     } else {
         if (!L.rccl && !L.ensure_rccl()) return fail("RCCL exchange: %s", L.error.c_str());
