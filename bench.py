@@ -918,6 +918,22 @@ def lambda_search_wallclock(wl):
     return res
 
 
+def cgroup_cpu_quota():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max or v1 cfs quota / period); None = unlimited or
+    unknown.  Printed next to the team sizes tried: a quota below the core count is why the largest teams lose."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def physical_cores():
     """(physical cores, hardware threads) of this box from lscpu."""
     try:
@@ -995,6 +1011,7 @@ def cpu_baseline(wl, eng):
         "physical_cores": phys,
         "hardware_threads": hw,
         "threads_available_to_this_process": avail,
+        "cgroup_cpu_quota_cores": cgroup_cpu_quota(),
         "kind": "port",
         "build": "oracle/cafe_oracle.c, gcc -O3 -march=native -ffp-contract=off -fopenmp, built on this box",
         "sample": "one objective evaluation of the first %d families of the bench table, OpenMP over families on "
