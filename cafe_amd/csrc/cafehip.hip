@@ -249,6 +249,7 @@ struct cafehip_ctx {
     int err_mfs = -1;
     int err_banded = 0, err_dlo = 0, err_dhi = 0, err_band_width = 0;
     uint8_t* d_leaf_has_err = nullptr;
+    int32_t* d_leaf_has_err32 = nullptr;   // the same flags as 32-bit words: k2c_nodes reads them with scalar loads
 
     // pinned, device-visible result block of the synchronous path
     HostResult* h_result = nullptr;
@@ -840,11 +841,36 @@ int rebuild_compression(cafehip_ctx* c)
     return upload_col_has_err(c);
 }
 
-int launch_k2c_inst(cafehip_ctx* c, const void* fn, int nft_w, const K2cArgs& a, int grid, int n_sets, int block)
+int launch_k2c_inst(cafehip_ctx* c, const void* fn, int nft_w, const K2cArgs& a_in, int grid, int n_sets, int block)
 {
+    K2cArgs a = a_in;
+    a.block_threads = block;
     const size_t lds = (size_t)16 * nft_w * c->LDv * sizeof(double);
     if (!fn) return fail("internal: no k2c_nodes instantiation for this shape");
     if (grant_lds(c, fn, lds, 64 * 1024)) return -1;
+#ifdef CAFE_K2_STAMPS
+    if (const char* stamps_file = getenv("CAFEHIP_STAMPS_FILE")) {
+        // debug builds: per (tile, wave) s_memtime stamps of this level, appended to <file>.k2c
+        K2cArgs b = a;
+        const size_t n = (size_t)grid * 16 * 8;
+        unsigned long long* d = nullptr;
+        HIP_TRY(hipMalloc(&d, n * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(d, 0, n * sizeof(unsigned long long), c->stream));
+        b.stamps = d;
+        if (launch_kernel(fn, dim3(grid, n_sets), dim3(block), lds, c->stream, b)) return -1;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<unsigned long long> h(n);
+        HIP_TRY(hipMemcpy(h.data(), d, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        hipFree(d);
+        if (FILE* f = fopen((std::string(stamps_file) + ".k2c").c_str(), "ab")) {
+            const long long hdr[4] = {grid, block / 64, 8, 0};
+            fwrite(hdr, sizeof hdr, 1, f);
+            fwrite(h.data(), sizeof(unsigned long long), n, f);
+            fclose(f);
+        }
+        return 0;
+    }
+#endif
     return launch_kernel(fn, dim3(grid, n_sets), dim3(block), lds, c->stream, a);
 }
 
@@ -872,7 +898,7 @@ int launch_compressed_levels(cafehip_ctx* c, int n_sets)
     a.PTfold = (c->d_err && c->fold_current) ? c->d_PTfold : nullptr;
     a.node_key = c->d_node_key;
     a.n_nodes = c->n_nodes;
-    a.leaf_has_err = c->d_leaf_has_err;
+    a.leaf_has_err32 = c->d_leaf_has_err32;
     a.tables = p.d_tables;
     a.table_set_stride = p.table_elems;
     a.C = c->C;
@@ -1765,6 +1791,7 @@ void cafehip_destroy(cafehip_ctx* c)
     hipFree(c->d_logprior);
     hipFree(c->d_err);
     hipFree(c->d_leaf_has_err);
+    hipFree(c->d_leaf_has_err32);
     hipFree(c->d_first_zero);
     for (int i = 0; i < kParamRing; ++i) {
         if (c->h_params[i]) hipHostFree(c->h_params[i]);
@@ -2047,8 +2074,10 @@ int cafehip_set_error_model(cafehip_ctx* c, int mfs, const double* errormatrix,
     HIP_TRY(hipStreamSynchronize(c->stream));
     hipFree(c->d_err);
     hipFree(c->d_leaf_has_err);
+    hipFree(c->d_leaf_has_err32);
     c->d_err = nullptr;
     c->d_leaf_has_err = nullptr;
+    c->d_leaf_has_err32 = nullptr;
     c->err_mfs = -1;
     c->h_leaf_has_err.clear();
     if (!errormatrix) return upload_col_has_err(c);
@@ -2076,6 +2105,11 @@ int cafehip_set_error_model(cafehip_ctx* c, int mfs, const double* errormatrix,
     for (int i = 0; i < c->n_nodes; i += 2) by_col[i / 2] = leaf_has_model ? leaf_has_model[i] : 1;
     HIP_TRY(hipMalloc(&c->d_leaf_has_err, by_col.size()));
     HIP_TRY(hipMemcpy(c->d_leaf_has_err, by_col.data(), by_col.size(), hipMemcpyHostToDevice));
+    {
+        std::vector<int32_t> w(by_col.begin(), by_col.end());
+        HIP_TRY(hipMalloc(&c->d_leaf_has_err32, w.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(c->d_leaf_has_err32, w.data(), w.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     c->h_leaf_has_err = by_col;
     c->err_mfs = mfs;
     return upload_col_has_err(c);

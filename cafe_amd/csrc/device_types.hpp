@@ -171,10 +171,13 @@ struct K2cArgs {
     const int32_t* node_key;          // device [n_sets][n_nodes]
     int n_nodes;
     const CTile* tiles;               // this level's tiles
-    const uint8_t* leaf_has_err;      // by count-table column, or NULL
+    const int32_t* leaf_has_err32;    // by count-table column (leaves), one word each, or NULL
     double* tables;
     size_t table_set_stride;
     int C, LD, KP, LDv, ksteps;
+    int block_threads;                // = blockDim.x (read from here: the implicit argument would be one more dependent load)
+    // debug builds (-DCAFE_K2_STAMPS): s_memtime stamps [tile][wave (16)][8], else NULL and unused
+    unsigned long long* stamps;
 };
 
 // ---- K3 --------------------------------------------------------------------------------------------------------

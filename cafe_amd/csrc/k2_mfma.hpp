@@ -44,6 +44,14 @@ typedef double cafe_d4 __attribute__((ext_vector_type(4)));
 #else
 #define K2_STAMP(slot) ((void)0)
 #endif
+#ifdef CAFE_K2_STAMPS
+#define K2C_STAMP(slot)                                                                                        \
+    do {                                                                                                       \
+        if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 16 + wave) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define K2C_STAMP(slot) ((void)0)
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // One edge product: acc[i][j] += node-vector tile(i) x matrix tile(j) over all k-steps, explicitly software-
@@ -1051,35 +1059,78 @@ __global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
 {
     extern __shared__ double Lbuf[];   // [16 * NFT_W][LDv]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    // A tile's set-up is a chain of dependent loads (tile record -> node -> matrix map -> columns) at ~1 us each (the
+    // tables written by the previous level have flushed L2: every stage is an Infinity-Cache round trip), and a level of
+    // a small table lasts as long as ONE tile.  The chain is two round trips before the product:
+    //   1. (needs blockIdx only) the tile's header, this thread's two child indices, AND the whole node -> matrix map
+    //      and error-model flags of a tree of up to 128 nodes, one entry per lane -- the three entries the tile needs
+    //      are then picked out of registers (v_readlane) instead of a second dependent round trip;
+    //      (larger trees: the five lookups as a second stage, all unconditionally, clamped where a field does not apply)
+    //   2. the gathers.
+    // (Left to itself the compiler sinks each lookup into the branch that uses it: eight serialised waits, round 3.)
+    // every argument requested at once (the compiler otherwise fetches the kernel arguments in two dependent batches)
+    asm volatile("" ::"s"(a.PT), "s"(a.PTfold), "s"(a.node_key), "s"(a.n_nodes), "s"(a.tiles), "s"(a.leaf_has_err32), "s"(a.tables),
+                 "s"(a.table_set_stride), "s"(a.C), "s"(a.LD), "s"(a.KP), "s"(a.LDv), "s"(a.ksteps), "s"(a.block_threads));
+    K2C_STAMP(0);
     const cafehip::CTile& t = a.tiles[blockIdx.x];
     const int set = blockIdx.y;
+    const int per_state = a.block_threads / (16 * NFT_W);   // blockDim / states threads per state (all threads busy; contiguous runs of both columns)
+    const int f = tid / per_state, l = tid - f * per_state;   // f < 16 * NFT_W
+    const int i0 = t.idx[0][f], i1 = t.idx[1][f];
+    const int32_t* nk = a.node_key + set * a.n_nodes;
+    const int32_t* lhe = a.leaf_has_err32 ? a.leaf_has_err32 : nk;   // (any readable words when there is no error model)
+    const bool map_in_lanes = a.n_nodes <= 128;
+    int keyv0 = 0, keyv1 = 0, flagv = 0;
+    if (map_in_lanes) {
+        keyv0 = nk[min(lane, a.n_nodes - 1)];
+        keyv1 = nk[min(lane + 64, a.n_nodes - 1)];
+        flagv = lhe[min(lane, (a.n_nodes + 1) / 2 - 1)];
+    }
+    int node = t.node, n_live = t.n_live, state0 = t.state0, out_off = t.out_off;
+    int child0 = t.child[0], child1 = t.child[1], kind0 = t.kind[0], kind1 = t.kind[1];
+    int leafcol0 = t.leafcol[0], leafcol1 = t.leafcol[1], tab_off0 = t.tab_off[0], tab_off1 = t.tab_off[1];
+#define K2C_UNIFORM(x) x = __builtin_amdgcn_readfirstlane(x)
+    K2C_UNIFORM(node); K2C_UNIFORM(n_live); K2C_UNIFORM(state0); K2C_UNIFORM(out_off); K2C_UNIFORM(child0); K2C_UNIFORM(child1);
+    K2C_UNIFORM(kind0); K2C_UNIFORM(kind1); K2C_UNIFORM(leafcol0); K2C_UNIFORM(leafcol1); K2C_UNIFORM(tab_off0); K2C_UNIFORM(tab_off1);
+    asm volatile("" : "+s"(node), "+s"(n_live), "+s"(state0), "+s"(out_off), "+s"(child0), "+s"(child1), "+s"(kind0), "+s"(kind1),
+                 "+s"(leafcol0), "+s"(leafcol1), "+s"(tab_off0), "+s"(tab_off1));
+    K2C_STAMP(1);
     double* const tab = a.tables + (size_t)set * a.table_set_stride;
-    const int node = t.node, n_live = t.n_live;
-    const int Wr = blockDim.x >> 6;
+    const int Wr = a.block_threads >> 6;
     const int RT = (a.C + 15) >> 4;
     const int rt_base = RT / Wr, rt_rem = RT - rt_base * Wr;
     const int ntile = rt_base + (wave < rt_rem ? 1 : 0);
     const int rt0 = wave * rt_base + min(wave, rt_rem);
     const unsigned kstride_bytes = 32u * (unsigned)a.LD;
-    // every index this tile needs from the evaluation's node -> matrix map, requested together (no branches: one
-    // round trip behind the tile record)
-    const int32_t* nk = a.node_key + set * a.n_nodes;
-    const int key_node = nk[node], key_c0 = nk[t.child[0]], key_c1 = nk[t.child[1]];
-    const uint8_t* lhe = a.leaf_has_err ? a.leaf_has_err : reinterpret_cast<const uint8_t*>(a.tiles);   // (any readable byte)
-    const bool err0 = lhe[t.leafcol[0]] != 0, err1 = lhe[t.leafcol[1]] != 0;
+    const bool leaf0 = kind0 == 0, leaf1 = kind1 == 0;
+    int key_node, key_c0, key_c1, flag0, flag1;
+    if (map_in_lanes) {
+        auto pick = [&](int v) { return v < 64 ? __builtin_amdgcn_readlane(keyv0, v) : __builtin_amdgcn_readlane(keyv1, v - 64); };
+        key_node = pick(node);
+        key_c0 = pick(child0);
+        key_c1 = pick(child1);
+        flag0 = __builtin_amdgcn_readlane(flagv, leaf0 ? leafcol0 : 0);
+        flag1 = __builtin_amdgcn_readlane(flagv, leaf1 ? leafcol1 : 0);
+    } else {
+        key_node = nk[node];
+        key_c0 = nk[child0];
+        key_c1 = nk[child1];
+        flag0 = lhe[leaf0 ? leafcol0 : 0];
+        flag1 = lhe[leaf1 ? leafcol1 : 0];
+    }
+    K2C_UNIFORM(key_node); K2C_UNIFORM(key_c0); K2C_UNIFORM(key_c1); K2C_UNIFORM(flag0); K2C_UNIFORM(flag1);
+    asm volatile("" : "+s"(key_node), "+s"(key_c0), "+s"(key_c1), "+s"(flag0), "+s"(flag1));
+#undef K2C_UNIFORM
+    K2C_STAMP(2);
+    const bool err0 = flag0 != 0, err1 = flag1 != 0;
     const size_t msz = (size_t)a.KP * a.LD;
     const k2_gbytes sb = k2_uniform(a.PT + (size_t)key_node * msz);
     {
         // L[state][k] = F_a[k] * F_b[k]
-        const bool leaf0 = t.kind[0] == 0, leaf1 = t.kind[1] == 0;
-        const bool fold0 = a.PTfold != nullptr && a.leaf_has_err != nullptr && err0;
-        const bool fold1 = a.PTfold != nullptr && a.leaf_has_err != nullptr && err1;
-        const double* base0 = leaf0 ? (fold0 ? a.PTfold : a.PT) + (size_t)key_c0 * msz : tab + t.tab_off[0];
-        const double* base1 = leaf1 ? (fold1 ? a.PTfold : a.PT) + (size_t)key_c1 * msz : tab + t.tab_off[1];
-        // blockDim / states threads per state (all threads busy; contiguous runs of both columns)
-        const int per_state = blockDim.x / (16 * NFT_W);
-        const int f = tid / per_state, l = tid - f * per_state;   // f < 16 * NFT_W
-        const int i0 = t.idx[0][f], i1 = t.idx[1][f];
+        const bool fold0 = a.PTfold != nullptr && a.leaf_has_err32 != nullptr && err0;
+        const bool fold1 = a.PTfold != nullptr && a.leaf_has_err32 != nullptr && err1;
+        const double* base0 = leaf0 ? (fold0 ? a.PTfold : a.PT) + (size_t)key_c0 * msz : tab + tab_off0;
+        const double* base1 = leaf1 ? (fold1 ? a.PTfold : a.PT) + (size_t)key_c1 * msz : tab + tab_off1;
         // a count beyond the column range: no such column (cafe/cafe_tree.c:208-209)
         const bool live = f < n_live && !(leaf0 && i0 > a.C - 1) && !(leaf1 && i1 > a.C - 1);
         const double* c0 = base0 + (size_t)(live ? i0 : 0) * a.LD;
@@ -1103,7 +1154,9 @@ __global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
             for (int k = l; k < a.LDv; k += per_state) L[k] = (live && k < a.C) ? c0[k] * c1[k] : 0.0;
         }
     }
+    K2C_STAMP(3);
     __syncthreads();
+    K2C_STAMP(4);
     cafe_d4 fac[NFT_W][NRT_W];
 #pragma unroll
     for (int i = 0; i < NFT_W; ++i)
@@ -1125,7 +1178,8 @@ __global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
             }
         }
     }
-    double* const out = tab + t.out_off + (size_t)t.state0 * a.LD;
+    K2C_STAMP(5);
+    double* const out = tab + out_off + (size_t)state0 * a.LD;
 #pragma unroll
     for (int i = 0; i < NFT_W; ++i) {
 #pragma unroll
@@ -1141,6 +1195,7 @@ __global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
             }
         }
     }
+    K2C_STAMP(6);
 }
 
 }  // namespace

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Phase timeline of the k2c_nodes launches (factor tables of compressed subtrees) of ONE evaluation, from the s_memtime
+stamps of a -DCAFE_K2_STAMPS build:
+
+    python tools/build_variant.py stamps -DCAFE_K2_STAMPS
+    CAFEHIP_LIB=tools/_variants/stamps/libcafehip.so python tools/k2c_stamps.py cfg2 [families]
+
+Per level: tiles, and the mean over tiles (slowest wave) of the cycles from the tile's start to: header loaded, matrix
+indices loaded, columns gathered and written to LDS, barrier passed, product done, rows stored; the span of the level
+(first start to last end) next to the mean tile."""
+import os
+import struct
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+    F = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    path = os.path.join(tempfile.gettempdir(), "k2c_stamps.bin")
+    for p in (path, path + ".k2c"):
+        if os.path.exists(p):
+            os.remove(p)
+    import torch
+    torch.cuda.init()
+    import cafe_amd
+    from cafe_amd import synth, prior as cprior
+    tree, counts, cfg = synth.make_config(name, F=F)
+    rng = cafe_amd.init_family_size(cfg["m"])
+    prior = cprior.prior_rfsize_poisson(rng.root_min, cprior.poisson_lambda_mle(counts))
+    eng = cafe_amd.Engine(0)
+    tree.apply(eng)
+    eng.set_families(counts, rng)
+    nl, nm = synth.node_rates(tree, cfg)
+    for _ in range(40):
+        eng.get_posterior(nl, nm, prior)
+    os.environ["CAFEHIP_STAMPS_FILE"] = path
+    eng.get_posterior(nl, nm, prior)
+    del os.environ["CAFEHIP_STAMPS_FILE"]
+    print(eng.describe())
+    eng.close()
+    raw = open(path + ".k2c", "rb").read()
+    off, level = 0, 0
+    names = ["header", "indices", "gathered", "barrier", "product", "stored"]
+    print("%5s %6s %6s | %s | %9s %9s" % ("level", "tiles", "waves", " ".join("%9s" % n for n in names), "mean tile", "span"))
+    while off < len(raw):
+        grid, waves, slots, _ = struct.unpack("4q", raw[off:off + 32])
+        off += 32
+        n = grid * 16 * slots
+        st = np.frombuffer(raw[off:off + 8 * n], np.uint64).reshape(grid, 16, slots)[:, :waves, :].astype(np.int64)
+        off += 8 * n
+        t0 = st[:, :, 0].min(axis=1)
+        cols = [(st[:, :, k].max(axis=1) - t0).mean() for k in range(1, 7)]
+        span = st[:, :, 6].max() - st[:, :, 0].min()
+        print("%5d %6d %6d | %s | %9.0f %9d" % (level, grid, waves, " ".join("%9.0f" % c for c in cols), cols[-1], span))
+        level += 1
+
+
+if __name__ == "__main__":
+    main()
