@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, call v (final numbers of the round): whole GPU suite, then the round's measurements: bench lines (cfg2..cfg5, one-rank native, 2 ranks on one device),
 # rocprofv3 kernel stats + timeline of the default bench command, PMC traffic of every workload
-mkdir -p gpurun_out/r03v; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r03v; R=$GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r03af; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r03af; R=$GRAFT_REPO_ROOT
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log); tail -2 $O/smoke.log
 (timeout 2700 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log); tail -6 $O/pytest_gpu.log | cut -c1-200
 (timeout 900 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err; echo "rc=$?" >> $O/bench_cfg2.err); head -c 300 $O/bench_cfg2.json; echo
