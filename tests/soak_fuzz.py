@@ -1,12 +1,13 @@
 #!/usr/bin/env python
-"""Randomised soak of the C ABI against the oracle (test infrastructure: this tool, like tests/, may use oracle/).
+"""Randomised soak of the C ABI against the oracle (test infrastructure, kept under tests/ because it uses oracle/; not
+collected by pytest: run it by hand on a GPU box).
 Every iteration draws a tree (3..72 taxa; balanced / caterpillar / random joins), ranges, a table (duplicates, zero rows,
 conserved rows on large trees so that the reference's unscaled likelihood stays a normal double), a rate model (one
 lambda, lambda/mu, per-node), sometimes a banded error model on all or some species, and kernel options, then checks
   * per-family max likelihood / max posterior / argmax and the first-zero index against the oracle (1e-9 relative),
   * compressed walk == uncompressed walk, several parameter sets in one pass == single evaluations (bit for bit),
   * batch mode (per-row root range and column limit): trimmed == untrimmed bit for bit, and the oracle (1e-9).
-Usage: python tools/soak_fuzz.py [seconds] [first_seed]     -> one line per iteration, a summary, exit code 1 on a mismatch"""
+Usage: python tests/soak_fuzz.py [seconds] [first_seed]     -> one line per iteration, a summary, exit code 1 on a mismatch"""
 import os
 import sys
 import time
