@@ -141,6 +141,36 @@ class Engine:
                                                   None, None, None))
         return score.value, fz.value
 
+    @staticmethod
+    def address_of(array):
+        """Raw address of a C-contiguous float64 array for get_posterior_at (the caller keeps the array alive)."""
+        a = np.ascontiguousarray(array, np.float64)
+        if a is not array and not (isinstance(array, np.ndarray) and a.ctypes.data == array.ctypes.data):
+            raise ValueError("address_of needs a C-contiguous float64 array (a converted copy would not outlive the call)")
+        return a.ctypes.data
+
+    def get_posterior_at(self, addr_lambda, addr_mu, addr_prior, sharded=False):
+        """get_posterior / get_posterior_sharded on addresses taken once with address_of: a loop over many parameter
+        sets (bench.py, a likelihood surface) then spends its Python time on one foreign call per evaluation -- the
+        array checks and address look-ups of the plain wrapper cost ~5 us, 4 % of a configs[1] evaluation."""
+        if sharded:
+            f = getattr(self, "_fast_sh", None)
+            if f is None:
+                self._bind_fast_sharded()
+                f = self._fast_sh
+            _lib.check(f(self._h, addr_lambda, addr_mu, addr_prior, self._sscore_ref, self._sfz_ref))
+            return self._sscore.value, self._sfz.value
+        fast = self._fast_eval()
+        self._fz.value = -1
+        _lib.check(fast(self._h, addr_lambda, addr_mu, addr_prior, self._score_ref, self._fz_ref, None, None, None))
+        return self._score.value, self._fz.value
+
+    def _bind_fast_sharded(self):
+        vp = C.c_void_p
+        self._fast_sh = C.CFUNCTYPE(C.c_int, vp, vp, vp, vp, vp, vp)(("cafehip_eval_posterior_sharded", self._L))
+        self._sscore, self._sfz = C.c_double(), C.c_int32(-1)
+        self._sscore_ref, self._sfz_ref = C.addressof(self._sscore), C.addressof(self._sfz)
+
     def _fast_eval(self):
         f = getattr(self, "_fast", None)
         if f is None:
@@ -240,10 +270,8 @@ class Engine:
         pr = np.ascontiguousarray(prior, np.float64)
         f = getattr(self, "_fast_sh", None)
         if f is None:
-            vp = C.c_void_p
-            f = self._fast_sh = C.CFUNCTYPE(C.c_int, vp, vp, vp, vp, vp, vp)(("cafehip_eval_posterior_sharded", self._L))
-            self._sscore, self._sfz = C.c_double(), C.c_int32(-1)
-            self._sscore_ref, self._sfz_ref = C.addressof(self._sscore), C.addressof(self._sfz)
+            self._bind_fast_sharded()
+            f = self._fast_sh
         _lib.check(f(self._h, nl.__array_interface__["data"][0], nm.__array_interface__["data"][0],
                      pr.__array_interface__["data"][0], self._sscore_ref, self._sfz_ref))
         return self._sscore.value, self._sfz.value

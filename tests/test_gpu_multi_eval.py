@@ -100,3 +100,19 @@ def test_lambda_grid_batched_equals_sequential(tmp_path):
     _search(base + ["lambda -r 0.0005:0.0005:0.01 -o " + out0], False)
     _, st, _, _ = _search(base + ["lambda -r 0.0005:0.0005:0.01 -o " + out1], True)
     assert open(out0).read() == open(out1).read() and st[0] > 0
+
+
+def test_evaluation_on_addresses_equals_the_array_wrapper():
+    # bench.py's loop calls the ABI on addresses taken once (Engine.get_posterior_at): same call, same bits
+    eng, t, rng = _example_engine()
+    try:
+        prior = np.ascontiguousarray(O.prior_poisson(1000, rng.root_min, 9.442907))
+        for lam in (0.0017, 0.0031, 0.2):
+            nl, nm = np.full(t.n_nodes, lam), np.full(t.n_nodes, -1.0)
+            want = eng.get_posterior(nl, nm, prior)
+            got = eng.get_posterior_at(eng.address_of(nl), eng.address_of(nm), eng.address_of(prior))
+            assert got == want or (np.isinf(got[0]) and np.isinf(want[0]) and got[1] == want[1])
+        with pytest.raises(ValueError):
+            eng.address_of(np.arange(10.0)[::2])
+    finally:
+        eng.close()
