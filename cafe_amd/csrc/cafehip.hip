@@ -1155,6 +1155,8 @@ int launch_mfma4_g(cafehip_ctx* c, K2MfmaArgs a, int G, int nrt_w, int grid, int
 
 // measured wave-grid choices of this process, by problem shape
 constexpr int kTuneReps = 4;
+constexpr int kTuneRounds = 5;   // round 0 warm-up, round 1 every grid, rounds 2-4 those within 5 % of the best (minimum kept):
+                                 // with one re-timing the choice between two grids 3 % apart flipped in one run out of five
 std::mutex g_tuned_mu;
 std::map<std::array<long, 8>, K2Cand> g_tuned;
 std::array<long, 8> tune_key(const cafehip_ctx* c, int n_items)
@@ -1280,7 +1282,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
                 ms /= (float)std::max(t.reps_launched, 1);
                 // round 0 runs while the clocks are still ramping up (a grid measured 0.236 ms there and 0.170 ms
                 // in steady state): it is a warm-up and eliminates nothing.  Round 1 times every grid (up to kTuneReps
-                // launches each, see below), round 2 once more those within 5 % of round 1's best.
+                // launches each, see below), rounds 2-4 once more each those within 5 % of the best so far.
                 if (t.round <= 1) t.best_ms[t.cur] = ms;
                 else t.best_ms[t.cur] = std::min(t.best_ms[t.cur], ms);
                 t.pending = false;
@@ -1293,8 +1295,8 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
                         t.cur = 0;
                         ++t.round;
                     }
-                } while (t.round == 2 && t.best_ms[t.cur] > 1.05f * best);
-                if (t.round >= 3) {
+                } while (t.round >= 2 && t.round < kTuneRounds && t.best_ms[t.cur] > 1.05f * best);
+                if (t.round >= kTuneRounds) {
                     t.locked = (int)(std::min_element(t.best_ms.begin(), t.best_ms.end()) - t.best_ms.begin());
                     if (c->opt.k2tune_log)
                         for (size_t i = 0; i < t.cands.size(); ++i)
