@@ -6,7 +6,8 @@ conserved rows on large trees so that the reference's unscaled likelihood stays 
 lambda, lambda/mu, per-node), sometimes a banded error model on all or some species, and kernel options, then checks
   * per-family max likelihood / max posterior / argmax and the first-zero index against the oracle (1e-9 relative),
   * compressed walk == uncompressed walk, several parameter sets in one pass == single evaluations (bit for bit),
-  * batch mode (per-row root range and column limit): trimmed == untrimmed bit for bit, and the oracle (1e-9).
+  * batch mode (per-row root range and column limit): trimmed == untrimmed bit for bit, and the oracle (1e-9);
+  * Viterbi node sizes (K4) of a sample of the batch rows against the oracle (reported, a last-bit tie may differ).
 Usage: python tests/soak_fuzz.py [seconds] [first_seed]     -> one line per iteration, a summary, exit code 1 on a mismatch"""
 import os
 import sys
@@ -18,6 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests import _orc as O  # noqa: E402
 from tests.test_gpu_fuzz import random_newick  # noqa: E402
+
+
+STATS = {"viterbi_rows": 0, "viterbi_differ": 0, "viterbi_examples": []}
 
 
 def one(seed):
@@ -109,6 +113,33 @@ def one(seed):
                 assert np.array_equal(trimmed == 0, ~nz), "batch zero pattern: " + tag
                 worst_b = float(np.max(np.abs(trimmed[nz] - ref[nz]) / ref[nz], initial=0))
                 assert worst_b < 1e-9, "batch vs oracle %.3g: %s" % (worst_b, tag)
+                # K4: Viterbi node sizes of up to 64 of the rows under per-row ranges, against the oracle's max-product +
+                # backtrack on fresh tables (a tie decided by the last bit may legitimately differ: counted, not failed)
+                nv = min(B, 64)
+                rmx = rows[:nv].max(axis=1)
+                vlo = np.full(nv, rmin, np.int32)
+                vhi = np.maximum(vlo, np.minimum(np.rint(rmx * 1.25), rmax)).astype(np.int32)
+                vcm = np.minimum(rmx + np.maximum(50, rmx // 5), mx).astype(np.int32)
+                got = eng.viterbi(rows[:nv], vlo, vhi, vcm)
+                import ctypes as C
+                Lo = O.lib()
+                ct = t.ctree()
+                Mm = max(rng.max, rng.root_max)
+                hmat = Lo.orc_matrices_build(C.byref(ct), O.dptr(np.ascontiguousarray(lam)), O.dptr(np.ascontiguousarray(mu)), Mm, 1)
+                sof = Mm + 2
+                vit = np.zeros(t.n_nodes * sof, np.int32)
+                Lb = np.zeros(t.n_nodes * sof)
+                for i in range(nv):
+                    r = O.make_range(0, int(vcm[i]), int(vlo[i]), int(vhi[i]))
+                    fs = np.full(t.n_nodes, -1, np.int32)
+                    fs[0::2] = rows[i]
+                    vit[:] = 0
+                    Lo.orc_tree_viterbi(C.byref(ct), C.byref(r), hmat, O.iptr(fs), O.iptr(vit), O.dptr(Lb), sof)
+                    STATS["viterbi_rows"] += 1
+                    if list(got[i]) != list(fs):
+                        STATS["viterbi_differ"] += 1
+                        STATS["viterbi_examples"].append("%s row %d" % (tag[:60], i))
+                Lo.orc_matrices_free(hmat)
         finally:
             eng.close()
     (s1, z1, ml1, am1, mp1), (s0, z0, ml0, am0, mp0) = res["1"], res["0"]
@@ -145,6 +176,9 @@ def main():
         n += 1
         seed += 1
     print("soak: %d iterations, %d failures, worst relative error vs the oracle %.3g, %.0f s" % (n, bad, worst, time.time() - t0))
+    print("soak: Viterbi node sizes identical to the oracle's on %d of %d rows%s"
+          % (STATS["viterbi_rows"] - STATS["viterbi_differ"], STATS["viterbi_rows"],
+             "" if not STATS["viterbi_differ"] else "; differing: " + "; ".join(STATS["viterbi_examples"][:8])))
     sys.exit(1 if bad else 0)
 
 
