@@ -7,6 +7,7 @@ lambda, lambda/mu, per-node), sometimes a banded error model on all or some spec
   * per-family max likelihood / max posterior / argmax and the first-zero index against the oracle (1e-9 relative),
   * compressed walk == uncompressed walk, several parameter sets in one pass == single evaluations (bit for bit),
   * batch mode (per-row root range and column limit): trimmed == untrimmed bit for bit, and the oracle (1e-9);
+  * the k-cluster model (2-4 clusters): per-family MAP, memberships, score and new weights against the oracle (1e-9);
   * Viterbi node sizes (K4) of a sample of the batch rows against the oracle (reported, a last-bit tie may differ).
 Usage: python tests/soak_fuzz.py [seconds] [first_seed]     -> one line per iteration, a summary, exit code 1 on a mismatch"""
 import os
@@ -21,7 +22,7 @@ from tests import _orc as O  # noqa: E402
 from tests.test_gpu_fuzz import random_newick  # noqa: E402
 
 
-STATS = {"viterbi_rows": 0, "viterbi_differ": 0, "viterbi_examples": []}
+STATS = {"viterbi_rows": 0, "viterbi_differ": 0, "viterbi_examples": [], "cluster_checks": 0}
 
 
 def one(seed):
@@ -92,6 +93,23 @@ def one(seed):
                 for i in range(3):
                     s1, z1 = singles[i]
                     assert (ms[i] == s1 or (np.isinf(ms[i]) and np.isinf(s1))) and mz[i] == z1, "multi-set differs: " + tag
+            if comp == "1" and err is None and rs.rand() < 0.5:
+                # k-cluster model (cafe_get_clustered_posterior): K rate sets with weights, against the oracle
+                K = int(rs.randint(2, 5))
+                kl = np.array([lam * f for f in rs.uniform(0.5, 1.6, size=K)])
+                km = np.array([np.where(mu < 0, -1.0, mu * f) for f in rs.uniform(0.5, 1.6, size=K)])
+                w = rs.rand(K) + 0.1
+                w /= w.sum()
+                so_k, fz_k, MAPo, pzo, newo = O.clustered_posterior(t, counts, rng, kl, km, w, prior, nthreads=os.cpu_count() or 1)
+                s_k, fzg_k, memb, MAPg, pzg = eng.clustered_posterior(kl, km, w, prior, per_family=True)
+                assert fzg_k == fz_k, "cluster first zero %d vs %d: %s" % (fzg_k, fz_k, tag)
+                if fz_k < 0 and np.isfinite(so_k):
+                    nzk = MAPo > 0
+                    assert np.max(np.abs(MAPg[nzk] - MAPo[nzk]) / MAPo[nzk], initial=0) < 1e-9, "cluster MAP: " + tag
+                    assert np.max(np.abs(pzg - pzo), initial=0) < 1e-9, "cluster memberships: " + tag
+                    assert abs(s_k - so_k) <= 1e-9 * abs(so_k), "cluster score %r vs %r: %s" % (s_k, so_k, tag)
+                    assert np.allclose(memb / len(counts), newo, rtol=1e-9, atol=1e-12), "cluster weights: " + tag
+                    STATS["cluster_checks"] += 1
             if comp == "1" and err is None:
                 B = int(rs.randint(1, 700))
                 rows = rs.randint(0, top + 1, size=(B, n)).astype(np.int32) if not big else counts[rs.randint(0, F, size=B)]
@@ -176,6 +194,7 @@ def main():
         n += 1
         seed += 1
     print("soak: %d iterations, %d failures, worst relative error vs the oracle %.3g, %.0f s" % (n, bad, worst, time.time() - t0))
+    print("soak: k-cluster evaluations checked against the oracle: %d" % STATS["cluster_checks"])
     print("soak: Viterbi node sizes identical to the oracle's on %d of %d rows%s"
           % (STATS["viterbi_rows"] - STATS["viterbi_differ"], STATS["viterbi_rows"],
              "" if not STATS["viterbi_differ"] else "; differing: " + "; ".join(STATS["viterbi_examples"][:8])))
