@@ -598,14 +598,16 @@ def main():
     leg.prepare_rates(args.warmup + args.steps + MIN_KERNEL_SAMPLES)
     priming = leg.prime(fixed_count=(1000 if F_local <= 20000 else 60) if multi else None)
     dt, last = leg.run(args.warmup, args.steps, rank=rank)
+    per_rank_dt = [dt]
     if multi:
         if args.comm == "native":
             slots8 = eng.comm_allgather(np.float64(dt).tobytes(), 8)
-            dt = max(float(np.frombuffer(b, np.float64)[0]) for b in slots8)
+            per_rank_dt = [float(np.frombuffer(b, np.float64)[0]) for b in slots8]
         else:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
+            every = [None] * world
+            dist.all_gather_object(every, dt)
+            per_rank_dt = [float(x) for x in every]
+        dt = max(per_rank_dt)
     if rank == 0 and not multi:
         leg.extra_kernel_samples(args.warmup + args.steps)
 
@@ -649,7 +651,24 @@ def main():
         out["setup_ms"] = setup
     if multi:
         info = eng.comm_info() if args.comm == "native" else {}
-        out["rccl_ranks"] = world
+        # what the communicator itself reports, gathered from EVERY rank before anything else touches it: the mode the
+        # ranks agreed on after the functional probe, what RCCL says its world is (0 when RCCL was never initialised --
+        # the direct mode does not load it), and each rank's own clock over the timed region
+        status = eng.comm_status() if args.comm == "native" else None
+        per_rank = [1e3 * x / args.steps for x in per_rank_dt]
+        out["per_rank_ms_per_step"] = per_rank
+        out["rank_skew_ms_per_step"] = {"min": min(per_rank), "max": max(per_rank), "max_minus_min": max(per_rank) - min(per_rank)}
+        if status is not None:
+            blob = json.dumps(status).encode()
+            every = [json.loads(b.rstrip(b"\0").decode()) for b in eng.comm_allgather(blob, 1024)]
+            out["comm_world"] = status["comm_world"]
+            out["rccl_initialised"] = all(e["rccl_initialised"] for e in every)
+            out["rccl_ranks"] = min(e["rccl_ranks"] for e in every)   # ncclCommCount as RCCL returned it; 0 = RCCL not in use
+            out["comm_status_per_rank"] = every
+        else:
+            out["comm_world"] = world
+            out["rccl_initialised"] = comm.get("backend") == "nccl"
+            out["rccl_ranks"] = dist.get_world_size() if comm.get("backend") == "nccl" else 0
         out["comm"] = args.comm
         if native_error:
             out["comm_fallback"] = "the native exchange could not be set up: " + native_error
@@ -710,7 +729,7 @@ def exchange_report(args, leg, eng, info, wl, rank, world):
     this rank's block without a communicator path: cafehip_eval_posterior).  Then the same steps with one
     ncclAllGather behind the score kernel (option comm=rccl), exchange timed with HIP events on the stream."""
     km = np.array(leg.kernel_ms) if leg.kernel_ms else None
-    rep = {"mode": info.get("mode"), "ranks": world}
+    rep = {"mode": info.get("mode"), "ranks": world, "distinct_devices": not args.same_device}
     # plain score kernel on this block
     eng.enable_timing(True)
     plain = []
@@ -727,11 +746,15 @@ def exchange_report(args, leg, eng, info, wl, rank, world):
             rep["exchange_ms_per_step"] = max(0.0, rep["score_kernel_ms"] - k3_plain)
             rep["how"] = "direct: every rank's score kernel stores its packed row into the other ranks' buffers over xGMI and waits " \
                          "for theirs; exchange = that kernel's HIP-event duration minus the plain score kernel's on the same block " \
-                         "(includes the skew between ranks)"
+                         "(includes the skew between ranks)" + \
+                         (" -- NOTE --same-device: the ranks share ONE GPU, the stores never leave it; this number says nothing about xGMI" if args.same_device else "")
         else:
             rep["exchange_ms_per_step"] = float(km[:, 4].mean())
             rep["how"] = "rccl: one ncclAllGather of the packed rows on the context's stream + pick-up kernel, HIP events around them"
-    # the other mode, same steps (RCCL needs one device per rank: skipped with --same-device)
+    # the other mode, same steps, ALWAYS when the ranks sit on distinct devices (RCCL needs one device per rank: with
+    # --same-device the line says so instead)
+    if info.get("mode") == "direct" and args.same_device and world > 1:
+        rep["rccl"] = {"skipped": "--same-device: RCCL refuses two ranks on one device"}
     if info.get("mode") == "direct" and not args.same_device:
         try:
             eng.set_option("comm", "rccl")
@@ -750,7 +773,9 @@ def exchange_report(args, leg, eng, info, wl, rank, world):
                     ex.append(eng.comm_info()["exchange_ms"])
                     eng.enable_timing(False)
             leg.barrier()
+            st = eng.comm_status()
             rep["rccl"] = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / n, "exchange_ms_per_step": float(np.mean(ex)),
+                           "rccl_initialised": st["rccl_initialised"], "rccl_ranks": st["rccl_ranks"],
                            "how": "the same steps with option comm=rccl: ncclAllGather + pick-up kernel behind the score kernel, "
                                   "HIP events on the stream (every 5th of 50 steps)"}
         except Exception as e:   # RCCL unavailable on this box: the direct mode does not need it

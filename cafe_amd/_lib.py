@@ -45,6 +45,10 @@ SIGNATURES = {
     "cafehip_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "cafehip_comm_host_selftest": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "cafehip_comm_info": (C.c_int, [C.c_void_p, _ip, _ip, _ip, _dp, _dp, C.POINTER(C.c_long)]),
+    "cafehip_comm_resync": (C.c_int, [C.c_void_p]),
+    "cafehip_comm_status": (C.c_int, [C.c_void_p, _ip, _dp]),
+    "cafehip_comm_cleanup": (C.c_int, [C.c_void_p]),
+    "cafehip_comm_mode_selftest": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "cafehip_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cafehip_fetch_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "cafehip_last_kernel_ms": (C.c_int, [C.c_void_p, _dp]),
@@ -66,6 +70,7 @@ HOST_SIGNATURES = {
     "cafehost_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cafehost_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cafehost_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "cafehost_comm_cleanup": (C.c_int, [C.c_void_p]),
     "cafehost_init_comm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cafehost_speculation_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "cafehost_exchange_stats": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_long)]),

@@ -287,7 +287,12 @@ struct cafehip_ctx {
     int comm_mode = 0;                          // option "comm": 0 auto (direct when every rank mapped every buffer), 1 rccl, 2 direct
     std::vector<int32_t> blk_lo, blk_hi;        // every rank's block [lo, hi) of the global table
     int x_slots = 0;                            // chunk slots of a rank's packed row
-    unsigned long long x_seq = 0;               // exchange sequence number (direct mode), never reused
+    unsigned long long x_seq = 0;               // exchange sequence number (direct mode); re-aligned to 0 by every collective
+                                                // cafehip_comm_set_blocks / cafehip_comm_resync, advanced only by a launch that went out
+    K3xArgs x_last;                             // the last direct exchange's arguments: what a host-paced re-poll waits on
+    int comm_agreed_mode = 0;                   // what the ranks agreed on in cafehip_comm_init: 2 direct, 1 rccl
+    int comm_injected = 0;                      // CAFEHIP_COMM_INJECT made this rank mute in the probe (tests)
+    long x_repolls = 0;                         // k_x_collect launches (a peer was more than a wait slice late)
     double *d_packed = nullptr, *d_gathered = nullptr;   // RCCL mode: [slots + 1] and [world][slots + 1]
     int packed_slots = 0;
     hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;
@@ -1479,6 +1484,9 @@ int check_ready(cafehip_ctx* c)
     return 0;
 }
 
+// one in-kernel wait of the direct exchange (the host repeats it until comm_timeout_s is over)
+static double x_wait_slice_s() { return std::min(1.0, comm_timeout_s()); }
+
 int ensure_output_sets(cafehip_ctx* c, int n_sets)
 {
     if (n_sets <= c->out_sets) return 0;
@@ -1574,17 +1582,20 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
         x.rank = L.rank;
         x.world = L.world;
         x.slots = c->x_slots;
-        x.xseq = ++c->x_seq;
+        x.xseq = c->x_seq + 1;
         const int parity = (int)(x.xseq & 1);
         for (int r = 0; r < L.world; ++r) {
             x.rows[r] = CommLink::rows_of(L.peer_xbuf[r], parity);
             x.flags[r] = reinterpret_cast<unsigned long long*>(CommLink::flags_of(L.peer_xbuf[r], parity));
         }
-        // a rank that died must not hang the others' GPUs; a rank that is merely late (it wrote a report, loaded a table)
-        // must not be mistaken for one: the same patience as the host-side barriers (comm_timeout_s, 120 s), in ticks
-        // of the 100 MHz wall clock.  Each rank decides alone when to give up -- nothing here needs the ranks to agree.
-        x.timeout_ticks = (long long)(comm_timeout_s() * 1e8);
+        // a rank that died must not hang the others' GPUs, and no GPU sits in one kernel for long: the in-kernel wait is
+        // one slice (<= 1 s, in ticks of the 100 MHz wall clock); a rank that is merely late (it wrote a report, loaded
+        // a table) is waited for by the HOST, slice after slice, for comm_timeout_s (cafehip_eval_posterior_sharded).
+        // Each rank decides alone when to give up -- nothing here needs the ranks to agree.
+        x.timeout_ticks = (long long)(x_wait_slice_s() * 1e8);
         if (launch_kernel(k3x_kernel(), dim3(std::max(c->n_chunks, 1)), dim3(CAFEHIP_CHUNK), 0, c->stream, x)) return -1;
+        c->x_seq = x.xseq;   // the launch went out: only now is the number taken
+        c->x_last = x;
     } else if (c->n_chunks > 0) {
         K3Args k3{c->d_max_post, c->d_max_lik, c->F == c->Fu ? nullptr : c->d_fam2u, c->F, c->Fu, d_chunk_sums, d_first_zero, nullptr, nullptr, 0};
         if (host_out) {
@@ -2605,6 +2616,48 @@ int cafehip_comm_unique_id(void* out_id)
     return 0;
 }
 
+// Functional probe of the peer mappings (k_x_probe): this rank's kernel stores into every peer's probe words and waits
+// <= 1 s for theirs.  Returns how many peers' stores arrived here (world: all).
+static int run_comm_probe(cafehip_ctx* c, CommLink& L)
+{
+    L.probe_ran = false;
+    L.peers_seen = 0;
+    if (!L.p2p_ok) return 0;   // some rank could not even map: nobody launches (the peers' words would never be written)
+    const char* inj = getenv("CAFEHIP_COMM_INJECT");   // tests: "mute:<rank>" -- mapped, but its stores never leave
+    int mute = 0;
+    if (inj && !strncmp(inj, "mute:", 5) && atoi(inj + 5) == L.rank) mute = 1;
+    c->comm_injected = mute;
+    int32_t* d_seen = nullptr;
+    HIP_TRY(hipMalloc(&d_seen, sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(d_seen, 0, sizeof(int32_t), c->stream));
+    XProbeArgs a;
+    memset(&a, 0, sizeof a);
+    for (int r = 0; r < L.world; ++r) a.probe[r] = reinterpret_cast<unsigned long long*>(CommLink::probe_of(L.peer_xbuf[r]));
+    a.rank = L.rank;
+    a.world = L.world;
+    a.mute = mute;
+    a.nonce = L.nonce;
+    a.timeout_ticks = (long long)(std::min(1.0, comm_timeout_s()) * 1e8);
+    a.seen = d_seen;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (launch_kernel(kx_probe_kernel(), dim3(1), dim3(64), 0, c->stream, a)) {
+        hipFree(d_seen);
+        return -1;
+    }
+    int32_t seen = 0;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(&seen, d_seen, sizeof seen, hipMemcpyDeviceToHost);
+    hipFree(d_seen);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        seen = 0;   // a faulting probe is a failed probe: the ranks fall back together
+    }
+    L.probe_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    L.probe_ran = true;
+    L.peers_seen = seen;
+    return seen;
+}
+
 int cafehip_comm_init(cafehip_ctx* c, int rank, int world, const void* unique_id)
 {
     if (!c || !unique_id) return fail("null argument");
@@ -2616,7 +2669,31 @@ int cafehip_comm_init(cafehip_ctx* c, int rank, int world, const void* unique_id
         delete L;
         return fail("communicator: %s", msg.c_str());
     }
+    // "mapped" is not "reachable": every rank probes its peers with real stores and loads, and the ranks agree on ONE
+    // mode -- direct only if every rank saw every peer, else RCCL, else the communicator fails on every rank -- here,
+    // not inside the first evaluation.  (Everybody has zeroed its buffer and passed two barriers since: setup_p2p.)
+    const int seen = run_comm_probe(c, *L);
+    if (seen < 0) {
+        L->fail(cafehip_last_error());
+        delete L;
+        return -1;
+    }
+    const int mode = L->decide_mode(seen == world, [&] { return c->comm_mode != 2 && L->ensure_rccl(); });
+    if (mode <= 0) {
+        const std::string msg = mode < 0 ? L->error
+                                         : "no exchange mode works on every rank: direct refused (this rank mapped " + std::to_string(L->peers_mapped) +
+                                               " and heard " + std::to_string(L->peers_seen) + " of " + std::to_string(world) +
+                                               " ranks; at least one rank did not hear all)" +
+                                               (c->comm_mode == 2 ? ", and option comm=direct rules out RCCL" : ", RCCL: " + (L->error.empty() ? std::string("unavailable on some rank") : L->error));
+        delete L;
+        return fail("communicator: %s", msg.c_str());
+    }
+    if (mode == 1 && world > 1)
+        fprintf(stderr, "cafehip: rank %d: direct exchange refused by the probe (mapped %d, heard %d of %d ranks) -- all ranks use RCCL\n", rank,
+                L->peers_mapped, L->peers_seen, world);
+    c->comm_agreed_mode = mode;
     c->link = L;
+    c->x_seq = 0;
     c->blk_lo.clear();
     c->blk_hi.clear();
     return 0;
@@ -2626,8 +2703,23 @@ int cafehip_comm_init(cafehip_ctx* c, int rank, int world, const void* unique_id
 static int comm_pick_mode(cafehip_ctx* c)
 {
     if (c->comm_mode == 1) return 1;
-    if (c->link->p2p_ok) return 2;
+    if (c->link->direct_ok) return 2;   // the verdict every rank agreed on after the functional probe
     return c->comm_mode == 2 ? -1 : 1;
+}
+
+// collective: everybody is between evaluations; clear my exchange buffer between two barriers and restart the sequence
+static int comm_realign(cafehip_ctx* c)
+{
+    CommLink& L = *c->link;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!L.barrier()) return fail("communicator: %s", L.error.c_str());
+    if (L.xbuf) {
+        HIP_TRY(hipMemset(L.xbuf, 0, 2 * CommLink::parity_stride_bytes()));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    c->x_seq = 0;   // ranks that fell out of step (one failed or skipped an evaluation) are in step again from here
+    if (!L.barrier()) return fail("communicator: %s", L.error.c_str());
+    return 0;
 }
 
 int cafehip_comm_set_blocks(cafehip_ctx* c, const int32_t* block_lo, const int32_t* block_hi)
@@ -2662,12 +2754,8 @@ int cafehip_comm_set_blocks(cafehip_ctx* c, const int32_t* block_lo, const int32
         c->host_seq = 0;
     }
     // direct mode: rows of ranks with fewer chunks must read 0 in the slots they never write.  Everybody is between
-    // evaluations here (collective call): clear my buffer between two barriers
-    if (!L.barrier()) return fail("communicator: %s", L.error.c_str());
-    if (L.xbuf) {
-        HIP_TRY(hipMemset(L.xbuf, 0, L.xbuf_bytes));
-        HIP_TRY(hipDeviceSynchronize());
-    }
+    // evaluations here (collective call): clear my buffer between two barriers, sequence numbers back to 0
+    if (comm_realign(c)) return -1;
     // RCCL mode buffers
     if (slots != c->packed_slots || !c->d_packed) {
         hipFree(c->d_packed);
@@ -2731,7 +2819,17 @@ int cafehip_eval_posterior_sharded(cafehip_ctx* c, const double* node_lambda, co
         if (eval_device(c, node_lambda, node_mu, prior, nullptr, c->d_first_zero, true, 1, true)) return -1;
         bool peer_timeout = false;
         if (wait_host_seq(c, c->host_seq, &peer_timeout)) return -1;
-        if (peer_timeout) return fail("direct exchange: a rank did not deliver its row within %.0f s", comm_timeout_s());
+        const auto t_wait0 = std::chrono::steady_clock::now();
+        while (peer_timeout) {
+            // the score kernel gave up after one slice: wait on in slices of the same length (k_x_collect, one workgroup)
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait0).count() + x_wait_slice_s() > comm_timeout_s())
+                return fail("direct exchange: a rank did not deliver its row within %.0f s", comm_timeout_s());
+            K3xArgs x = c->x_last;
+            x.seq = ++c->host_seq;
+            ++c->x_repolls;
+            if (launch_kernel(kx_collect_kernel(), dim3(1), dim3(CAFEHIP_CHUNK), 0, c->stream, x)) return -1;
+            if (wait_host_seq(c, c->host_seq, &peer_timeout)) return -1;
+        }
         rows = c->h_result->chunk_sums;
     } else {
         if (!L.rccl && !L.ensure_rccl()) return fail("RCCL exchange: %s", L.error.c_str());
@@ -2783,6 +2881,53 @@ int cafehip_eval_posterior_sharded(cafehip_ctx* c, const double* node_lambda, co
     *score = fz >= 0 ? -INFINITY : s;   // cafe/lambda.cpp:753-760
     if (first_zero_global) *first_zero_global = fz;
     return 0;
+}
+
+int cafehip_comm_resync(cafehip_ctx* c)
+{
+    if (!c) return fail("null context");
+    if (!c->link) return fail("cafehip_comm_init has not been called");
+    HIP_TRY(hipSetDevice(c->device));
+    return comm_realign(c);
+}
+
+int cafehip_comm_status(cafehip_ctx* c, int32_t out[CAFEHIP_COMM_STATUS_WORDS], double* probe_ms)
+{
+    if (!c || !out) return fail("null argument");
+    memset(out, 0, sizeof(int32_t) * CAFEHIP_COMM_STATUS_WORDS);
+    if (probe_ms) *probe_ms = 0.0;
+    if (!c->link) return 0;
+    const CommLink& L = *c->link;
+    out[0] = L.world;
+    out[1] = c->comm_agreed_mode;
+    out[2] = c->x_mode_used ? c->x_mode_used : std::max(comm_pick_mode(c), 0);
+    out[3] = L.direct_ok ? 1 : 0;
+    out[4] = L.peers_mapped;
+    out[5] = L.probe_ran ? L.peers_seen : -1;
+    out[6] = L.rccl != nullptr ? 1 : 0;
+    out[7] = L.rccl_count;
+    out[8] = c->comm_injected;
+    out[9] = (int32_t)std::min<long>(c->x_repolls, INT32_MAX);
+    if (probe_ms) *probe_ms = L.probe_ms;
+    return 0;
+}
+
+int cafehip_comm_cleanup(const void* unique_id)
+{
+    if (!unique_id) return fail("null argument");
+    return CommLink::unlink_names(unique_id);
+}
+
+int cafehip_comm_mode_selftest(int rank, int world, const void* unique_id, int my_probe_ok, int my_rccl_ok, int* mode)
+{
+    // the mode agreement alone (CommLink::decide_mode over the shared-memory mailboxes), the local outcomes injected:
+    // what the CPU test suite runs with several processes, one of them "mapped but unreachable"
+    if (!unique_id || !mode) return fail("null argument");
+    CommLink L;
+    if (!L.init(-1, rank, world, unique_id)) return fail("communicator: %s", L.error.c_str());
+    *mode = L.decide_mode(my_probe_ok != 0, [&] { return my_rccl_ok != 0; });
+    if (*mode < 0) return fail("communicator: %s", L.error.c_str());
+    return L.barrier() ? 0 : fail("communicator: %s", L.error.c_str());
 }
 
 int cafehip_comm_allgather(cafehip_ctx* c, const void* mine, size_t nbytes_mine, void* all, size_t nbytes_slot)

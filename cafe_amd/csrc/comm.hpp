@@ -10,6 +10,12 @@
 //   * RCCL (resolved with dlopen when first needed) as the other exchange mode: ONE ncclAllGather of the same packed
 //     rows on the context's stream -- the map + sum of cafe/lambda.cpp:698-722 either way.
 //
+//   * mode agreement: "mapped" is not "reachable".  After the mapping every rank runs a FUNCTIONAL probe (a one-
+//     workgroup kernel stores a nonce into every peer's probe words and waits <= 1 s for theirs, cafehip_comm_init),
+//     and the ranks agree through the mailboxes: direct only if EVERY rank saw EVERY peer, else RCCL if every rank
+//     could join one communicator, else the communicator fails on every rank -- together, at set-up, never inside
+//     the first evaluation (decide_mode).
+//
 // Nothing here touches family data: the exchange moves (chunks + 1) doubles per rank and evaluation.
 #pragma once
 #include <dlfcn.h>
@@ -57,6 +63,7 @@ struct RcclApi {
     int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string error;
 
@@ -76,6 +83,7 @@ struct RcclApi {
         AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
         CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        CommCount = (decltype(CommCount))dlsym(lib, "ncclCommCount");   // optional: what RCCL itself says its world is
         if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !GetErrorString) {
             error = "librccl lacks an expected entry point";
             dlclose(lib);
@@ -116,6 +124,8 @@ struct CommControl {
     std::atomic<uint32_t> bar_gen;
     std::atomic<uint32_t> gather_serial;      // per-call data segments: name suffix
     std::atomic<uint32_t> failed;             // a rank hit an error inside a collective step: everybody gives up
+    std::atomic<uint32_t> fail_owner;         // 1 + the rank whose message stands in fail_msg (first failure wins)
+    char fail_msg[160];
     uint32_t world;
     unsigned char mail[kCommMaxWorld][128];   // one mailbox per rank (IPC handle / RCCL id / flags)
 };
@@ -128,12 +138,21 @@ public:
     // exchange buffer of the objective evaluation: [2 parities][flags: kCommMaxWorld u64][rows: world x (slots + 1) f64]
     void* xbuf = nullptr;                      // mine (uncached device memory)
     void* peer_xbuf[kCommMaxWorld] = {};       // everyone's, mapped here (peer_xbuf[rank] == xbuf)
-    bool p2p_ok = false;
+    bool p2p_ok = false;                       // every rank MAPPED every buffer (API success only)
+    bool direct_ok = false;                    // ... and every rank's probe kernel SAW every peer's store: the agreed verdict
+    bool probe_ran = false;
+    int peers_mapped = 0, peers_seen = 0;      // this rank's own view (itself included)
+    double probe_ms = 0.0;
+    uint64_t nonce = 0;                        // same on every rank of the job (from the id)
     size_t xbuf_bytes = 0;
     // RCCL
     ncclComm_t rccl = nullptr;
     bool rccl_tried = false;
+    int rccl_count = 0;                        // ncclCommCount of the live communicator (0: none)
 
+    // [parity 0][parity 1][probe words: kCommMaxWorld u64]
+    static uint64_t* probe_of(void* base) { return reinterpret_cast<uint64_t*>(static_cast<char*>(base) + 2 * parity_stride_bytes()); }
+    static size_t total_bytes() { return 2 * parity_stride_bytes() + sizeof(uint64_t) * kCommMaxWorld; }
     static size_t parity_stride_bytes() { return sizeof(uint64_t) * kCommMaxWorld + sizeof(double) * (size_t)kCommMaxWorld * (kCommSlotCap + 1); }
     static uint64_t* flags_of(void* base, int parity) { return reinterpret_cast<uint64_t*>(static_cast<char*>(base) + parity * parity_stride_bytes()); }
     static double* rows_of(void* base, int parity) { return reinterpret_cast<double*>(flags_of(base, parity) + kCommMaxWorld); }
@@ -143,8 +162,52 @@ public:
     bool fail(const std::string& m)
     {
         error = m;
-        if (ctl_) ctl_->failed.store(1);
+        if (ctl_) {
+            // the first failure names itself for the others: they report THIS message, not a barrier time-out
+            uint32_t nobody = 0;
+            if (ctl_->fail_owner.compare_exchange_strong(nobody, (uint32_t)rank + 1)) {
+                snprintf(ctl_->fail_msg, sizeof ctl_->fail_msg, "%s", m.c_str());
+                std::atomic_thread_fence(std::memory_order_release);
+            }
+            ctl_->failed.store(1);
+        }
         return false;
+    }
+
+    // what another rank reported when it gave up (empty: nobody did)
+    std::string peer_failure() const
+    {
+        if (!ctl_ || !ctl_->failed.load()) return "";
+        const uint32_t who = ctl_->fail_owner.load();
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!who) return "a rank failed";
+        char buf[sizeof ctl_->fail_msg + 1];
+        memcpy(buf, ctl_->fail_msg, sizeof ctl_->fail_msg);
+        buf[sizeof ctl_->fail_msg] = 0;
+        return "rank " + std::to_string(who - 1) + " failed: " + buf;
+    }
+
+    // names this communicator's id maps to under /dev/shm (control segment + per-call gather segments): a launcher
+    // that had to kill its ranks removes what they could not (cafehip_comm_cleanup)
+    static int unlink_names(const void* id)
+    {
+        uint64_t h = 1469598103934665603ull;
+        for (int i = 0; i < kCommIdBytes; ++i) h = (h ^ static_cast<const unsigned char*>(id)[i]) * 1099511628211ull;
+        char nm[96];
+        snprintf(nm, sizeof nm, "/cafehip_%016llx", (unsigned long long)h);
+        int n = shm_unlink(nm) == 0 ? 1 : 0;
+        int misses = 0;
+        for (uint32_t serial = 1; misses < 64; ++serial) {
+            char g[128];
+            snprintf(g, sizeof g, "%s_g%u", nm, serial);
+            if (shm_unlink(g) == 0) {
+                ++n;
+                misses = 0;
+            } else {
+                ++misses;
+            }
+        }
+        return n;
     }
 
     // Every rank of the job calls this with the same id (any 128 bytes unique to the job).
@@ -160,6 +223,7 @@ public:
         char nm[64];
         snprintf(nm, sizeof nm, "/cafehip_%016llx", (unsigned long long)h);
         name_ = nm;
+        nonce = (h << 8) | 0x80ull;   // low byte left for the rank; never 0
         int fd = shm_open(nm, O_CREAT | O_RDWR, 0600);
         if (fd < 0) return fail(std::string("shm_open ") + nm + ": " + strerror(errno));
         if (ftruncate(fd, sizeof(CommControl)) != 0) {
@@ -193,7 +257,10 @@ public:
             ctl_->bar_gen.fetch_add(1);
             return true;
         }
-        if (!wait_until([&] { return ctl_->bar_gen.load() != gen; })) return fail("barrier timed out (a rank died?)");
+        if (!wait_until([&] { return ctl_->bar_gen.load() != gen; })) {
+            const std::string other = peer_failure();
+            return fail(other.empty() ? "barrier timed out (a rank died?)" : other);
+        }
         return true;
     }
 
@@ -211,6 +278,7 @@ public:
     // bytes in rank order.  One shared segment per call (created by rank 0, unlinked once everyone has mapped it).
     bool host_allgather(const void* mine, size_t nbytes_mine, void* all, size_t nbytes_slot)
     {
+        if (nbytes_mine > nbytes_slot) return fail("all-gather: a block of " + std::to_string(nbytes_mine) + " bytes does not fit its " + std::to_string(nbytes_slot) + "-byte slot");
         if (world == 1) {
             if (nbytes_mine) memcpy(all, mine, nbytes_mine);
             return true;
@@ -231,7 +299,7 @@ public:
             }
         }
         if (!barrier()) return false;
-        if (ctl_->failed.load()) return fail("a rank failed inside host_allgather");
+        if (ctl_->failed.load()) return fail(peer_failure());
         if (rank != 0) {
             fd = shm_open(nm, O_RDWR, 0600);
             if (fd < 0) fail(std::string("gather segment open: ") + strerror(errno));
@@ -279,12 +347,53 @@ public:
             }
         if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
         const int rc = api.CommInitRank(&rccl, world, id, rank);
+        std::string why;
         if (rc != ncclSuccess) {
             rccl = nullptr;
-            error = std::string("ncclCommInitRank: ") + api.GetErrorString(rc);
+            why = std::string("ncclCommInitRank: ") + api.GetErrorString(rc);
+        }
+        rccl_count = 0;
+        if (rccl && api.CommCount && api.CommCount(rccl, &rccl_count) != ncclSuccess) rccl_count = 0;
+        if (rccl && !api.CommCount) rccl_count = world;   // (an RCCL without the query: the init succeeded with `world`)
+        // a communicator is usable only if EVERY rank holds one of the full size
+        bool everyone = false;
+        if (!all_ranks(rccl != nullptr && rccl_count == world, &everyone)) return false;
+        if (!everyone) {
+            if (rccl) api.CommDestroy(rccl);
+            rccl = nullptr;
+            rccl_count = 0;
+            error = why.empty() ? "RCCL communicator could not be formed on every rank" : why;
             return false;
         }
         return true;
+    }
+
+    // collective AND: *result = every rank posted true
+    bool all_ranks(bool mine, bool* result)
+    {
+        *result = mine;
+        if (world == 1) return true;
+        unsigned char post[128] = {(unsigned char)(mine ? 1 : 0)}, all[kCommMaxWorld][128];
+        if (!exchange_mail(post, 1, all)) return false;
+        for (int r = 0; r < world; ++r) *result = *result && all[r][0] != 0;
+        return true;
+    }
+
+    // The exchange mode of the job, agreed by every rank at set-up (collective): 2 direct when every rank's probe saw
+    // every peer; otherwise 1 rccl when `join_rccl` (collective itself: ensure_rccl) succeeds everywhere; otherwise 0 --
+    // the same value on every rank, so either all carry on in one mode or all fail together.  -1: the control segment
+    // itself failed (a rank died).
+    template <class JoinRccl>
+    int decide_mode(bool my_probe_ok, JoinRccl join_rccl)
+    {
+        bool all_direct = false;
+        if (!all_ranks(my_probe_ok, &all_direct)) return -1;
+        direct_ok = all_direct;
+        if (all_direct) return 2;
+        const bool mine = join_rccl();
+        bool all_rccl = false;
+        if (!all_ranks(mine, &all_rccl)) return -1;
+        return all_rccl ? 1 : 0;
     }
 
     void close()
@@ -299,6 +408,7 @@ public:
         xbuf = nullptr;
         if (rccl) rccl_api().CommDestroy(rccl);
         rccl = nullptr;
+        rccl_count = 0;
         if (ctl_) munmap(ctl_, sizeof(CommControl));
         ctl_ = nullptr;
     }
@@ -326,7 +436,7 @@ private:
     // publish its IPC handle, map everyone else's.  p2p_ok only if EVERY rank mapped every buffer.
     bool setup_p2p()
     {
-        xbuf_bytes = 2 * parity_stride_bytes();
+        xbuf_bytes = total_bytes();
         int good = device >= 0 ? 1 : 0;   // (device < 0: host-only link, cafehip_comm_host_selftest)
         if (good && hipSetDevice(device) != hipSuccess) {
             (void)hipGetLastError();
@@ -363,6 +473,7 @@ private:
         if (world == 1) {
             peer_xbuf[0] = xbuf;
             p2p_ok = good != 0;
+            peers_mapped = good;
             return true;
         }
         if (!exchange_mail(post, sizeof post, all)) return false;
@@ -379,6 +490,7 @@ private:
                 }
             }
         }
+        for (int r = 0; r < world; ++r) peers_mapped += peer_xbuf[r] != nullptr;
         unsigned char ok1[128] = {(unsigned char)good};
         if (!exchange_mail(ok1, 1, all)) return false;
         p2p_ok = true;

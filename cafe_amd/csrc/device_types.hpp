@@ -223,6 +223,14 @@ struct K3xArgs {
     long long timeout_ticks;    // wall_clock64() ticks to wait for the peers before giving up (host sees -seq)
 };
 
+struct XProbeArgs {   // k_x_probe
+    unsigned long long* probe[kXMaxWorld];   // rank r's probe words: [kXMaxWorld]
+    int rank, world, mute;
+    unsigned long long nonce;
+    long long timeout_ticks;
+    int32_t* seen;                           // device word: peers whose store arrived
+};
+
 struct ClusterWeights {
     double w[kMaxSets];
 };

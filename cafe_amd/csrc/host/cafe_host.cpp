@@ -423,12 +423,20 @@ struct GlibcRand {
         memset(state, 0, sizeof state);
         initstate_r(1, state, sizeof state, &rd);  // glibc's state before any srand()
     }
+    unsigned long long draws = 0;   // values taken from the stream so far (single and bulk)
     void seed(unsigned v) { srandom_r(v, &rd); }
     double unifrnd()
     {
         int32_t r = 0;
         random_r(&rd, &r);
+        ++draws;
         return r / (RAND_MAX + 1.0);
+    }
+    void skip(unsigned long long n)
+    {
+        int32_t r = 0;
+        for (unsigned long long i = 0; i < n; ++i) random_r(&rd, &r);
+        draws += n;
     }
     static double to_unit(int32_t r) { return r / (RAND_MAX + 1.0); }
     // The next n values of rand() in one tight loop (the Monte-Carlo null draws 15 million of them): the additive
@@ -437,6 +445,7 @@ struct GlibcRand {
     // the same stream.  Any other generator type falls back to random_r.
     void fill_raw(int32_t* out, size_t n)
     {
+        draws += n;
         if (rd.rand_type != 3 || !rd.fptr || !rd.rptr || !rd.end_ptr || !rd.state) {
             for (size_t i = 0; i < n; ++i) random_r(&rd, &out[i]);
             return;
@@ -615,6 +624,11 @@ struct cafehost_session {
     // (cafehip_comm_*, include/cafehip.h); this session only tells it every rank's block of the table
     bool native_comm = false;
     std::vector<int32_t> all_lo, all_hi;                  // every rank's block of the table
+    // an UNSHARDED session inside a sharded job: while set, this rank loads whole tables and evaluates them alone on
+    // its GPU (lhtest deals its files to the ranks: whole searches per GPU instead of 59-family tables cut N ways)
+    bool solo = false;
+    int opt_lhtest_deal = 1;                              // cafehost_set_option "lhtest_deal": 0 = every rank runs every file, sharded
+    bool mute_log = false;
 
     void hipapi_check(hipError_t e, const char* what)
     {
@@ -738,6 +752,7 @@ struct cafehost_session {
 
     void log(const char* fmt, ...)
     {  // cafe_log, cafe/cafe_main.c:26-44
+        if (mute_log) return;
         va_list ap;
         va_start(ap, fmt);
         vfprintf(flog, fmt, ap);
@@ -781,10 +796,11 @@ struct cafehost_session {
         {
             // contiguous chunk-aligned blocks (same rule as cafe_amd/distributed.py shard_bounds)
             const int n_chunks = (Fall + CAFEHIP_CHUNK - 1) / CAFEHIP_CHUNK;
-            const int base = n_chunks / shard_world, extra = n_chunks % shard_world;
+            const int world_ = solo ? 1 : shard_world, rank_ = solo ? 0 : shard_rank;   // solo: the whole table is mine
+            const int base = n_chunks / world_, extra = n_chunks % world_;
             int c0 = 0;
-            for (int r = 0; r < shard_rank; ++r) c0 += base + (r < extra ? 1 : 0);
-            const int nc = base + (shard_rank < extra ? 1 : 0);
+            for (int r = 0; r < rank_; ++r) c0 += base + (r < extra ? 1 : 0);
+            const int nc = base + (rank_ < extra ? 1 : 0);
             shard_lo = std::min(c0 * CAFEHIP_CHUNK, Fall);
             shard_hi = std::min((c0 + nc) * CAFEHIP_CHUNK, Fall);
         }
@@ -800,7 +816,7 @@ struct cafehost_session {
         else
             hip_check(cafehip_set_error_model(ctx, 0, nullptr, nullptr));
         device_families_current = true;
-        if (native_comm) wire_native();
+        if (native_comm && !solo) wire_native();
     }
 
     // ---- prior: cafe_set_prior_rfsize_empirical, cafe/lambda.cpp:808-870 ----
@@ -902,7 +918,7 @@ struct cafehost_session {
 
     bool speculation_pays()
     {
-        if (exchange || native_comm) return false;   // sharded: every evaluation already ends in an exchange
+        if (exchange || (native_comm && !solo)) return false;   // sharded: every evaluation already ends in an exchange
         if (opt_speculate >= 0) return opt_speculate != 0;
         int wg = 0, cu = 0;
         if (cafehip_launch_info(ctx, &wg, &cu) != 0) return false;
@@ -946,7 +962,7 @@ struct cafehost_session {
     {
         double score = 0;
         zero = -1;
-        if (native_comm) {
+        if (native_comm && !solo) {
             // K1 -> tables -> walk -> score kernel with the exchange inside (or one ncclAllGather behind it): the map +
             // sum of cafe/lambda.cpp:698-722 over every rank's block, same bits on every rank
             hip_check(cafehip_eval_posterior_sharded(ctx, nl.data(), nm.data(), pr.data(), &score, &zero));
@@ -2478,18 +2494,140 @@ struct cafehost_session {
         if (pr.size() < 1000) pr.assign(1000, 0.0);
         char lbuf[64];
         snprintf(lbuf, sizeof lbuf, "%lf", lam);
-        for (auto& f : files) {
+        // the two searches of one file (:1497-1527) -> its output line
+        auto one_file = [&](const std::string& f) {
+            std::string line;
+            char b[64];
             dispatch("load -i " + dir + "/" + f + " -p 0.01 -t 10 -l " + log_name);
             dispatch("tree " + tree_str);
             dispatch(std::string("lambda -s -l ") + lbuf);
-            fprintf(fout, "\t%lf\t%lf", posterior_with_prior(pr), params[0]);
+            snprintf(b, sizeof b, "\t%lf\t%lf", posterior_with_prior(pr), params[0]);
+            line += b;
             dispatch(std::string("lambda -s -v ") + lbuf + " -t " + ltree);
-            fprintf(fout, "\t%lf", posterior_with_prior(pr));
-            for (int j = 0; j < num_lambdas; ++j) fprintf(fout, "\t%lf", params[j]);
-            fprintf(fout, "\n");
-            fflush(fout);
+            snprintf(b, sizeof b, "\t%lf", posterior_with_prior(pr));
+            line += b;
+            for (int j = 0; j < num_lambdas; ++j) {
+                snprintf(b, sizeof b, "\t%lf", params[j]);
+                line += b;
+            }
+            return line + "\n";
+        };
+        const bool deal = native_comm && shard_world > 1 && opt_lhtest_deal != 0 && !files.empty();
+        if (!deal) {
+            // one rank -- or every rank running every search on its block of every table (option lhtest_deal=0)
+            for (auto& f : files) {
+                const std::string line = one_file(f);
+                fputs(line.c_str(), fout);
+                fflush(fout);
+            }
+            if (fout != stdout) fclose(fout);
+            return 0;
         }
+        // Sharded job: the files are independent full searches on small tables ("an outer embarrassingly-
+        // parallel axis across GPUs").  Cutting a 59-family table N ways buys nothing and costs an exchange per evaluation;
+        // instead rank r takes files r, r + N, ... and runs the WHOLE pipeline of each alone on its GPU (`solo`), the
+        // formatted lines are gathered and rank 0 writes them in file order -- byte for byte the one-rank output.  The
+        // random starts come from ONE stream in the one-rank run: a file consumes a number of draws that depends only on
+        // the command shapes (prior fit 1 + one per lambda of each search), so a rank steps over the files it does not
+        // run (checked against the count its own files really took).
+        have_lambda_tree = false;
+        set_lambda_tree(ltree);
+        const unsigned long long draws_per_file = (1 + 1) + (1 + (unsigned long long)num_lambdas);
+        std::string mine, problem;
+        solo = true;
+        device_families_current = false;
+        try {
+            for (size_t i = 0; i < files.size(); ++i) {
+                if ((int)(i % shard_world) != shard_rank) {
+                    rng.skip(draws_per_file);
+                    continue;
+                }
+                const unsigned long long before = rng.draws;
+                mine += one_file(files[i]);
+                if (rng.draws - before != draws_per_file)
+                    throw std::runtime_error("lhtest: a file took " + std::to_string(rng.draws - before) + " random draws where " +
+                                             std::to_string(draws_per_file) + " were stepped over on the other ranks");
+            }
+        } catch (const std::exception& e) {
+            problem = e.what();   // the others must hear of it: they are about to wait for this rank's lines
+        }
+        solo = false;
+        device_families_current = false;
+        // gather: [status byte][lines] per rank, sizes first
+        std::string payload = problem.empty() ? std::string(1, 'k') + mine : std::string(1, 'E') + problem;
+        long long my_size = (long long)payload.size();
+        std::vector<long long> sizes(shard_world, 0);
+        if (allgather(allgather_user, &my_size, sizeof my_size, sizes.data(), sizeof(long long)) != 0) throw std::runtime_error("lhtest: allgather failed");
+        long long slot = 1;
+        for (long long v : sizes) slot = std::max(slot, v);
+        std::vector<char> all((size_t)slot * shard_world);
+        if (allgather(allgather_user, payload.data(), my_size, all.data(), slot) != 0) throw std::runtime_error("lhtest: allgather failed");
+        std::vector<std::string> lines_of(shard_world);
+        for (int r = 0; r < shard_world; ++r) {
+            const char* p = all.data() + (size_t)r * slot;
+            if (sizes[r] < 1 || p[0] != 'k') {
+                if (fout != stdout) fclose(fout);
+                throw std::runtime_error("lhtest: rank " + std::to_string(r) + " failed: " + std::string(p + 1, p + std::max<long long>(sizes[r], 1)));
+            }
+            lines_of[r].assign(p + 1, p + sizes[r]);
+        }
+        std::vector<size_t> cursor(shard_world, 0);
+        for (size_t i = 0; i < files.size(); ++i) {
+            const int r = (int)(i % shard_world);
+            const size_t e = lines_of[r].find('\n', cursor[r]);
+            if (e == std::string::npos) throw std::runtime_error("lhtest: rank " + std::to_string(r) + " returned too few lines");
+            fwrite(lines_of[r].data() + cursor[r], 1, e + 1 - cursor[r], fout);
+            cursor[r] = e + 1;
+        }
+        fflush(fout);
         if (fout != stdout) fclose(fout);
+        // Leave every rank where the one-rank run ends: the LAST file's table loaded (sharded again), its second
+        // search's model and prior in force -- the owner of that file hands its results round.
+        {
+            const int owner = (int)((files.size() - 1) % shard_world);
+            const int np = num_lambdas;
+            std::vector<double> blob((size_t)np + 4, 0.0), every(((size_t)np + 4) * shard_world, 0.0);
+            if (shard_rank == owner) {
+                std::copy(params.begin(), params.begin() + std::min<size_t>(params.size(), np), blob.begin());
+                blob[np] = poisson_lambda;
+                blob[np + 1] = last_score;
+                blob[np + 2] = search_iters;
+                blob[np + 3] = n_evals;
+            }
+            if (allgather(allgather_user, blob.data(), (long long)(blob.size() * sizeof(double)), every.data(), (long long)(blob.size() * sizeof(double))) != 0)
+                throw std::runtime_error("lhtest: allgather failed");
+            const double* ob = every.data() + (size_t)owner * blob.size();
+            mute_log = true;
+            try {
+                dispatch("load -i " + dir + "/" + files.back() + " -p 0.01 -t 10 -l " + log_name);
+                dispatch("tree " + tree_str);
+            } catch (...) {
+                mute_log = false;
+                throw;
+            }
+            mute_log = false;
+            has_mu = false;
+            eqbg = false;
+            num_mus = 0;
+            k_clusters = 0;
+            have_lambda_tree = false;
+            set_lambda_tree(ltree);
+            num_params = num_lambdas;
+            params.assign(ob, ob + np);
+            poisson_lambda = ob[np];
+            last_score = ob[np + 1];
+            search_iters = (int)ob[np + 2];
+            n_evals = (int)ob[np + 3];
+            prior.assign(1000, 0.0);
+            for (int i = 0; i < 1000; ++i) prior[i] = poisspdf(range.root_min - 1 + i, poisson_lambda);
+            spec.clear();
+            upload();
+            std::vector<double> nl_, nm_;
+            node_rates(params.data(), nl_, nm_);
+            bool ok = true;
+            for (double v : nl_) ok = ok && v >= 0;
+            if (ok) hip_check(cafehip_reset_birthdeath_cache(ctx, nl_.data(), nm_.data()));
+        }
         return 0;
     }
 
@@ -2701,6 +2839,10 @@ int cafehost_set_option(cafehost_session* s, const char* key, const char* value)
         s->opt_timing = atoi(v.c_str()) != 0;
         return 0;
     }
+    if (k == "lhtest_deal") {
+        s->opt_lhtest_deal = atoi(v.c_str());
+        return 0;
+    }
     if (k == "prior_file") {
         s->opt_prior_file = v;
         s->spec.clear();
@@ -2806,6 +2948,12 @@ int cafehost_comm_unique_id(void* out_id)
     static_assert(CAFEHOST_COMM_ID_BYTES == CAFEHIP_COMM_ID_BYTES, "one id size");
     if (cafehip_comm_unique_id(out_id) != 0) return host_fail(std::string("cafehip: ") + cafehip_last_error());
     return 0;
+}
+
+int cafehost_comm_cleanup(const void* unique_id)
+{
+    if (!unique_id) return host_fail("null communicator id");
+    return cafehip_comm_cleanup(unique_id);
 }
 
 int cafehost_init_comm(cafehost_session* s, int rank, int world, const void* unique_id)

@@ -87,22 +87,32 @@ int main(int argc, char** argv)
         }
         // wait for whichever child ends next; one that dies (e.g. before it joins the communicator) would leave the
         // others waiting in ncclCommInitRank or a collective forever: end them too
+        // Only OUR children are waited for (one waitpid per live pid, polled: another child of this process is left
+        // alone), and a reaped child leaves the list at once -- its pid may be reused by an unrelated process, which must
+        // never be signalled.
         int bad = 0;
-        size_t left = kids.size();
-        while (left > 0) {
-            int st = 0;
-            const pid_t k = waitpid(-1, &st, 0);
-            if (k < 0) break;
-            if (std::find(kids.begin(), kids.end(), k) == kids.end()) continue;
-            --left;
-            if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
-                if (!bad)
-                    for (pid_t other : kids)
-                        if (other != k) kill(other, SIGTERM);   // exact pids of our own children (already-reaped ones are gone)
-                ++bad;
+        std::vector<pid_t> live = kids;
+        while (!live.empty()) {
+            bool progressed = false;
+            for (size_t i = 0; i < live.size();) {
+                int st = 0;
+                const pid_t k = waitpid(live[i], &st, WNOHANG);
+                if (k == 0) {
+                    ++i;
+                    continue;
+                }
+                progressed = true;
+                live.erase(live.begin() + i);   // reaped (or not ours any more: k < 0)
+                if (k < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+                    if (!bad)
+                        for (pid_t other : live) kill(other, SIGTERM);   // exact pids of children that are still running
+                    ++bad;
+                }
             }
+            if (!progressed) usleep(2000);
         }
         unlink(path);
+        if (bad) cafehost_comm_cleanup(id);   // killed ranks cannot remove their shared-memory names: do it for them
         return bad ? 1 : 0;
     }
 

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(K3Args a)
 // copies all rows to the pinned host block the host spins on.  No collective launch, no extra kernel: the sharded
 // evaluation is the same three launches as the single-GPU one.  Buffers alternate by the parity of the sequence
 // number: a rank can be at most one evaluation ahead of another (it needs the other's row to finish).
-// A peer that never shows up ends the wait after timeout_ticks: the host reads -seq and reports the failure.
+// The wait is bounded (timeout_ticks, ~1 s): a GPU never sits in this kernel longer; the host reads -seq and re-polls
+// with k_x_collect in slices until ITS patience (comm_timeout_s) is over.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long x_load_flag(const unsigned long long* p)
 {
@@ -300,10 +301,79 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score_x(K3xArgs a)
     __syncthreads();
     const double* all = a.rows[a.rank];
     const int n = a.world * (a.slots + 1);
-    for (int k = threadIdx.x; k < n; k += CAFEHIP_CHUNK) a.host->chunk_sums[k] = __builtin_nontemporal_load(all + k);
+    if (!s_fail)
+        for (int k = threadIdx.x; k < n; k += CAFEHIP_CHUNK) a.host->chunk_sums[k] = __builtin_nontemporal_load(all + k);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) a.host->done_seq = s_fail ? -a.seq : a.seq;   // -seq: the host re-polls with k_x_collect
+}
+
+// ------------------------------------------------------------------------------------
+// The wait of k3_score_x on its own (one workgroup): a rank whose peers had not delivered within the score kernel's
+// bounded wait (~1 s: a GPU never sits in one kernel longer than that) is re-polled by the HOST with this kernel until
+// the host's own patience (comm_timeout_s) runs out -- a peer that is merely late (it wrote a report, loaded a table)
+// is waited for in slices, a dead one ends the call.  Publishes seq (all rows in host->chunk_sums) or -seq.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CAFEHIP_CHUNK) void k_x_collect(K3xArgs a)
+{
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < a.world) {
+        const unsigned long long* mine = a.flags[a.rank] + threadIdx.x;
+        const long long t0 = wall_clock64();
+        while (x_load_flag(mine) != a.xseq) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > a.timeout_ticks) {
+                s_fail = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    const double* all = a.rows[a.rank];
+    const int n = a.world * (a.slots + 1);
+    if (!s_fail)
+        for (int k = threadIdx.x; k < n; k += CAFEHIP_CHUNK) a.host->chunk_sums[k] = __builtin_nontemporal_load(all + k);
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) a.host->done_seq = s_fail ? -a.seq : a.seq;
+}
+
+// ------------------------------------------------------------------------------------
+// Functional probe of the direct exchange, run once per communicator by cafehip_comm_init: lane t stores (nonce | my
+// rank) into word [my rank] of rank t's probe area THROUGH THE PEER MAPPING and waits (bounded) until (nonce | t)
+// stands in word [t] of my own area -- i.e. until rank t's store has really arrived in my memory and is visible to
+// the same kind of load the score kernel polls with.  seen = peers whose word arrived (myself included).  `mute`
+// (tests: CAFEHIP_COMM_INJECT) skips the stores: the others then see this rank as mapped but unreachable.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_x_probe(XProbeArgs a)
+{
+    __shared__ int s_seen;
+    if (threadIdx.x == 0) s_seen = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < a.world) {
+        const int t = threadIdx.x;
+        if (!a.mute) {
+            __hip_atomic_store(&a.probe[t][a.rank], a.nonce | (unsigned long long)a.rank, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+        }
+        const unsigned long long want = a.nonce | (unsigned long long)t;
+        const unsigned long long* mine = a.probe[a.rank] + t;
+        const long long t0 = wall_clock64();
+        bool ok = false;
+        for (;;) {
+            if (x_load_flag(mine) == want) {
+                ok = true;
+                break;
+            }
+            if (wall_clock64() - t0 > a.timeout_ticks) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (ok) atomicAdd(&s_seen, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *a.seen = s_seen;
 }
 
 // ------------------------------------------------------------------------------------
@@ -542,6 +612,8 @@ const void* k2_v1_kernel(int nf)
 }
 const void* k3_kernel(bool host_out) { return host_out ? reinterpret_cast<const void*>(&k3_score<true>) : reinterpret_cast<const void*>(&k3_score<false>); }
 const void* k3x_kernel() { return reinterpret_cast<const void*>(&k3_score_x); }
+const void* kx_collect_kernel() { return reinterpret_cast<const void*>(&k_x_collect); }
+const void* kx_probe_kernel() { return reinterpret_cast<const void*>(&k_x_probe); }
 const void* k3_cluster_kernel() { return reinterpret_cast<const void*>(&k3_cluster_score); }
 const void* fetch_small_kernel() { return reinterpret_cast<const void*>(&k_fetch_small); }
 const void* k4_kernel(int nf)

@@ -30,6 +30,8 @@ const void* k2c_kernel(int nft_w, int nrt_w, bool batch_gathers);
 const void* k2_v1_kernel(int nf);          // k2_prune_v1<NF>(K2Args), NF in {1, 2, 4, 8, 16}
 const void* k3_kernel(bool host_out);      // k3_score<HOST_OUT>(K3Args)
 const void* k3x_kernel();                  // k3_score_x(K3xArgs): score + direct multi-GPU exchange
+const void* kx_collect_kernel();           // k_x_collect(K3xArgs): the exchange's wait alone (host-paced re-poll)
+const void* kx_probe_kernel();             // k_x_probe(XProbeArgs): functional probe of the peer mappings
 const void* k3_cluster_kernel();           // k3_cluster_score(K3cArgs)
 const void* fetch_small_kernel();          // k_fetch_small(FetchArgs)
 const void* k4_kernel(int nf);             // k4_viterbi<NF>(K4Args), NF in {1, 2, 4, 8}

@@ -284,6 +284,21 @@ class Engine:
         return {"rank": r.value, "world": w.value, "mode": {0: "none", 1: "rccl", 2: "direct"}[m.value],
                 "exchange_ms": ms.value, "host_seconds": hs.value, "calls": n.value}
 
+    def comm_status(self):
+        """What the communicator's set-up found (cafehip_comm_status): the mode the ranks agreed on after the functional
+        probe, what this rank mapped and heard, and what RCCL itself reports -- for logs and bench records."""
+        w = np.zeros(16, np.int32)
+        ms = C.c_double()
+        _lib.check(self._L.cafehip_comm_status(self._h, _i(w), C.byref(ms)))
+        name = {0: "none", 1: "rccl", 2: "direct"}
+        return {"comm_world": int(w[0]), "mode_agreed_at_init": name[int(w[1])], "mode": name[int(w[2])],
+                "direct_ok_on_every_rank": bool(w[3]), "peers_mapped": int(w[4]), "peers_heard_by_probe": int(w[5]),
+                "rccl_initialised": bool(w[6]), "rccl_ranks": int(w[7]), "probe_injected_mute": bool(w[8]),
+                "host_paced_repolls": int(w[9]), "probe_ms": ms.value}
+
+    def comm_resync(self):
+        _lib.check(self._L.cafehip_comm_resync(self._h))
+
     def num_chunks(self):
         return self._L.cafehip_num_chunks(self._h)
 

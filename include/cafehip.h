@@ -233,7 +233,8 @@ int cafehip_viterbi(cafehip_ctx *ctx, int B, const int32_t *counts, const int32_
  * takes the same decisions and nothing is broadcast.  Two exchange modes (option "comm" = auto | direct | rccl):
  *   direct  the score kernel of every rank stores its row straight into an uncached buffer of every other rank
  *           (hipIpc-mapped, over xGMI) and waits for the others' flags: no collective launch, the sharded evaluation
- *           is the same launches as the single-GPU one.  Used when every rank could map every buffer.
+ *           is the same launches as the single-GPU one.  Used when every rank could map every buffer AND the
+ *           functional probe of cafehip_comm_init heard every peer on every rank.
  *   rccl    ONE ncclAllGather of the rows on the context's stream (librccl resolved with dlopen when first needed),
  *           picked up with cafehip_fetch_small.
  * Rendezvous, barriers and the all-gather of host blocks (report phase) run over a POSIX shared-memory segment named
@@ -242,6 +243,11 @@ int cafehip_viterbi(cafehip_ctx *ctx, int B, const int32_t *counts, const int32_
  * order.  No reference counterpart (the reference is one process; its threads split the same loop). */
 #define CAFEHIP_COMM_ID_BYTES 128
 int cafehip_comm_unique_id(void *out_id /* CAFEHIP_COMM_ID_BYTES */);
+/* Joins the ranks: rendezvous, buffers mapped, then a FUNCTIONAL probe -- every rank's one-workgroup kernel stores a
+ * nonce into every peer's buffer through the mapping and waits at most 1 s for theirs -- and one collective decision
+ * through the mailboxes: direct only if every rank heard every peer, else RCCL (communicator formed here, by every
+ * rank), else the call fails ON EVERY RANK with the same reason.  No rank can discover an unreachable peer later,
+ * inside an evaluation.  Option "comm" = rccl / direct set BEFORE this call restricts the choice. */
 int cafehip_comm_init(cafehip_ctx *ctx, int rank, int world, const void *unique_id);
 /* After cafehip_set_families: every rank's block [block_lo[r], block_hi[r]) of the GLOBAL table (world entries each,
  * contiguous, starting on multiples of CAFEHIP_CHUNK); this rank's table must hold its block's rows.  Sizes the
@@ -252,6 +258,25 @@ int cafehip_comm_set_blocks(cafehip_ctx *ctx, const int32_t *block_lo, const int
  * single-GPU call. */
 int cafehip_eval_posterior_sharded(cafehip_ctx *ctx, const double *node_lambda, const double *node_mu,
                                    const double *prior, double *score, int32_t *first_zero_global);
+/* A peer that does not deliver its row is waited for in slices: the score kernel itself waits at most ~1 s, then the
+ * host re-polls with a one-workgroup kernel until CAFEHIP_COMM_TIMEOUT_S (default 120 s) is over and the call fails.
+ * Collective re-alignment after such a failure (or after one rank skipped an evaluation): every rank calls this
+ * between evaluations; exchange buffers are cleared and the sequence numbers restart, as cafehip_comm_set_blocks does. */
+int cafehip_comm_resync(cafehip_ctx *ctx);
+/* What the set-up found, for logs and bench records (none of it is needed to run):
+ *   out[0] world            out[1] mode agreed at init (2 direct, 1 rccl)   out[2] mode in use now (option "comm" may
+ *   override)               out[3] 1 if the probe verdict was "direct" on every rank
+ *   out[4] peer buffers this rank mapped (itself included)   out[5] peers whose probe store arrived here (-1: no probe)
+ *   out[6] 1 if an RCCL communicator is live (ncclCommInitRank succeeded on every rank)
+ *   out[7] ncclCommCount of that communicator (0 without one)   out[8] 1 if CAFEHIP_COMM_INJECT muted this rank (tests)
+ *   out[9] host-paced re-polls so far (a peer was more than one wait slice late)
+ * *probe_ms: wall time of the probe on this rank. */
+#define CAFEHIP_COMM_STATUS_WORDS 16
+int cafehip_comm_status(cafehip_ctx *ctx, int32_t out[CAFEHIP_COMM_STATUS_WORDS], double *probe_ms);
+/* For a launcher whose ranks were killed: removes the shared-memory names this id maps to (control segment and
+ * per-call gather segments); returns how many it removed.  Not collective. */
+int cafehip_comm_cleanup(const void *unique_id);
+
 /* All-gather of host blocks (report phase: Monte-Carlo null by root size, per-family p-values): rank r contributes
  * nbytes_mine <= nbytes_slot bytes, `all` receives world slots of nbytes_slot bytes in rank order. */
 int cafehip_comm_allgather(cafehip_ctx *ctx, const void *mine, size_t nbytes_mine, void *all, size_t nbytes_slot);
@@ -266,6 +291,11 @@ int cafehip_comm_info(cafehip_ctx *ctx, int *rank, int *world, int *mode, double
  * as cafehip_comm_allgather) without a context or a device -- what the CPU test suite runs with several processes. */
 int cafehip_comm_host_selftest(int rank, int world, const void *unique_id, const void *mine, size_t nbytes_mine,
                                void *all, size_t nbytes_slot);
+
+/* Test hook: the mode agreement of cafehip_comm_init alone, over the same mailboxes, with this rank's local outcomes
+ * injected (my_probe_ok: "my probe heard every peer"; my_rccl_ok: "I could join the RCCL communicator").  *mode = 2
+ * direct, 1 rccl, 0 none -- the same on every rank.  No device. */
+int cafehip_comm_mode_selftest(int rank, int world, const void *unique_id, int my_probe_ok, int my_rccl_ok, int *mode);
 
 /* Multi-GPU exchange helper: bring `nbytes` (a multiple of 8, <= 1 MiB) of device memory -- the output of the
  * caller's collective, enqueued on the context's stream -- to the host without a copy command or a stream

@@ -78,6 +78,8 @@ int cafehost_set_allgather(cafehost_session *s, cafehost_allgather_fn fn, void *
 #define CAFEHOST_COMM_ID_BYTES 128
 int cafehost_comm_unique_id(void *out_id /* CAFEHOST_COMM_ID_BYTES */);
 int cafehost_init_comm(cafehost_session *s, int rank, int world, const void *unique_id);
+/* launcher only, after it had to kill its ranks: removes the shared-memory names of that id (cafehip_comm_cleanup) */
+int cafehost_comm_cleanup(const void *unique_id);
 /* host time inside RCCL exchange steps (collective launch + result pick-up; the direct exchange has none: it is
  * part of the score kernel) and the number of sharded evaluations */
 int cafehost_exchange_stats(cafehost_session *s, double *seconds, long *calls);

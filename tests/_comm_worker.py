@@ -1,5 +1,7 @@
 """One rank of the native communicator tests (started by tests/test_comm_host.py and tests/test_gpu_comm.py):
     python tests/_comm_worker.py host  <rank> <world> <idfile> <out.json>
+    python tests/_comm_worker.py mode  <rank> <world> <idfile> <out.json> <probe_ok> <rccl_ok>
+    python tests/_comm_worker.py oversize <rank> <world> <idfile> <out.json> <bad_rank>
     python tests/_comm_worker.py gpu   <rank> <world> <idfile> <out.json> <cfg> <F_total> <mode> <steps>
 `host`: rendezvous + barriers + host all-gather through the shared-memory segment, no GPU.
 `gpu`: every rank on device 0 builds its block of a synthetic table, evaluates `steps` parameter sets through
@@ -33,6 +35,33 @@ def host(rank, world, idfile, out):
     json.dump({"rank": rank, "ok": bool(ok), "err": "" if rc == 0 else L.cafehip_last_error().decode()}, open(out, "w"))
 
 
+def mode(rank, world, idfile, out, probe_ok, rccl_ok):
+    """The mode agreement of cafehip_comm_init alone, this rank's local outcomes injected (no device)."""
+    from cafe_amd import _lib
+    L = _lib.load()
+    uid = open(idfile, "rb").read()
+    m = C.c_int(-7)
+    rc = L.cafehip_comm_mode_selftest(rank, world, C.c_char_p(uid), int(probe_ok), int(rccl_ok), C.byref(m))
+    json.dump({"rank": rank, "rc": rc, "mode": m.value, "err": "" if rc == 0 else L.cafehip_last_error().decode()}, open(out, "w"))
+
+
+def oversize(rank, world, idfile, out, bad_rank):
+    """Host all-gather in which `bad_rank` offers more bytes than a slot holds: it must fail THERE with the size message
+    and on the other ranks at once with that rank's message, not after a barrier time-out."""
+    import time
+    from cafe_amd import _lib
+    L = _lib.load()
+    uid = open(idfile, "rb").read()
+    slot = 64
+    n = 200 if rank == bad_rank else 64
+    mine = np.zeros(n, np.uint8)
+    allb = np.zeros(slot * world, np.uint8)
+    t0 = time.time()
+    rc = L.cafehip_comm_host_selftest(rank, world, C.c_char_p(uid), mine.ctypes.data_as(C.c_void_p), n,
+                                      allb.ctypes.data_as(C.c_void_p), slot)
+    json.dump({"rank": rank, "rc": rc, "seconds": time.time() - t0, "err": "" if rc == 0 else L.cafehip_last_error().decode()}, open(out, "w"))
+
+
 def gpu(rank, world, idfile, out, cfg_name, F_total, mode, steps):
     import cafe_amd
     from cafe_amd import distributed as D
@@ -46,9 +75,19 @@ def gpu(rank, world, idfile, out, cfg_name, F_total, mode, steps):
     prior = cprior.prior_rfsize_poisson(rng.root_min, cprior.poisson_lambda_mle(counts))
     bounds = D.shard_bounds(F_total, world)
     lo, hi = bounds[rank]
-    eng = cafe_amd.Engine(0)
+    import time
+    eng = cafe_amd.Engine(rank if os.environ.get("COMM_WORKER_DEVICE_PER_RANK") else 0)
     eng.set_option("comm", mode)
-    eng.comm_init(rank, world, open(idfile, "rb").read())
+    t0 = time.time()
+    try:
+        eng.comm_init(rank, world, open(idfile, "rb").read())
+    except Exception as e:   # noqa: BLE001 -- the test wants to see what every rank was told
+        json.dump({"rank": rank, "init_error": str(e), "init_seconds": time.time() - t0}, open(out, "w"))
+        eng.close()
+        return
+    init_seconds = time.time() - t0
+    delay = os.environ.get("COMM_WORKER_DELAY", "")   # "rank:step:seconds": that rank is late for that evaluation
+    d_rank, d_step, d_sec = (int(delay.split(":")[0]), int(delay.split(":")[1]), float(delay.split(":")[2])) if delay else (-1, -1, 0.0)
     tree.apply(eng)
     eng.set_families(counts[lo:hi], rng)
     eng.comm_set_blocks(bounds)
@@ -57,6 +96,8 @@ def gpu(rank, world, idfile, out, cfg_name, F_total, mode, steps):
         nl, nm = synth.node_rates(tree, cfg, 1.0 + 0.01 * s, 1.0 + 0.007 * s)
         if s == steps - 1:
             nl = nl * 400.0        # absurd rates: some family gets zero likelihood -> -inf and a first-zero index
+        if rank == d_rank and s == d_step:
+            time.sleep(d_sec)
         sc, fz = eng.get_posterior_sharded(nl, nm, prior)
         scores.append((float(sc).hex(), int(fz)))
     # a second table through the same communicator (re-wiring)
@@ -68,13 +109,18 @@ def gpu(rank, world, idfile, out, cfg_name, F_total, mode, steps):
     sc, fz = eng.get_posterior_sharded(nl, nm, prior)
     scores.append((float(sc).hex(), int(fz)))
     info = eng.comm_info()
+    status = eng.comm_status()
     eng.close()
-    json.dump({"rank": rank, "scores": scores, "info": info}, open(out, "w"))
+    json.dump({"rank": rank, "scores": scores, "info": info, "status": status, "init_seconds": init_seconds}, open(out, "w"))
 
 
 if __name__ == "__main__":
     kind, rank, world, idfile, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     if kind == "host":
         host(rank, world, idfile, out)
+    elif kind == "mode":
+        mode(rank, world, idfile, out, int(sys.argv[6]), int(sys.argv[7]))
+    elif kind == "oversize":
+        oversize(rank, world, idfile, out, int(sys.argv[6]))
     else:
         gpu(rank, world, idfile, out, sys.argv[6], int(sys.argv[7]), sys.argv[8], int(sys.argv[9]))
