@@ -2403,9 +2403,11 @@ struct cafehost_session {
         cdf.reset(mats, S);
         for (int t = 0; t < num_trials; ++t) {
             const std::string base = prefix_path + "_" + std::to_string(t + 1);
-            FILE* ft = fopen((base + ".tab").c_str(), "w");
+            // sharded job: every rank simulates (the random stream must stay in step), ONE rank writes
+            const bool writer = shard_rank == 0;
+            FILE* ft = fopen(writer ? (base + ".tab").c_str() : "/dev/null", "w");
             if (!ft) throw std::runtime_error(base + ".tab failed to open");
-            FILE* fr = fopen((base + ".truth").c_str(), "w");
+            FILE* fr = fopen(writer ? (base + ".truth").c_str() : "/dev/null", "w");
             if (!fr) {
                 fclose(ft);
                 throw std::runtime_error(base + ".truth failed to open");
@@ -2435,6 +2437,12 @@ struct cafehost_session {
             }
             fclose(ft);
             fclose(fr);
+        }
+        if (report_sharded()) {
+            // nobody goes on (e.g. to an lhtest over these files) before the writer has closed them
+            char token = 0;
+            std::vector<char> every(shard_world);
+            if (allgather(allgather_user, &token, 1, every.data(), 1) != 0) throw std::runtime_error("genfamily: barrier failed");
         }
         return 0;
     }
@@ -2513,6 +2521,12 @@ struct cafehost_session {
             return line + "\n";
         };
         const bool deal = native_comm && shard_world > 1 && opt_lhtest_deal != 0 && !files.empty();
+        const auto t_lh0 = std::chrono::steady_clock::now();
+        auto report_time = [&](const char* how) {
+            if (opt_timing && shard_rank == 0)
+                fprintf(stderr, "lhtest: %zu files in %.4f s (%s, %d rank%s)\n", files.size(),
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_lh0).count(), how, shard_world, shard_world > 1 ? "s" : "");
+        };
         if (!deal) {
             // one rank -- or every rank running every search on its block of every table (option lhtest_deal=0)
             for (auto& f : files) {
@@ -2521,6 +2535,7 @@ struct cafehost_session {
                 fflush(fout);
             }
             if (fout != stdout) fclose(fout);
+            report_time(shard_world > 1 ? "every rank runs every file on its block" : "one rank");
             return 0;
         }
         // Sharded job: the files are independent full searches on small tables ("an outer embarrassingly-
@@ -2628,6 +2643,7 @@ struct cafehost_session {
             for (double v : nl_) ok = ok && v >= 0;
             if (ok) hip_check(cafehip_reset_birthdeath_cache(ctx, nl_.data(), nm_.data()));
         }
+        report_time("files dealt to the ranks");
         return 0;
     }
 
@@ -2823,6 +2839,7 @@ int cafehost_create(cafehost_session** out, int device_id, const char* log_path)
     // read once, here: nothing consults the environment during a command
     if (const char* e = getenv("CAFEHOST_SPECULATE")) s->opt_speculate = atoi(e) != 0;
     if (getenv("CAFEHOST_TIMING")) s->opt_timing = true;
+    if (const char* e = getenv("CAFEHOST_LHTEST_DEAL")) s->opt_lhtest_deal = atoi(e);
     *out = s;
     return 0;
 }
@@ -2964,6 +2981,8 @@ int cafehost_init_comm(cafehost_session* s, int rank, int world, const void* uni
     if (s->native_comm) return host_fail("this session already has a communicator");
     if (cafehip_comm_init(s->ctx, rank, world, unique_id) != 0) return host_fail(std::string("cafehip: ") + cafehip_last_error());
     s->native_comm = true;
+    s->allgather = &cafehost_session::native_allgather;   // (host blocks: report phase, genfamily's barrier, lhtest's lines)
+    s->allgather_user = s;
     s->shard_rank = rank;
     s->shard_world = world;
     s->device_families_current = false;   // the next upload shards the table and wires the exchange

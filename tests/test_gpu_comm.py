@@ -165,3 +165,48 @@ def test_command_line_front_end_shards_over_ranks_of_one_device(tmp_path, world)
     exp = open(os.path.join(GOLD, "test2.cafe")).read().splitlines()
     assert got[:1] + got[2:] == exp[:1] + exp[2:]
     assert re.search(r"%d ranks, \d+ exchanges" % world, r.stderr)
+
+
+def test_lhtest_files_are_dealt_to_the_ranks_and_the_output_is_the_one_rank_file(tmp_path):
+    # SURVEY.md 8 f-4 / cafe/cafe_commands.cpp:1473-1536: lhtest is 7 independent two-search pipelines on small simulated
+    # tables.  Sharded, rank r runs files r, r + N, ... WHOLE on its GPU; rank 0 writes the gathered lines in file order --
+    # byte for byte the one-rank file, and the session ends where the one-rank run ends (the `lambda -s` after it draws the
+    # same random start on the same table: same result line).  CAFEHOST_LHTEST_DEAL=0 is the round-3 behaviour (every
+    # rank runs every search on its block of every table): same bytes again.
+    import time
+    GOLD = os.path.join(ROOT, "tests", "golden")
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+    sim = tmp_path / "sim"
+    sim.mkdir()
+    gen = tmp_path / "gen.sh"
+    gen.write_text("\n".join(["seed 10", "load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"), "tree " + newick, "lambda -s",
+                              "genfamily %s/rnd -t 7" % sim]) + "\n")
+    r = subprocess.run([CLI, str(gen)], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len([f for f in os.listdir(sim) if f.endswith(".tab")]) == 7
+
+    def run(world, deal=True):
+        out = tmp_path / ("lh_%d_%d.out" % (world, deal))
+        script = tmp_path / ("lh_%d_%d.sh" % (world, deal))
+        script.write_text("\n".join(["seed 10", "load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"), "tree " + newick,
+                                     "lambda -s", "lhtest -d %s -t (((1,1)1,(2,2)2)2,2) -l 0.0107527 -o %s" % (sim, out),
+                                     "lambda -s"]) + "\n")
+        args = [CLI] + (["--gpus", str(world), "--same-device"] if world > 1 else []) + [str(script)]
+        t0 = time.time()
+        r = subprocess.run(args, capture_output=True, text=True, timeout=900, cwd=str(tmp_path),
+                           env=dict(os.environ, CAFEHIP_COMM_TIMEOUT_S="90", CAFEHOST_LHTEST_DEAL="1" if deal else "0"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        last = re.findall(r"Lambda Search Result: (\d+)\s*\nLambda : (\S+) & Score: (\S+)", r.stdout)[-1]
+        return open(out).read(), last, time.time() - t0
+
+    one, last_one, t_one = run(1)
+    assert one.count("\n") == 7
+    times = {1: t_one}
+    for world in (2, 3):
+        got, last, t = run(world)
+        times[world] = t
+        assert got == one, world
+        assert last == last_one, world      # the session after lhtest is the one-rank session: table, model, random stream
+    got, last, t = run(2, deal=False)
+    assert got == one and last == last_one
+    print("lhtest wall clock, 7 files, ranks sharing ONE device: %s; undealt 2 ranks %.2f s" % (times, t))
