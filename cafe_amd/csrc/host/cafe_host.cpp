@@ -270,36 +270,46 @@ struct FMinSearch {
         idx.assign(N1, 0);
     }
 
-    // __qsort_double_with_index :77-107
-    void qsort_idx(int left, int right)
+    // Order fv ascending, idx riding along (libcommon/fminsearch.cpp:77-107 does this job).  NOT a stable sort, and which
+    // of two equal values ends up first steers the simplex (the worst vertex is the one replaced), so the permutation has
+    // to be the reference's: a hole-moving partition around the FIRST element of a span, the hole alternating between
+    // the low and the high end.  Restated here with an explicit work list; comparisons are written as the reference has
+    // them (`key <= x`, `key >= x`: a NaN score -- the k-cluster objective can return one -- must stop both scans).
+    void order_values_with_index()
     {
-        double pivot = fv[left];
-        int pivot_idx = idx[left];
-        int from = left, to = right;
-        while (from < to) {
-            while (pivot <= fv[to] && from < to) to--;
-            if (from != to) {
-                fv[from] = fv[to];
-                idx[from] = idx[to];
-                from++;
+        struct Span { int lo, hi; };
+        std::vector<Span> work;
+        work.push_back(Span{0, N});
+        while (!work.empty()) {
+            const Span span = work.back();
+            work.pop_back();
+            if (span.lo >= span.hi) continue;
+            const double key = fv[span.lo];
+            const int key_id = idx[span.lo];
+            int a = span.lo, b = span.hi;   // unsettled part; the hole is at a (low phase) or at b (high phase)
+            for (;;) {
+                while (a < b && key <= fv[b]) --b;     // from the top: first value below the key ...
+                if (a == b) break;
+                fv[a] = fv[b];                         // ... drops into the hole at the bottom; the hole is at b now
+                idx[a] = idx[b];
+                ++a;
+                while (a < b && key >= fv[a]) ++a;     // from the bottom: first value above the key ...
+                if (a == b) break;
+                fv[b] = fv[a];                         // ... rises into the hole at the top; the hole is at a again
+                idx[b] = idx[a];
+                --b;
             }
-            while (pivot >= fv[from] && from < to) from++;
-            if (from != to) {
-                fv[to] = fv[from];
-                idx[to] = idx[from];
-                to--;
-            }
+            fv[a] = key;
+            idx[a] = key_id;
+            work.push_back(Span{span.lo, a - 1});      // the two sides are disjoint: their order does not matter
+            work.push_back(Span{a + 1, span.hi});
         }
-        fv[from] = pivot;
-        idx[from] = pivot_idx;
-        if (left < from) qsort_idx(left, from - 1);
-        if (right > from) qsort_idx(from + 1, right);
     }
 
     void sort()
     {  // __fminsearch_sort :109-123
         for (int i = 0; i < N1; ++i) idx[i] = i;
-        qsort_idx(0, N);
+        order_values_with_index();
         for (int i = 0; i < N1; ++i) vsort[i] = v[idx[i]];
         v = vsort;
     }
@@ -376,32 +386,28 @@ struct FMinSearch {
                 }
                 prefetch(pts);
             }
-            const double fv_r = eq(x_r.data());
-            if (fv_r < fv[0]) {
+            // the reference's accept rules (libcommon/fminsearch.cpp:203-237), one decision per outcome of the reflection:
+            // better than the best -> try the expansion; no better than the worst -> contract (inside when strictly
+            // worse, outside on a tie) or shrink; anything in between -> take the reflection
+            const double f_reflect = eq(x_r.data());
+            const double f_best = fv[0], f_worst = fv[N];
+            if (f_reflect < f_best) {
                 for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + chi * (x_r[a] - x_mean[a]);
-                const double fv_e = eq(x_tmp.data());
-                if (fv_e < fv_r)
-                    set_last(x_tmp, fv_e);
-                else
-                    set_last(x_r, fv_r);
-            } else if (fv_r >= fv[N]) {
-                if (fv_r > fv[N]) {
-                    for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + psi * (x_mean[a] - v[N][a]);
-                    const double fv_cc = eq(x_tmp.data());
-                    if (fv_cc < fv[N])
-                        set_last(x_tmp, fv_cc);
-                    else
-                        shrink();
-                } else {
-                    for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + psi * (x_r[a] - x_mean[a]);
-                    const double fv_c = eq(x_tmp.data());
-                    if (fv_c <= fv_r)
-                        set_last(x_tmp, fv_c);
-                    else
-                        shrink();
-                }
+                const double f_expand = eq(x_tmp.data());
+                if (f_expand < f_reflect) set_last(x_tmp, f_expand);
+                else set_last(x_r, f_reflect);
+            } else if (f_reflect > f_worst) {
+                for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + psi * (x_mean[a] - v[N][a]);
+                const double f_inside = eq(x_tmp.data());
+                if (f_inside < f_worst) set_last(x_tmp, f_inside);
+                else shrink();
+            } else if (f_reflect >= f_worst) {   // == the worst (a NaN fails both tests above and this one: next branch)
+                for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + psi * (x_r[a] - x_mean[a]);
+                const double f_outside = eq(x_tmp.data());
+                if (f_outside <= f_reflect) set_last(x_tmp, f_outside);
+                else shrink();
             } else {
-                set_last(x_r, fv_r);
+                set_last(x_r, f_reflect);
             }
         }
         bymax = (i == maxiters);
@@ -487,26 +493,17 @@ std::string join_double(const double* v, int n)
 // pvalue(), libcommon/mathfunc.c:663-689: rank of v in the ascending null sample, ties split in half
 double pvalue_rank(double v, const double* conddist, int size)
 {
-    int from = 0;
-    int to = size - 1;
-    int mi;
-    while (from < to) {
-        mi = from + (to - from) / 2;
-        if (conddist[mi] > v) {
-            to = mi - 1;
-        } else if (conddist[mi] < v) {
-            from = mi + 1;
-        } else {
-            for (from = mi - 1; from >= 0 && conddist[from] == v; from--) {
-            }
-            for (to = mi + 1; to < size && conddist[to] == v; to++) {
-            }
-            from++, to--;
-            break;
-        }
-    }
-    if (from > to) to = from;
-    return (double)(from + (conddist[from] <= v ? 1 : 0) + (to - from) / 2.0) / (double)size;
+    // conddist is sorted ascending (the caller sorts the null's likelihoods).  With `below` values smaller than v and a
+    // run of `equal` values equal to it, the reference's search ends on (first, last) of that run and returns
+    // (first + 1 + (last - first) / 2) / size -- the middle of the run, one-based -- or below / size when nothing equals v.
+    if (size <= 0) return 0.0;
+    const double* const end = conddist + size;
+    const double* const first_not_below = std::lower_bound(conddist, end, v);
+    const double* const first_above = std::upper_bound(first_not_below, end, v);
+    const int below = (int)(first_not_below - conddist);
+    const int equal = (int)(first_above - first_not_below);
+    if (equal == 0) return (double)below / (double)size;
+    return (double)(below + 1 + (equal - 1) / 2.0) / (double)size;
 }
 
 std::string fmt_g(double v)
@@ -651,9 +648,6 @@ struct cafehost_session {
             all_hi[r] = std::min((c0 + nc) * CAFEHIP_CHUNK, Fall);
             c0 += nc;
         }
-        // (a rank whose block is empty still starts at a chunk boundary of the table's end)
-        for (int r = 1; r < shard_world; ++r)
-            if (all_lo[r] != all_hi[r - 1]) all_lo[r] = all_hi[r - 1];
         hip_check(cafehip_comm_set_blocks(ctx, all_lo.data(), all_hi.data()));
         allgather = &cafehost_session::native_allgather;
         allgather_user = this;
@@ -732,6 +726,8 @@ struct cafehost_session {
     std::vector<double> rep_max_p;
     std::vector<int32_t> rep_sizes;      // F x n_nodes
     std::vector<double> rep_branch_p;    // F x (n_nodes-1), -1 = not computed
+    std::vector<double> rep_avg_exp;     // per (node, child) pair: mean size change (compute_size_deltas)
+    std::vector<int> rep_expand, rep_remain, rep_decrease;
 
     // phylogeny_string (libtree/phylogeny.c:490-540): names + ":%g" branch lengths; `label` adds a suffix
     std::string tree_string(const std::function<std::string(int)>& label, bool with_bl) const
@@ -830,10 +826,21 @@ struct cafehost_session {
             std::ifstream in(opt_prior_file);
             if (!in) throw std::runtime_error("ERROR(prior_file): Cannot open " + opt_prior_file + " in read mode.");
             prior.assign(1000, 0.0);
-            double v;
+            double v, total = 0;
             int n = 0;
-            while (n < 1000 && (in >> v)) prior[n++] = v;
+            while (n < 1000 && (in >> v)) {
+                if (!(v >= 0) || !std::isfinite(v))
+                    throw std::runtime_error("ERROR(prior_file): value " + std::to_string(n + 1) + " of " + opt_prior_file + " is not a finite probability >= 0");
+                total += v;
+                prior[n++] = v;
+            }
             if (n == 0) throw std::runtime_error("ERROR(prior_file): no values in " + opt_prior_file);
+            const int need = range.root_max - range.root_min + 1;
+            if (n < need)
+                throw std::runtime_error("ERROR(prior_file): " + opt_prior_file + " holds " + std::to_string(n) + " values but the root sizes " +
+                                         std::to_string(range.root_min) + ".." + std::to_string(range.root_max) + " need " + std::to_string(need));
+            if (std::fabs(total - 1.0) > 1e-6 && shard_rank == 0)
+                fprintf(stderr, "WARNING(prior_file): the %d values of %s sum to %.9g, not 1\n", n, opt_prior_file.c_str(), total);
             log("Root size prior read from %s (%d values)\n", opt_prior_file.c_str(), n);
             (void)unifrnd();   // the fit's random start: the stream stays where the reference's flow would leave it
             return;
@@ -1185,6 +1192,9 @@ struct cafehost_session {
         fam.load(file, max_size);
         have_family = true;
         cond_dist.clear();
+        rep_sizes.clear();   // (`report <name> save` has nothing to write for a new table)
+        rep_max_p.clear();
+        rep_expand.clear();
         err_file.clear();
         err_mfs = -1;
         range = init_family_size(fam.max_size);  // set_range_from_family
@@ -1226,6 +1236,8 @@ struct cafehost_session {
         tree = HostTree::parse(newick);
         have_tree = true;
         have_lambda_tree = false;
+        rep_sizes.clear();
+        rep_expand.clear();
         if (!quiet) log("%s\n", tree.newick.c_str());
         sync_species_index();
         device_families_current = false;
@@ -1846,7 +1858,6 @@ struct cafehost_session {
             std::copy(probs.begin() + (size_t)i * trials, probs.begin() + (size_t)(i + 1) * trials, cond_dist[i].begin());
             std::sort(cond_dist[i].begin(), cond_dist[i].end());  // :41
         }
-        t_phase = std::chrono::steady_clock::now() - (std::chrono::steady_clock::now() - t_phase);
         phase("likelihoods (GPU) + sorting the samples");
     }
 
@@ -1865,9 +1876,24 @@ struct cafehost_session {
         if ((int)params.size() != num_params || num_params == 0)
             throw std::runtime_error("ERROR: Lambda values were not set. Please set lambda values with the 'lambda' or 'lambdamu' command.\n");
         if (tokens.size() < 2) throw std::runtime_error("Usage(report): report <name>");
-        for (size_t i = 2; i < tokens.size(); ++i)
-            throw std::runtime_error("report " + tokens[i] + " is outside this build's scope (text report only)");
+        // get_report_parameters, cafe/reports.cpp:599-628: `save` writes the report of the state already computed (no
+        // Monte-Carlo null, no Viterbi pass: cafe_do_report's just_save path, :650-708) -- the reference's only report
+        // checkpoint; html / json / branchcutting / likelihood / lh2 are formats and tests outside SURVEY.md section 8
+        bool just_save = false;
+        for (size_t i = 2; i < tokens.size(); ++i) {
+            if (iequals(tokens[i], "save")) {
+                just_save = true;
+                break;
+            }
+            throw std::runtime_error("report " + tokens[i] + " is outside this build's scope (text report and `save` only; html, json, "
+                                     "branchcutting, likelihood and lh2 are SURVEY.md section 2 OUT OF SCOPE)");
+        }
         const std::string name = tokens[1];
+        if (just_save) {
+            if (rep_sizes.size() != (size_t)fam.F() * tree.n || rep_max_p.size() != (size_t)fam.F() || rep_expand.size() != (size_t)tree.n - 1)
+                throw std::runtime_error("ERROR(report): nothing to save -- run `report <name>` on this table first");
+            return write_report_text(name);
+        }
         upload();
         // matrices for the fitted parameters, resident on the device + host copies for sampling and
         // for the exact ==/< comparisons of viterbi_sum_probabilities
@@ -1944,8 +1970,12 @@ struct cafehost_session {
         rep_max_p.assign(F, 0.0);
         rep_branch_p.assign((size_t)F * (n - 1), -1.0);
         const int npairs = n - 1;
-        std::vector<double> avg_exp(npairs, 0.0);
-        std::vector<int> n_expand(npairs, 0), n_remain(npairs, 0), n_decrease(npairs, 0);
+        std::vector<double>& avg_exp = rep_avg_exp;      // kept in the session: `report <name> save` writes them again
+        std::vector<int>&n_expand = rep_expand, &n_remain = rep_remain, &n_decrease = rep_decrease;
+        avg_exp.assign(npairs, 0.0);
+        n_expand.assign(npairs, 0);
+        n_remain.assign(npairs, 0);
+        n_decrease.assign(npairs, 0);
         // families are independent here; worker threads take contiguous blocks and keep private integer tallies
         // (exact in any order), so the report does not depend on the thread count
         struct Tally {
@@ -2016,8 +2046,17 @@ struct cafehost_session {
         }
         for (double& v : avg_exp) v /= std::max(F, 1);
         lap("p-values (host)");
+        const int rc = write_report_text(name);
+        lap("writing the file");
+        return rc;
+    }
 
-        // ---- text report: operator<<(ostream&, const Report&), cafe/reports.cpp:453-501 ----
+    // ---- text report: operator<<(ostream&, const Report&), cafe/reports.cpp:453-501 ----
+    int write_report_text(const std::string& name)
+    {
+        const int F = fam.F(), n = tree.n, npairs = n - 1;
+        const std::vector<double>& avg_exp = rep_avg_exp;
+        const std::vector<int>&n_expand = rep_expand, &n_remain = rep_remain, &n_decrease = rep_decrease;
         if (shard_world > 1 && shard_rank != 0) {  // one writer
             log("Report Done\n");
             return 0;
@@ -2107,7 +2146,6 @@ struct cafehost_session {
             for (auto& c : chunks) fwrite(c.data(), 1, c.size(), fp);
         }
         fclose(fp);
-        lap("writing the file");
         log("Report Done\n");
         return 0;
     }
@@ -2889,6 +2927,28 @@ int cafehost_rng_selftest(unsigned seed, int n_before, int n_bulk, int n_after)
     for (int i = 0; i < n; ++i)
         if (want[i] != got[i]) return host_fail("bulk random stream differs from random_r at draw " + std::to_string(i));
     return 0;
+}
+
+double cafehost_pvalue_selftest(double v, const double* sorted_null, int size) { return pvalue_rank(v, sorted_null, size); }
+
+int cafehost_fminsearch_selftest(cafehost_math_fn eq, int n, void* args, const double* x0, double tolx, double tolf, double* xmin,
+                                 double* fmin, int* bymax)
+{
+    if (!eq || !x0 || !xmin || !fmin || n < 1) return host_fail("bad argument");
+    FMinSearch pfm;
+    pfm.init(n);
+    pfm.tolx = tolx;
+    pfm.tolf = tolf;
+    std::vector<double> x(n);
+    pfm.eq = [&](const double* p) {
+        std::copy(p, p + n, x.begin());
+        return eq(x.data(), args);
+    };
+    pfm.minimize(x0);
+    std::copy(pfm.v[0].begin(), pfm.v[0].end(), xmin);
+    *fmin = pfm.fv[0];
+    if (bymax) *bymax = pfm.bymax ? 1 : 0;
+    return pfm.iters;
 }
 
 void cafehost_destroy(cafehost_session* s)

@@ -41,6 +41,14 @@ int cafehost_run_script(cafehost_session *s, const char *path);
  * draws and n_after single draws after srandom(seed) reproduce random_r's own stream (the reference's rand(),
  * libcommon/mathfunc.c unifrnd). */
 int cafehost_rng_selftest(unsigned seed, int n_before, int n_bulk, int n_after);
+/* Test hooks (no session, no GPU) for the two host routines whose exact behaviour steers results: the rank of a
+ * likelihood in a sorted Monte-Carlo null (pvalue, libcommon/mathfunc.c:663-689) and the Nelder-Mead of the searches
+ * (fminsearch_min, libcommon/fminsearch.cpp:264-302: returns the iteration count, fills the best vertex / value).
+ * tests/test_host_vs_ref_build.py compares both bit for bit with the reference's own objects (oracle/_ref). */
+typedef double (*cafehost_math_fn)(double *x, void *args);
+double cafehost_pvalue_selftest(double v, const double *sorted_null, int size);
+int cafehost_fminsearch_selftest(cafehost_math_fn eq, int n, void *args, const double *x0, double tolx, double tolf,
+                                 double *xmin, double *fmin, int *bymax);
 
 /* ---- multi-GPU (one process per GPU) ------------------------------------------------------------
  * Every rank runs the same script (same seed => same Nelder-Mead decisions); a rank scores only its

@@ -153,6 +153,17 @@ def test_report_reproduces_golden_test2_cafe(shell, tmp_path):
     # (v4.2.1 prints "Tree:<t>\nLambda:..." -- cafe/reports.cpp:461-470); every other line is identical
     assert exp[1].endswith(got[1]) and got[1] == "Lambda:\t0.00133949"
     assert got[:1] + got[2:] == exp[:1] + exp[2:]
+    # `report <name> save` (cafe/reports.cpp:599-628, cafe_do_report's just_save path): the report of the state already
+    # computed, written again without a Monte-Carlo null or a Viterbi pass -- the same bytes
+    import cafe_amd
+    out2 = str(tmp_path / "test2_saved")
+    shell.dispatch("report " + out2 + " save")
+    assert open(out2 + ".cafe").read() == open(out + ".cafe").read()
+    with pytest.raises(cafe_amd.CafeHipError, match="OUT OF SCOPE"):
+        shell.dispatch("report " + out2 + " html")
+    shell.dispatch("load -i %s -p 0.05 -max_size 20" % os.path.join(GOLD, "test2_families.txt"))
+    with pytest.raises(cafe_amd.CafeHipError, match="nothing to save"):
+        shell.dispatch("report " + out2 + " save")      # a new table: nothing has been computed for it
 
 
 @pytest.mark.parametrize("k1", ["", "perterm", "exact"])
