@@ -59,10 +59,17 @@ def test_forced_one_rank_run_goes_through_the_native_exchange():
         return json.loads(lines[0])
     plain = run([])
     forced = run(["--force-dist", "--comm", "native"])
-    assert forced["rccl_ranks"] == 1 and forced["comm"] == "native" and forced["n_gpus"] == 1
+    assert forced["comm"] == "native" and forced["n_gpus"] == 1 and forced["comm_world"] == 1
+    # the timed region ran in direct mode: RCCL was never loaded, and the record says so (rccl_ranks used to be
+    # hard-wired to the torch world size); what RCCL itself reports appears with the comparison leg that initialises it
+    assert forced["rccl_ranks"] == 0 and forced["rccl_initialised"] is False
+    st = forced["comm_status_per_rank"][0]
+    assert st["mode_agreed_at_init"] == "direct" and st["peers_heard_by_probe"] == 1
+    assert len(forced["per_rank_ms_per_step"]) == 1 and forced["rank_skew_ms_per_step"]["max_minus_min"] == 0
     x = forced["exchange"]
     assert x["mode"] == "direct" and x["exchange_ms_per_step"] < 0.020        # <= 20 us with one rank
-    assert "rccl" in x and ("error" in x["rccl"] or x["rccl"]["exchange_ms_per_step"] > 0)
+    assert "rccl" in x and ("error" in x["rccl"] or (x["rccl"]["exchange_ms_per_step"] > 0 and x["rccl"]["rccl_ranks"] == 1
+                                                      and x["rccl"]["rccl_initialised"]))
     assert forced["config"]["last_score"] == plain["config"]["last_score"]     # same step, same table: same bits
     assert forced["ms_per_step"] < 1.25 * plain["ms_per_step"]
 
