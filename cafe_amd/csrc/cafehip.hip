@@ -182,11 +182,7 @@ struct cafehip_ctx {
         int batch_lockstep = 1;       // batch mode: workgroups start generation by generation (L2 reuse of the edge matrices)
         int walk_lockstep = 0;        // the same pacing for the family walk of an objective evaluation
         int batch_lockstep_slack = 0; // ... a generation starts when all but this percentage of the previous ones have finished
-        int fuse_score = 1;           // the score reduced in the walk's tail instead of a k3_score launch (round 4)
     } opt;
-    int32_t* d_score_arrive = nullptr;      // [score_arrive_cap]: per-chunk arrival words + the global one, zero between evaluations
-    int score_arrive_cap = 0;
-    bool score_fused = false;               // the last walk launch carried the score (no k3_score launch follows)
     bool walk_compressed = false;           // the MFMA launcher walks the reduced tree (set around one launch)
     bool last_compressed = false;           // ... and the last objective evaluation did
     std::vector<int32_t> h_ucounts;         // unique rows, host copy
@@ -1327,8 +1323,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     const int nf = use4 ? 4 * k.nft_w * k.wf : 16 * k.nft_w * k.wf;
     const int grid = (n_items + nf - 1) / nf;
     const int block = 64 * k.wf * k.wr;
-    // (the score tail reduces a chunk in LDS the walk no longer needs: CAFEHIP_CHUNK doubles + two flag words)
-    const size_t lds = std::max(mfma_lds_bytes(c, nf, n_items), v1.score_host ? (size_t)CAFEHIP_CHUNK * 8 + 16 : (size_t)0);
+    const size_t lds = mfma_lds_bytes(c, nf, n_items);
     K2MfmaArgs a;
     memset(&a, 0, sizeof a);
     a.PT = v1.PT;
@@ -1423,17 +1418,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     }
     if (tuning_launch) c->tune.reps_launched = reps;
     int rc = 0;
-    c->score_fused = false;
     for (int rep = 0; rep < reps && rc == 0; ++rep) {
-        // the score rides in the tail of the LAST launch of this evaluation (a measurement repeats the walk, which is
-        // idempotent; the chunk arrival words are not)
-        if (v1.score_host && rep == reps - 1 && n_sets == 1) {
-            a.score_host = v1.score_host;
-            a.score_arrive = v1.score_arrive;
-            a.score_first_zero = v1.score_first_zero;
-            a.score_seq = v1.score_seq;
-            c->score_fused = true;
-        }
         if (use4) rc = launch_mfma4_g(c, a, k.nft_w, k.nrt_w, grid, block, lds);
         else rc = launch_mfma16(c, a, k.nft_w, k.nrt_w, grid, block, lds);
     }
@@ -1573,19 +1558,9 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
             c->ev_mid_used = true;
         }
         c->walk_compressed = use_c;
-        // synchronous single-set evaluation of a table without duplicate rows: the walk's tail reduces the score and
-        // publishes it (k2_score_tail) -- no k3_score launch
-        c->score_fused = false;
-        if (host_out && !direct_exchange && n_sets == 1 && c->F == c->Fu && c->n_chunks > 0 && c->opt.fuse_score && c->opt.k2 != 1) {
-            a.score_host = c->h_result;
-            a.score_arrive = c->d_score_arrive;
-            a.score_first_zero = d_first_zero;
-            a.score_seq = c->host_seq + 1;
-        }
         const int rc = launch_k2(c, a, c->Fu, n_sets);
         c->walk_compressed = false;
         if (rc) return -1;
-        if (c->score_fused) ++c->host_seq;
         c->last_compressed = use_c && c->k2_used_mfma;
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], c->stream));
@@ -1621,8 +1596,6 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
         if (launch_kernel(k3x_kernel(), dim3(std::max(c->n_chunks, 1)), dim3(CAFEHIP_CHUNK), 0, c->stream, x)) return -1;
         c->x_seq = x.xseq;   // the launch went out: only now is the number taken
         c->x_last = x;
-    } else if (c->score_fused) {
-        // the walk published the score itself
     } else if (c->n_chunks > 0) {
         K3Args k3{c->d_max_post, c->d_max_lik, c->F == c->Fu ? nullptr : c->d_fam2u, c->F, c->Fu, d_chunk_sums, d_first_zero, nullptr, nullptr, 0};
         if (host_out) {
@@ -1665,7 +1638,7 @@ int collect_kernel_ms(cafehip_ctx* c)
 // environment ONCE, when the context is created (tools/ sweeps), never during an evaluation
 const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
                                     "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch",
-                                    "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "fuse_score", "comm"};
+                                    "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "comm"};
 
 int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
 {
@@ -1713,7 +1686,6 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     else if (key == "batch_lockstep") o.batch_lockstep = iv != 0;
     else if (key == "walk_lockstep") o.walk_lockstep = iv != 0;
     else if (key == "batch_lockstep_slack") o.batch_lockstep_slack = std::min(std::max(iv, 0), 100);
-    else if (key == "fuse_score") o.fuse_score = iv != 0;
     else if (key == "comm") {
         if (val == "rccl") c->comm_mode = 1;
         else if (val == "direct") c->comm_mode = 2;
@@ -1842,7 +1814,6 @@ void cafehip_destroy(cafehip_ctx* c)
     if (c->ev_mid) hipEventDestroy(c->ev_mid);
     hipHostFree(c->h_result);
     hipFree(c->d_arrive);
-    hipFree(c->d_score_arrive);
     hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -2053,15 +2024,6 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
         c->LDv = 32 * ((std::max(need - 2, 0) + 31) / 32) + 2;
     }
     c->n_chunks = (F + CAFEHIP_CHUNK - 1) / CAFEHIP_CHUNK;
-    if (c->n_chunks + 1 > c->score_arrive_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        hipFree(c->d_score_arrive);
-        c->d_score_arrive = nullptr;
-        c->score_arrive_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_score_arrive, (size_t)(c->n_chunks + 1) * sizeof(int32_t)));
-        c->score_arrive_cap = c->n_chunks + 1;
-    }
-    HIP_TRY(hipMemsetAsync(c->d_score_arrive, 0, (size_t)c->score_arrive_cap * sizeof(int32_t), c->stream));
 
     HIP_TRY(hipMalloc(&c->d_counts, std::max<size_t>(ucounts.size(), 1) * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(c->d_counts, ucounts.data(), ucounts.size() * sizeof(int32_t), hipMemcpyHostToDevice));

@@ -110,11 +110,6 @@ struct K2Args {
     double* max_lik;
     int32_t* argmax;
     double* max_post;
-    // ask the matrix-core walk to reduce the score in its tail (K2MfmaArgs::score_*); NULL: a k3_score launch follows
-    struct HostResult* score_host;
-    int32_t* score_arrive;
-    int32_t* score_first_zero;
-    int32_t score_seq;
 };
 
 // ---- K2 on the matrix cores (k2_mfma.hpp) ----------------------------------------------------------------------
@@ -165,11 +160,6 @@ struct K2MfmaArgs {
     const double* tables;
     const int32_t* table_off;
     size_t table_set_stride;
-    // score reduced in the walk's tail (k2_score_tail) instead of a k3_score launch, or all NULL / 0
-    struct HostResult* score_host;     // pinned host block: chunk sums + the (first-zero, sequence) word
-    int32_t* score_arrive;             // device [n_chunks + 1], all zero between evaluations
-    int32_t* score_first_zero;         // device word, reset by K1
-    int32_t score_seq;
     // debug builds (-DCAFE_K2_STAMPS): s_memtime stamps [workgroup][wave][K2_STAMP_SLOTS], else NULL and unused
     unsigned long long* stamps;
 };

@@ -353,83 +353,6 @@ __device__ __forceinline__ int k2_wave_min(int v)
                min(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
 }
 
-// Per-family outputs.  When the score is reduced in the walk's own tail (k2_score_tail) the values are read by a
-// workgroup of ANOTHER XCD before the launch ends: they are stored at agent scope (written through the XCD's L2).
-template <class T>
-__device__ __forceinline__ void k2_store_out(T* p, T v, bool through)
-{
-    if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// The score of an objective evaluation inside the walk's tail (cafe/lambda.cpp:698-722: sum over families of
-// log max_posterior, first family with zero likelihood) -- what k3_score does as a separate launch (5 us of kernel + a
-// dispatch gap at configs[1], and nothing to overlap them with).  Chunks are k3_score's: CAFEHIP_CHUNK families in family
-// order, the same fixed-shape tree sum of the same log() values, so the chunk sums carry the same bits.  A chunk is
-// covered by a handful of workgroups; each counts itself in on the chunk's arrival word once its per-family outputs
-// are written through, and the LAST one to arrive reads the chunk's values back (agent scope), reduces them and
-// stores the sum into the pinned host block; the last chunk to finish publishes (first-zero index, sequence number)
-// in the one 8-byte word the host spins on.  No fences: every value that crosses workgroups travels in agent- or
-// system-scope accesses and each producer waits for its own stores (s_waitcnt) before it counts in -- a release fence
-// would write back the XCD's whole L2 (the parks), which is what made the round-1 attempt 30 % slower.
-// Only for tables without duplicate rows (family i == unique row i) and one parameter set; the launcher keeps the
-// k3_score launch otherwise.  `red`: CAFEHIP_CHUNK doubles + 2 ints of LDS, free once the epilogue is over.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void k2_score_tail(const K2MfmaArgs& a, double* red, int fam0, int tid)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's epilogue stores are acknowledged ...
-    __syncthreads();                                    // ... and so are every other wave's of the workgroup
-    int* s_flag = reinterpret_cast<int*>(red + CAFEHIP_CHUNK);
-    const int F = a.Fu;
-    const int n_chunks = (F + CAFEHIP_CHUNK - 1) / CAFEHIP_CHUNK;
-    const int nthr = blockDim.x;
-    const int last_fam = min(fam0 + a.NF, F) - 1;
-    for (int c = fam0 / CAFEHIP_CHUNK; c <= last_fam / CAFEHIP_CHUNK; ++c) {
-        const int c_first = c * CAFEHIP_CHUNK;
-        if (tid == 0) {
-            const int c_last = min(c_first + CAFEHIP_CHUNK, F) - 1;
-            const int expected = c_last / a.NF - c_first / a.NF + 1;   // workgroups holding families of this chunk
-            s_flag[0] = __hip_atomic_fetch_add(&a.score_arrive[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1;
-        }
-        __syncthreads();
-        const bool reduce_it = s_flag[0] != 0;
-        __syncthreads();
-        if (!reduce_it) continue;
-        for (int j = tid; j < CAFEHIP_CHUNK; j += nthr) {
-            const int i = c_first + j;
-            double v = 0.0;
-            if (i < F) {
-                v = log(__hip_atomic_load(a.max_post + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));      // cafe/lambda.cpp:721
-                if (__hip_atomic_load(a.max_lik + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0.0)
-                    atomicMin(a.score_first_zero, i);                                                          // cafe/lambda.cpp:715-720
-            }
-            red[j] = v;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the atomicMin above has landed before this chunk counts as done)
-        __syncthreads();
-#pragma unroll
-        for (int sft = CAFEHIP_CHUNK / 2; sft > 0; sft >>= 1) {   // k3_score's tree, addition for addition
-            for (int j = tid; j < sft; j += nthr) red[j] += red[j + sft];
-            __syncthreads();
-        }
-        if (tid == 0) {
-            __hip_atomic_store(&a.score_host->chunk_sums[c], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&a.score_arrive[c], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next evaluation
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (__hip_atomic_fetch_add(&a.score_arrive[n_chunks], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_chunks - 1) {
-                // every chunk's sum was acknowledged before its workgroup counted it in: publish
-                const int32_t fz0 = atomicMin(a.score_first_zero, INT32_MAX);   // atomic read of the final value
-                __hip_atomic_store(&a.score_arrive[n_chunks], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                static_assert(offsetof(HostResult, first_zero) == 4 && offsetof(HostResult, done_seq) == 0, "one 8-byte word");
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.score_host),
-                                   ((unsigned long long)(unsigned)fz0 << 32) | (unsigned)a.score_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        __syncthreads();   // red is reused by the workgroup's next chunk
-    }
-}
-
 // REGS: the root range fits PR registers per lane (R <= 64 * PR), the lane's prior values and root-vector entries
 // live in registers for the whole epilogue; PR = 2 (R <= 128, e.g. the 125 root sizes of a table whose largest
 // family has 100 members) halves the scan of PR = 4 (R <= 256)
@@ -444,7 +367,6 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
     unsigned long long* fmaxbits = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(scratch) + 8 * 64);   // [NF]
     const double* prior = a.prior;
     const double* logprior = a.logprior;
-    const bool through = a.score_arrive != nullptr;   // outputs read back by another workgroup (k2_score_tail)
     double pr[PR], lpr[PR];
     if (REGS) {
         // one global round trip per wave instead of one per family and pass (L2 latency under load is ~1-2 k cycles)
@@ -518,15 +440,15 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
             qmax = k2_wave_max(qmax);
         }
         if (lane == 0) {
-            k2_store_out(&max_lik[u], best, through);
-            k2_store_out(&argmax[u], (int32_t)bi, through);
+            max_lik[u] = best;
+            argmax[u] = bi;
         }
         if (!(qmax >= 1e-290) || t >= 64) {
             // plain form: every root size through log and exp
             double bestp = -INFINITY;
             for (int i = lane; i < a.R; i += 64) bestp = fmax(bestp, exp(log(L[i]) + logprior[i]));
             bestp = k2_wave_max(bestp);
-            if (lane == 0) k2_store_out(&max_post[u], bestp, through);
+            if (lane == 0) max_post[u] = bestp;
             continue;
         }
         fastmask |= 1ull << t;
@@ -568,7 +490,7 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
     {
         const int f = wave + lane * nwaves;
         if (f < a.NF && fam0 + f < a.Fu && ((fastmask >> lane) & 1ull))
-            k2_store_out(&max_post[fam0 + f], __longlong_as_double((long long)fmaxbits[f]), through);
+            max_post[fam0 + f] = __longlong_as_double((long long)fmaxbits[f]);
     }
 }
 
@@ -848,7 +770,6 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     if (a.gen_done && tid == 0) atomicAdd(a.gen_done, 1);
     k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
-    if (a.score_arrive) k2_score_tail(a, Lbuf, fam0, tid);
 }
 
 
@@ -1125,7 +1046,6 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     if (a.gen_done && tid == 0) atomicAdd(a.gen_done, 1);
     k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
-    if (a.score_arrive) k2_score_tail(a, Lbuf, fam0, tid);
 }
 
 
