@@ -1937,6 +1937,15 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
     HIP_TRY(hipStreamSynchronize(c->stream));
     const auto t_setup0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+    // CAFEHIP_SETUP_LOG=1: where the set-up time goes, lap by lap, on stderr (tools/setup_laps.py)
+    static const bool lap_log = getenv("CAFEHIP_SETUP_LOG") != nullptr;
+    auto t_lap = t_setup0;
+    auto lap = [&](const char* what) {
+        if (!lap_log) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "set_families lap %-28s %8.3f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_lap).count());
+        t_lap = now;
+    };
     // the reference asserts 0 <= familysize < size_of_factor (cafe/cafe_tree.c:207)
     const int sof = std::max(R, range_max + 1);
     for (size_t i = 0; i < (size_t)F * n_leaves; ++i)
@@ -1993,12 +2002,15 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
     }
     const int Fu = (int)uniq_rows.size();
     c->setup_ms[0] = ms_since(t_setup0);
+    lap("validate + dedup");
     const auto t_setup1 = std::chrono::steady_clock::now();
     std::vector<int32_t> ucounts((size_t)std::max(Fu, 1) * n_leaves, 0);
     for (int u = 0; u < Fu; ++u)
         memcpy(&ucounts[(size_t)u * n_leaves], counts + (size_t)uniq_rows[u] * n_leaves, sizeof(int32_t) * n_leaves);
 
+    lap("unique rows gathered");
     free_family_buffers(c);
+    lap("free old buffers");
     c->h_ucounts = ucounts;
     if (Fu == 0) c->h_ucounts.clear();
     c->out_sets = 1;
@@ -2041,9 +2053,11 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
         memset((void*)c->h_result, 0, bytes);
         c->h_result_chunks = c->n_chunks;
     }
+    lap("table + output buffers");
     if (new_M) {
         c->lnc.build(M);
-            hipFree(c->d_lncA);
+        lap("ln C tables (host)");
+        hipFree(c->d_lncA);
         hipFree(c->d_lncB);
         c->d_lncA = c->d_lncB = nullptr;
         HIP_TRY(hipMalloc(&c->d_lncA, c->lnc.A.size() * sizeof(double)));
@@ -2062,10 +2076,13 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
         c->pt_keys_cap = 0;
         c->have_matrices = false;
     }
+    lap("ln C upload");
     if (c->n_nodes > 0 && ensure_matrix_storage(c)) return -1;
+    lap("matrix storage");
     c->setup_ms[2] = ms_since(t_setup1);
     const auto t_setup2 = std::chrono::steady_clock::now();
     if (rebuild_compression(c)) return -1;
+    lap("compression plan + upload");
     c->setup_ms[1] = ms_since(t_setup2);
     c->setup_ms[3] = ms_since(t_setup0);
     return 0;

@@ -45,6 +45,12 @@ int cafehost_rng_selftest(unsigned seed, int n_before, int n_bulk, int n_after);
  * likelihood in a sorted Monte-Carlo null (pvalue, libcommon/mathfunc.c:663-689) and the Nelder-Mead of the searches
  * (fminsearch_min, libcommon/fminsearch.cpp:264-302: returns the iteration count, fills the best vertex / value).
  * tests/test_host_vs_ref_build.py compares both bit for bit with the reference's own objects (oracle/_ref). */
+/* The empirical root-size prior's Poisson fit (find_poisson_lambda, cafe/lambda.cpp:771-838) on the given leaf sizes
+ * (count - 1 of every non-zero count, table order) from the given start; lookahead = 0: one sweep over the sizes per
+ * objective call as the reference does it, 1: the points Nelder-Mead may ask for evaluated several per sweep -- the
+ * fitted value, the score and the iteration count must be the same bits.  *passes = sweeps over the table. */
+int cafehost_poisson_fit_selftest(const int *leaf_sizes, long n, double start, int lookahead, double *lambda, double *score,
+                                  int *iters, long *passes);
 typedef double (*cafehost_math_fn)(double *x, void *args);
 double cafehost_pvalue_selftest(double v, const double *sorted_null, int size);
 int cafehost_fminsearch_selftest(cafehost_math_fn eq, int n, void *args, const double *x0, double tolx, double tolf,

@@ -91,3 +91,39 @@ def test_nelder_mead_nan_scores_take_the_same_branches():
     # the k-cluster objective can return NaN (cafe/cafe_main.c:204, 0/0 membership): every comparison with it is false
     f = lambda x: math.nan if 0.45 < x[0] < 0.55 else (x[0] - 0.2) ** 2 + (x[1] - 0.1) ** 2
     _same(*_run_both(f, [0.5, 0.5]))
+
+
+def test_poisson_prior_fit_with_lookahead_is_the_plain_fit_bit_for_bit():
+    # find_poisson_lambda (cafe/lambda.cpp:771-838): the objective is one long chain of dependent additions over every
+    # non-zero leaf count; the look-ahead evaluates the points the 1-D Nelder-Mead may ask for several per sweep.  Fitted
+    # lambda, score and iteration count must be the SAME BITS as one sweep per call -- on small tables (one core runs the
+    # chains) and large ones (chains dealt to threads) -- with far fewer sweeps; and the plain fit must be the reference's
+    # own fminsearch on the reference's own poisspdf (oracle/_ref).
+    import time
+    R, H = _ref(), _host()
+    rs = np.random.RandomState(5)
+    for n, lam_true, start in ((300, 3.0, 0.37), (5000, 9.4, 0.0123), (60000, 1.3, 0.9), (1200000, 7.7, 0.5557)):
+        xs = np.ascontiguousarray(rs.poisson(lam_true, n).astype(np.int32))
+        if n == 5000:
+            xs[17] = 400        # poisspdf underflows: log(0) = -inf terms, the fit must walk through them identically
+        out = {}
+        for la in (0, 1):
+            lam, sc, it, ps = C.c_double(), C.c_double(), C.c_int(), C.c_long()
+            t0 = time.time()
+            assert H.cafehost_poisson_fit_selftest(xs.ctypes.data_as(C.POINTER(C.c_int32)), n, start, la, C.byref(lam), C.byref(sc),
+                                                   C.byref(it), C.byref(ps)) == 0
+            out[la] = (lam.value, sc.value, it.value, ps.value, time.time() - t0)
+        assert out[0][:3] == out[1][:3], (n, out)
+        assert out[1][3] < 0.75 * out[0][3], (n, out)       # sweeps over the table: at most three quarters, typically a third
+        if n <= 5000:
+            # ... and the plain fit is the reference's: its fminsearch, its poisspdf, the same sum
+            def cb(xp, _):
+                s = 0.0
+                for x in xs:
+                    ll = R.poisspdf(int(x), xp[0])
+                    s += math.log(ll) if ll > 0 else -math.inf
+                return -s
+            xr, fr, br = np.zeros(1), C.c_double(), C.c_int()
+            it_r = R.ref_fminsearch(O.MATH_FUNC(cb), 1, None, O.dptr(np.array([start])), 1e-6, 1e-6, O.dptr(xr), C.byref(fr), C.byref(br))
+            assert (xr[0], fr.value, it_r) == out[0][:3], (n, xr[0], fr.value, it_r, out[0])
+        print("poisson fit n=%d: plain %d sweeps %.3f s, look-ahead %d sweeps %.3f s" % (n, out[0][3], out[0][4], out[1][3], out[1][4]))
