@@ -701,24 +701,32 @@ int rebuild_compression(cafehip_ctx* c)
         const int a = left[v], b = right[v];
         const bool ok_children = (!internal(a) || comp[a]) && (!internal(b) || comp[b]);
         if (v != c->root && ok_children) {
-            std::unordered_map<uint64_t, int32_t> ids;
-            ids.reserve(std::min<size_t>(limit + 1, 1u << 20));
+            // open-addressing table keyed by the pair of child states (linear probing; at most `limit` entries in a power
+            // of two of at least twice that)
+            size_t cap = 64;
+            while (cap < 2 * (std::min<size_t>(limit, (size_t)Fu) + 1)) cap <<= 1;
+            std::vector<uint64_t> keys(cap);
+            std::vector<int32_t> vals(cap, -1);
+            int32_t n_ids = 0;
             std::vector<int32_t> mine(Fu);
             bool fits = true;
+            const int32_t *sa = sid[a].data(), *sb = sid[b].data();
             for (int u = 0; u < Fu; ++u) {
-                const uint64_t key = ((uint64_t)(uint32_t)sid[a][u] << 32) | (uint32_t)sid[b][u];
-                auto it = ids.find(key);
-                if (it == ids.end()) {
-                    if (ids.size() >= limit) { fits = false; break; }
-                    it = ids.emplace(key, (int32_t)ids.size()).first;
-                    idx0[v].push_back(sid[a][u]);
-                    idx1[v].push_back(sid[b][u]);
+                const uint64_t key = ((uint64_t)(uint32_t)sa[u] << 32) | (uint32_t)sb[u];
+                size_t at = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+                while (vals[at] >= 0 && keys[at] != key) at = (at + 1) & (cap - 1);
+                if (vals[at] < 0) {
+                    if ((size_t)n_ids >= limit) { fits = false; break; }
+                    keys[at] = key;
+                    vals[at] = n_ids++;
+                    idx0[v].push_back(sa[u]);
+                    idx1[v].push_back(sb[u]);
                 }
-                mine[u] = it->second;
+                mine[u] = vals[at];
             }
-            if (fits && !ids.empty()) {
+            if (fits && n_ids > 0) {
                 comp[v] = 1;
-                D[v] = (int)ids.size();
+                D[v] = n_ids;
                 level[v] = 1 + std::max(comp[a] ? level[a] : 0, comp[b] ? level[b] : 0);
                 sid[v].swap(mine);
             } else {
