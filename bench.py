@@ -47,7 +47,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured float4 copy)
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak: 256 CUs x 4 SIMDs x 32 flop/cycle x 2.4 GHz
 MIN_KERNEL_SAMPLES = 16
-TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")]
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")]
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
@@ -708,6 +708,9 @@ def main():
                                  "(VERDICT r02: 61-72 % of the matrix work of the bench tables disappears by subtree-state compression)"}
         for name, w2 in (("test1", test1_workload()), ("turnover", turnover_workload(args.config))):
             out["tables"][name] = table_leg(w2, local_rank)
+        # ... and the headline table itself with subtree-state compression switched off: the floor a table that shares
+        # nothing would run at (every family walks the whole tree; same values bit for bit)
+        out["tables"]["uncompressed"] = table_leg(wl, local_rank, options={"compress": 0})
 
     if rank == 0 and world == 1 and not multi and not args.no_search and args.table == "synthetic":
         out["lambda_search"] = lambda_search_wallclock(wl)
@@ -810,9 +813,14 @@ def strong_leg(args, eng, comm, rank, world, local_rank):
             "last_score": last, "setup_ms": leg.setup["set_families_ms"]}
 
 
-def table_leg(w, local_rank):
-    """Headline measurement on another table: evaluations/s, kernel times, roofline with work saved."""
-    leg = Leg(w, local_rank, None)
+def table_leg(w, local_rank, options=None):
+    """Headline measurement on another table (or under other library options): evaluations/s, kernel times, roofline with
+    work saved."""
+    import cafe_amd
+    eng = cafe_amd.Engine(local_rank)
+    for k, v in (options or {}).items():
+        eng.set_option(k, v)
+    leg = Leg(w, local_rank, None, shared_engine=eng)
     steps, warm = 100, 5
     leg.prepare_rates(warm + steps + MIN_KERNEL_SAMPLES)
     priming = leg.prime()
@@ -823,6 +831,8 @@ def table_leg(w, local_rank):
            "ms_per_step": 1e3 * dt / steps, "steps": steps, "kernel_ms": kms,
            "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "factor_tables", "pruning_total", "whole_evaluation")},
            "setup_ms": leg.setup["set_families_ms"], "engine": desc, "last_score": last}
+    if options:
+        res["options"] = options
     leg.eng.close()
     return res
 

@@ -43,6 +43,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert r["traffic_minimal_bytes"] > 0 and "whole_evaluation" in r
     assert d["strong_scaling"]["families_total"] == 8 * 62464 and d["strong_scaling"]["value"] > 1e6
     assert d["tables"]["test1"]["families"] == 14787 and d["tables"]["turnover"]["value"] > 1e6
+    # round 4: the headline table with compression off is the floor of "the headline is a property of the table"
+    u = d["tables"]["uncompressed"]
+    assert u["options"] == {"compress": 0} and "used=1" not in u["engine"]
+    assert u["value"] < d["value"]
     assert c["matrix_build_s"] > 0 and c["family_loop_value"] > c["value"]
 
 
