@@ -32,6 +32,11 @@
 #include "../../../include/cafehip.h"
 #include "../../../include/cafehost.h"
 #include "../host_math.hpp"
+#include "glibc_rand.hpp"
+#include "host_util.hpp"
+#include "nelder_mead.hpp"
+#include "poisson_prior.hpp"
+#include "tree_table.hpp"
 
 namespace {
 
@@ -43,730 +48,7 @@ int host_fail(const std::string& msg)
     return -1;
 }
 
-// ------------------------------------------------------------------------------------
-// tree: Newick -> nlist arrays (tree_build_node_list, cafe/cafe_commands.cpp:2028-2051)
-// ------------------------------------------------------------------------------------
-struct HostTree {
-    int n = 0, root = -1;
-    std::vector<int32_t> parent, left, right;
-    std::vector<double> bl;
-    std::vector<std::string> name;
-    std::string newick;  // as typed
-
-    int n_leaves() const { return (n + 1) / 2; }
-
-    static HostTree parse(const std::string& text)
-    {
-        std::string s = text;
-        while (!s.empty() && (s.back() == ';' || isspace((unsigned char)s.back()))) s.pop_back();
-        struct Raw {
-            std::string name;
-            double bl = -1.0;  // the root keeps -1 (libtree/phylogeny.c)
-            std::vector<int> kids;
-        };
-        std::vector<Raw> raw;
-        size_t pos = 0;
-        std::function<int()> rec = [&]() -> int {
-            const int me = (int)raw.size();
-            raw.emplace_back();
-            if (pos < s.size() && s[pos] == '(') {
-                ++pos;
-                while (true) {
-                    const int ch = rec();
-                    raw[me].kids.push_back(ch);
-                    if (pos < s.size() && s[pos] == ',') {
-                        ++pos;
-                        continue;
-                    }
-                    if (pos >= s.size() || s[pos] != ')') throw std::runtime_error("Failed to load tree from provided string");
-                    ++pos;
-                    break;
-                }
-            }
-            size_t j = pos;
-            while (j < s.size() && s[j] != ',' && s[j] != '(' && s[j] != ')' && s[j] != ':') ++j;
-            raw[me].name = s.substr(pos, j - pos);
-            pos = j;
-            if (pos < s.size() && s[pos] == ':') {
-                size_t k = pos + 1;
-                while (k < s.size() && s[k] != ',' && s[k] != '(' && s[k] != ')') ++k;
-                raw[me].bl = atof(s.substr(pos + 1, k - pos - 1).c_str());
-                pos = k;
-            }
-            return me;
-        };
-        const int r = rec();
-        if (pos != s.size()) throw std::runtime_error("Failed to load tree from provided string");
-        // in-order numbering: even = leaf, odd = internal
-        std::vector<int> order;
-        std::vector<std::pair<int, int>> st;
-        st.push_back({r, 0});
-        while (!st.empty()) {
-            auto [v, stage] = st.back();
-            st.pop_back();
-            if (raw[v].kids.empty()) {
-                order.push_back(v);
-            } else if (stage == 0) {
-                if (raw[v].kids.size() != 2) throw std::runtime_error("Tree must be binary");
-                st.push_back({v, 1});
-                st.push_back({raw[v].kids[0], 0});
-            } else {
-                order.push_back(v);
-                st.push_back({raw[v].kids[1], 0});
-            }
-        }
-        HostTree t;
-        t.n = (int)order.size();
-        std::vector<int> id(raw.size());
-        for (int i = 0; i < t.n; ++i) id[order[i]] = i;
-        t.parent.assign(t.n, -1);
-        t.left.assign(t.n, -1);
-        t.right.assign(t.n, -1);
-        t.bl.assign(t.n, -1.0);
-        t.name.assign(t.n, "");
-        for (size_t v = 0; v < raw.size(); ++v) {
-            const int i = id[v];
-            t.name[i] = raw[v].name;
-            t.bl[i] = raw[v].bl;
-            if (!raw[v].kids.empty()) {
-                t.left[i] = id[raw[v].kids[0]];
-                t.right[i] = id[raw[v].kids[1]];
-                t.parent[t.left[i]] = i;
-                t.parent[t.right[i]] = i;
-            }
-        }
-        t.root = id[r];
-        t.newick = s;
-        return t;
-    }
-
-    double max_branch_length() const
-    {
-        double m = 0;
-        for (double b : bl) m = std::max(m, b);
-        return m;
-    }
-};
-
-bool iequals(const std::string& a, const std::string& b)
-{
-    if (a.size() != b.size()) return false;
-    for (size_t i = 0; i < a.size(); ++i)
-        if (tolower((unsigned char)a[i]) != tolower((unsigned char)b[i])) return false;
-    return true;
-}
-
-// ------------------------------------------------------------------------------------
-// family table (load_gene_families, cafe/gene_family.cpp:186-225)
-// ------------------------------------------------------------------------------------
-struct HostFamilies {
-    std::string path;
-    std::vector<std::string> species, ids, desc;
-    std::vector<int32_t> counts;  // F x species.size(), file column order
-    int max_size = 0;
-    int F() const { return (int)ids.size(); }
-
-    static std::vector<std::string> split(const std::string& s, char sep)
-    {
-        std::vector<std::string> out;
-        std::string cur;
-        for (char ch : s) {
-            if (ch == sep) {
-                out.push_back(cur);
-                cur.clear();
-            } else {
-                cur.push_back(ch);
-            }
-        }
-        out.push_back(cur);
-        return out;
-    }
-
-    void load(const std::string& file, int max_size_filter)
-    {
-        std::ifstream in(file);
-        if (!in) throw std::runtime_error("ERROR(load): Cannot open " + file + " in read mode.");
-        path = file;
-        std::string line;
-        if (!std::getline(in, line)) throw std::runtime_error("Failed to identify species for gene families");
-        while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
-        const char sep = (line.find('\t') != std::string::npos) ? '\t' : ',';
-        auto head = split(line, sep);
-        if (head.size() < 3) throw std::runtime_error("Failed to identify species for gene families");
-        species.assign(head.begin() + 2, head.end());
-        ids.clear();
-        desc.clear();
-        counts.clear();
-        max_size = 0;
-        while (std::getline(in, line)) {
-            while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
-            if (line.empty()) continue;
-            auto v = split(line, sep);
-            if (v.size() != species.size() + 2)
-                throw std::runtime_error("Inconsistency in column count: expected " + std::to_string(species.size() + 2) +
-                                         ", but found " + std::to_string(v.size()));
-            std::vector<int32_t> row(species.size());
-            int mx = 0;
-            for (size_t i = 0; i < species.size(); ++i) {
-                char* end = nullptr;
-                const long val = strtol(v[i + 2].c_str(), &end, 10);
-                if (end == v[i + 2].c_str()) throw std::runtime_error("Error reading family '" + v[1] + "'");
-                row[i] = (int32_t)val;
-                mx = std::max(mx, (int)val);
-            }
-            // cafe/gene_family.cpp:217: keep the row when max_size < 0 or max(row) <= max_size
-            if (max_size_filter < 0 || mx <= max_size_filter) {
-                desc.push_back(v[0]);
-                ids.push_back(v[1]);
-                counts.insert(counts.end(), row.begin(), row.end());
-                max_size = std::max(max_size, mx);
-            }
-        }
-    }
-};
-
-struct HostRange {
-    int min = 0, max = 0, root_min = 1, root_max = 1;
-};
-
-// init_family_size, cafe/cafe_family.c:357-364
-HostRange init_family_size(int max)
-{
-    HostRange r;
-    r.root_min = 1;
-    r.root_max = (int)std::max(30.0, std::rint(max * 1.25));
-    r.max = max + std::max(50, max / 5);
-    r.min = 0;
-    return r;
-}
-
-// ------------------------------------------------------------------------------------
-// Nelder-Mead exactly as libcommon/fminsearch.cpp (defaults :7-21, loop :264-302)
-// ------------------------------------------------------------------------------------
-struct FMinSearch {
-    int N = 0, N1 = 0, maxiters = 10000, iters = 0, bymax = 0;
-    double rho = 1, chi = 2, psi = 0.5, sigma = 0.5, tolx = 1e-6, tolf = 1e-6, delta = 0.05, zero_delta = 0.00025;
-    std::vector<std::vector<double>> v, vsort;
-    std::vector<double> fv, x_mean, x_r, x_tmp;
-    std::vector<int> idx;
-    std::function<double(const double*)> eq;
-    // Optional: told which points the NEXT calls of eq() may ask for -- the four candidates of an iteration
-    // (reflection, expansion, the two contractions: all functions of the current simplex,
-    // libcommon/fminsearch.cpp:198-237), the initial simplex, the vertices of a shrink -- so that the owner can
-    // evaluate them in one batched device pass.  eq() is still called in the reference's order with the reference's
-    // accept rules; the hook only changes where the values come from.
-    std::function<void(const std::vector<std::vector<double>>&)> prefetch;
-
-    void init(int n)
-    {
-        N = n;
-        N1 = n + 1;
-        v.assign(N1, std::vector<double>(N, 0.0));
-        vsort = v;
-        fv.assign(N1, 0.0);
-        x_mean.assign(N, 0.0);
-        x_r.assign(N, 0.0);
-        x_tmp.assign(N, 0.0);
-        idx.assign(N1, 0);
-    }
-
-    // Order fv ascending, idx riding along (libcommon/fminsearch.cpp:77-107 does this job).  NOT a stable sort, and which
-    // of two equal values ends up first steers the simplex (the worst vertex is the one replaced), so the permutation has
-    // to be the reference's: a hole-moving partition around the FIRST element of a span, the hole alternating between
-    // the low and the high end.  Restated here with an explicit work list; comparisons are written as the reference has
-    // them (`key <= x`, `key >= x`: a NaN score -- the k-cluster objective can return one -- must stop both scans).
-    void order_values_with_index()
-    {
-        struct Span { int lo, hi; };
-        std::vector<Span> work;
-        work.push_back(Span{0, N});
-        while (!work.empty()) {
-            const Span span = work.back();
-            work.pop_back();
-            if (span.lo >= span.hi) continue;
-            const double key = fv[span.lo];
-            const int key_id = idx[span.lo];
-            int a = span.lo, b = span.hi;   // unsettled part; the hole is at a (low phase) or at b (high phase)
-            for (;;) {
-                while (a < b && key <= fv[b]) --b;     // from the top: first value below the key ...
-                if (a == b) break;
-                fv[a] = fv[b];                         // ... drops into the hole at the bottom; the hole is at b now
-                idx[a] = idx[b];
-                ++a;
-                while (a < b && key >= fv[a]) ++a;     // from the bottom: first value above the key ...
-                if (a == b) break;
-                fv[b] = fv[a];                         // ... rises into the hole at the top; the hole is at a again
-                idx[b] = idx[a];
-                --b;
-            }
-            fv[a] = key;
-            idx[a] = key_id;
-            work.push_back(Span{span.lo, a - 1});      // the two sides are disjoint: their order does not matter
-            work.push_back(Span{a + 1, span.hi});
-        }
-    }
-
-    void sort()
-    {  // __fminsearch_sort :109-123
-        for (int i = 0; i < N1; ++i) idx[i] = i;
-        order_values_with_index();
-        for (int i = 0; i < N1; ++i) vsort[i] = v[idx[i]];
-        v = vsort;
-    }
-
-    bool checkV() const
-    {  // :126-141
-        double mx = -1.7976931348623157e+308;
-        for (int i = 0; i < N; ++i)
-            for (int j = 0; j < N; ++j) mx = std::max(mx, std::fabs(v[i + 1][j] - v[i][j]));
-        return mx <= tolx;
-    }
-
-    bool checkF() const
-    {  // :143-154
-        double mx = -1.7976931348623157e+308;
-        for (int i = 1; i < N1; ++i) mx = std::max(mx, std::fabs(fv[i] - fv[0]));
-        return mx <= tolf;
-    }
-
-    void set_last(const std::vector<double>& x, double f)
-    {  // :252-262
-        v[N] = x;
-        fv[N] = f;
-        sort();
-    }
-
-    void shrink()
-    {  // :238-250
-        for (int i = 1; i < N1; ++i)
-            for (int j = 0; j < N; ++j) v[i][j] = v[0][j] + sigma * (v[i][j] - v[0][j]);
-        if (prefetch) prefetch(std::vector<std::vector<double>>(v.begin() + 1, v.end()));
-        for (int i = 1; i < N1; ++i) fv[i] = eq(v[i].data());
-        sort();
-    }
-
-    // The four points an iteration may evaluate for the SORTED simplex `sv` (reflection, expansion, inside and outside
-    // contraction: libcommon/fminsearch.cpp:189-237) -- the arithmetic of minimize() below, so that a caller looking
-    // ahead asks for bit-identical points.
-    std::vector<std::vector<double>> candidates(const std::vector<std::vector<double>>& sv) const
-    {
-        std::vector<std::vector<double>> pts(4, std::vector<double>(N));
-        for (int a = 0; a < N; ++a) {
-            double mean = 0;
-            for (int j = 0; j < N; ++j) mean += sv[j][a];
-            mean /= N;
-            const double xr = mean + rho * (mean - sv[N][a]);
-            pts[0][a] = xr;
-            pts[1][a] = mean + chi * (xr - mean);
-            pts[2][a] = mean + psi * (mean - sv[N][a]);
-            pts[3][a] = mean + psi * (xr - mean);
-        }
-        return pts;
-    }
-
-    int minimize(const double* X0)
-    {
-        // __fminsearch_min_init :156-187 (note the isinf(previous vertex) rule)
-        if (prefetch) {
-            // the simplex as it comes out when no vertex evaluates to infinity (otherwise some points differ and are
-            // simply evaluated on demand)
-            std::vector<std::vector<double>> pts(N1, std::vector<double>(N));
-            for (int i = 0; i < N1; ++i)
-                for (int j = 0; j < N; ++j) pts[i][j] = ((i - 1) == j) ? (X0[j] ? (1 + delta) * X0[j] : zero_delta) : X0[j];
-            prefetch(pts);
-        }
-        for (int i = 0; i < N1; ++i) {
-            for (int j = 0; j < N; ++j) {
-                const bool big = (i > 1 && std::isinf(fv[i - 1]));
-                if ((i - 1) == j)
-                    v[i][j] = X0[j] ? (1 + (big ? delta * 100 : delta)) * X0[j] : zero_delta;
-                else
-                    v[i][j] = X0[j];
-            }
-            fv[i] = eq(v[i].data());
-        }
-        sort();
-        int i;
-        for (i = 0; i < maxiters; ++i) {
-            if (checkV() && checkF()) break;
-            for (int a = 0; a < N; ++a) {  // x_mean :189-201
-                x_mean[a] = 0;
-                for (int j = 0; j < N; ++j) x_mean[a] += v[j][a];
-                x_mean[a] /= N;
-            }
-            for (int a = 0; a < N; ++a) x_r[a] = x_mean[a] + rho * (x_mean[a] - v[N][a]);
-            if (prefetch) {
-                std::vector<std::vector<double>> pts(4, std::vector<double>(N));
-                for (int a = 0; a < N; ++a) {
-                    pts[0][a] = x_r[a];
-                    pts[1][a] = x_mean[a] + chi * (x_r[a] - x_mean[a]);     // expansion
-                    pts[2][a] = x_mean[a] + psi * (x_mean[a] - v[N][a]);   // inside contraction
-                    pts[3][a] = x_mean[a] + psi * (x_r[a] - x_mean[a]);    // outside contraction
-                }
-                prefetch(pts);
-            }
-            // the reference's accept rules (libcommon/fminsearch.cpp:203-237), one decision per outcome of the reflection:
-            // better than the best -> try the expansion; no better than the worst -> contract (inside when strictly
-            // worse, outside on a tie) or shrink; anything in between -> take the reflection
-            const double f_reflect = eq(x_r.data());
-            const double f_best = fv[0], f_worst = fv[N];
-            if (f_reflect < f_best) {
-                for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + chi * (x_r[a] - x_mean[a]);
-                const double f_expand = eq(x_tmp.data());
-                if (f_expand < f_reflect) set_last(x_tmp, f_expand);
-                else set_last(x_r, f_reflect);
-            } else if (f_reflect > f_worst) {
-                for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + psi * (x_mean[a] - v[N][a]);
-                const double f_inside = eq(x_tmp.data());
-                if (f_inside < f_worst) set_last(x_tmp, f_inside);
-                else shrink();
-            } else if (f_reflect >= f_worst) {   // == the worst (a NaN fails both tests above and this one: next branch)
-                for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + psi * (x_r[a] - x_mean[a]);
-                const double f_outside = eq(x_tmp.data());
-                if (f_outside <= f_reflect) set_last(x_tmp, f_outside);
-                else shrink();
-            } else {
-                set_last(x_r, f_reflect);
-            }
-        }
-        bymax = (i == maxiters);
-        iters = i;
-        return bymax;
-    }
-};
-
-// The reference draws from glibc's process-global rand() (libcommon/mathfunc.c:91-94).  Other libraries
-// in the process (e.g. a collective backend) may call rand() too, so the session keeps a PRIVATE copy of
-// the same generator: rand() is random() on the default TYPE_3 state (128-byte table), which random_r
-// reproduces draw for draw for the same seed.
-struct GlibcRand {
-    struct random_data rd;
-    char state[128];
-    GlibcRand()
-    {
-        memset(&rd, 0, sizeof rd);
-        memset(state, 0, sizeof state);
-        initstate_r(1, state, sizeof state, &rd);  // glibc's state before any srand()
-    }
-    unsigned long long draws = 0;   // values taken from the stream so far (single and bulk)
-    void seed(unsigned v) { srandom_r(v, &rd); }
-    double unifrnd()
-    {
-        int32_t r = 0;
-        random_r(&rd, &r);
-        ++draws;
-        return r / (RAND_MAX + 1.0);
-    }
-    void skip(unsigned long long n)
-    {
-        int32_t r = 0;
-        for (unsigned long long i = 0; i < n; ++i) random_r(&rd, &r);
-        draws += n;
-    }
-    static double to_unit(int32_t r) { return r / (RAND_MAX + 1.0); }
-    // The next n values of rand() in one tight loop (the Monte-Carlo null draws 15 million of them): the additive
-    // feedback step of glibc's random_r for its default TYPE_3 generator -- *fptr += *rptr, result = *fptr >> 1,
-    // both pointers advance and wrap -- on the generator's own state, so single draws before and after continue
-    // the same stream.  Any other generator type falls back to random_r.
-    void fill_raw(int32_t* out, size_t n)
-    {
-        draws += n;
-        if (rd.rand_type != 3 || !rd.fptr || !rd.rptr || !rd.end_ptr || !rd.state) {
-            for (size_t i = 0; i < n; ++i) random_r(&rd, &out[i]);
-            return;
-        }
-        int32_t *f = rd.fptr, *r = rd.rptr, *const end = rd.end_ptr, *const st = rd.state;
-        for (size_t i = 0; i < n; ++i) {
-            const uint32_t val = (uint32_t)*f + (uint32_t)*r;
-            *f = (int32_t)val;
-            out[i] = (int32_t)(val >> 1);
-            ++f;
-            if (f >= end) {
-                f = st;
-                ++r;
-            } else {
-                ++r;
-                if (r >= end) r = st;
-            }
-        }
-        rd.fptr = f;
-        rd.rptr = r;
-    }
-};
-
-// poisspdf, libcommon/mathfunc.c:352-355
-double poisspdf(int x, double lambda) { return std::exp(x * std::log(lambda) - cafehip::gammaln(x + 1) - lambda); }
-
-std::string join_double(const double* v, int n)
-{  // string_pchar_join_double, libcommon/utils_string.c:227-237
-    std::string out;
-    char buf[64];
-    for (int i = 0; i < n; ++i) {
-        snprintf(buf, sizeof buf, "%15.14lf", v[i]);
-        out += buf;
-        if (i < n - 1) out += ",";
-    }
-    return out;
-}
-
-// pvalue(), libcommon/mathfunc.c:663-689: rank of v in the ascending null sample, ties split in half
-double pvalue_rank(double v, const double* conddist, int size)
-{
-    // conddist is sorted ascending (the caller sorts the null's likelihoods).  With `below` values smaller than v and a
-    // run of `equal` values equal to it, the reference's search ends on (first, last) of that run and returns
-    // (first + 1 + (last - first) / 2) / size -- the middle of the run, one-based -- or below / size when nothing equals v.
-    if (size <= 0) return 0.0;
-    const double* const end = conddist + size;
-    const double* const first_not_below = std::lower_bound(conddist, end, v);
-    const double* const first_above = std::upper_bound(first_not_below, end, v);
-    const int below = (int)(first_not_below - conddist);
-    const int equal = (int)(first_above - first_not_below);
-    if (equal == 0) return (double)below / (double)size;
-    return (double)(below + 1 + (equal - 1) / 2.0) / (double)size;
-}
-
-std::string fmt_g(double v)
-{  // default ostream << double (6 significant digits)
-    char buf[64];
-    snprintf(buf, sizeof buf, "%g", v);
-    return buf;
-}
-
-
-// ------------------------------------------------------------------------------------
-// Objective of the empirical root-size prior (__lnLPoisson, cafe/lambda.cpp:771-787): -sum_i log poisspdf(x_i, lambda)
-// over every non-zero leaf count of the table, added in table order.  The sum is one long chain of dependent additions
-// (4 million of them for the configs[3] shard: ~3 ms per call, ~70 calls per fit -- more than the whole GPU search at
-// that size), and its rounding sequence is what the reference computes, so it is kept addition for addition.  What
-// CAN be done is to evaluate SEVERAL lambdas per pass: the chains are independent, so a core interleaves a few at the
-// latency of one, and the cores take different ones.  Which lambdas: the 1-D Nelder-Mead only ever asks for points
-// that are fixed functions of its two vertices -- the four candidates of the current iteration and, for each of the
-// nine ordered simplices the iteration can end in, the four candidates of the next one.  prefetch() evaluates those in
-// one pass (every second iteration then finds all it needs in the cache); value() answers from the cache or, on a miss,
-// with a single chain.  Same values, same call order, same fitted lambda: only where the values come from changes.
-// ------------------------------------------------------------------------------------
-struct PoissonChains {
-    std::vector<uint16_t> sizes16;   // x_i (count - 1), table order
-    std::vector<int> sizes32;        // ... when one does not fit 16 bits
-    int max_x = 0;
-    std::vector<std::pair<double, double>> cache;   // (lambda, -score)
-    long passes = 0, chains = 0, hits = 0, misses = 0;
-
-    void set(const std::vector<int>& leaf_sizes)
-    {
-        max_x = 0;
-        for (int x : leaf_sizes) max_x = std::max(max_x, x);
-        sizes16.clear();
-        sizes32.clear();
-        if (max_x < 65536) sizes16.assign(leaf_sizes.begin(), leaf_sizes.end());
-        else sizes32 = leaf_sizes;
-        cache.clear();
-    }
-    size_t n() const { return sizes32.empty() ? sizes16.size() : sizes32.size(); }
-
-    // log(poisspdf(x, lambda)) is a pure function of x: once per distinct size, as the reference's loop body has it
-    void terms_of(double lambda, double* term) const
-    {
-        for (int x = 0; x <= max_x; ++x) {
-            double ll = poisspdf(x, lambda);
-            if (std::isnan(ll)) ll = 0;
-            term[x] = std::log(ll);
-        }
-    }
-
-    // Up to 8 chains in one sweep: eight scalar accumulators, each receiving ITS chain's additions in table order; the
-    // eight dependency chains overlap in the core's pipeline, so the sweep costs what one chain costs (measured: 3.0 ms
-    // for 4 M sizes with 1 or with 8 chains).  Unused lanes point at lane 0's table and are ignored.
-    template <class T>
-    static void sweep8(const T* xs, size_t n, const double* const* term, double* score)
-    {
-        const double *t0 = term[0], *t1 = term[1], *t2 = term[2], *t3 = term[3], *t4 = term[4], *t5 = term[5], *t6 = term[6], *t7 = term[7];
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
-        for (size_t i = 0; i < n; ++i) {
-            const size_t x = xs[i];
-            s0 += t0[x];
-            s1 += t1[x];
-            s2 += t2[x];
-            s3 += t3[x];
-            s4 += t4[x];
-            s5 += t5[x];
-            s6 += t6[x];
-            s7 += t7[x];
-        }
-        score[0] = s0, score[1] = s1, score[2] = s2, score[3] = s3, score[4] = s4, score[5] = s5, score[6] = s6, score[7] = s7;
-    }
-    template <class T>
-    static void sweep1(const T* xs, size_t n, const double* term, double* score)
-    {
-        double s = 0;
-        for (size_t i = 0; i < n; ++i) s += term[xs[i]];
-        *score = s;
-    }
-
-    static constexpr int kLanes = 8;
-    template <class T>
-    void run_group(const T* xs, const double* lambdas, int count, double* out) const
-    {
-        std::vector<double> tabs((size_t)count * (max_x + 1));
-        const double* term[kLanes];
-        double score[kLanes];
-        for (int k = 0; k < kLanes; ++k) {
-            if (k < count) terms_of(lambdas[k], tabs.data() + (size_t)k * (max_x + 1));
-            term[k] = tabs.data() + (size_t)(k < count ? k : 0) * (max_x + 1);
-        }
-        if (count == 1) sweep1(xs, n(), term[0], score);
-        else sweep8(xs, n(), term, score);
-        for (int k = 0; k < count; ++k) out[k] = -score[k];
-    }
-
-    void evaluate(const double* lambdas, int count, double* out) const
-    {
-        for (int k0 = 0; k0 < count; k0 += kLanes) {
-            const int g = std::min(kLanes, count - k0);
-            if (sizes32.empty()) run_group(sizes16.data(), lambdas + k0, g, out + k0);
-            else run_group(sizes32.data(), lambdas + k0, g, out + k0);
-        }
-    }
-
-    bool lookup(double lambda, double* f) const
-    {
-        for (auto it = cache.rbegin(); it != cache.rend(); ++it)
-            if (it->first == lambda) {
-                *f = it->second;
-                return true;
-            }
-        return false;
-    }
-
-    double value(double lambda)
-    {
-        double f;
-        if (lookup(lambda, &f)) {
-            ++hits;
-            return f;
-        }
-        ++misses;
-        evaluate(&lambda, 1, &f);
-        cache.emplace_back(lambda, f);
-        return f;
-    }
-
-    // evaluate every point not yet known, the chains dealt evenly to up to 16 cores
-    void prefetch(std::vector<double> want)
-    {
-        std::vector<double> todo;
-        for (double x : want) {
-            double f;
-            if (std::isnan(x) || lookup(x, &f) || std::find(todo.begin(), todo.end(), x) != todo.end()) continue;
-            todo.push_back(x);
-        }
-        if (todo.empty()) return;
-        if (cache.size() > 512) cache.erase(cache.begin(), cache.begin() + 256);
-        std::vector<double> f(todo.size());
-        const int hw = std::max(1u, std::thread::hardware_concurrency());
-        // small tables: one core runs everything (a thread costs more than their chains)
-        // (measured on the MI355X box's host, 4 M sizes: a one-chain sweep 1.7 ms, an eight-chain sweep 3.9 ms -- a chain per
-        // core while cores last, several per core only beyond that)
-        const int workers = (n() < 200000) ? 1 : std::max(1, std::min<int>({hw, 16, (int)todo.size()}));
-        if (workers == 1) {
-            evaluate(todo.data(), (int)todo.size(), f.data());
-        } else {
-            std::vector<std::thread> pool;
-            for (int w = 0; w < workers; ++w) {
-                const int a = (int)((long long)todo.size() * w / workers), b = (int)((long long)todo.size() * (w + 1) / workers);
-                if (b > a) pool.emplace_back([&, a, b] { evaluate(todo.data() + a, b - a, f.data() + a); });
-            }
-            for (auto& t : pool) t.join();
-        }
-        for (size_t i = 0; i < todo.size(); ++i) cache.emplace_back(todo[i], f[i]);
-        ++passes;
-        chains += (long)todo.size();
-    }
-};
-
-
-// find_poisson_lambda (cafe/lambda.cpp:808-838): 1-D Nelder-Mead on the objective above from the given start
-struct PoissonFit {
-    double lambda = 0, score = 0;
-    int iters = 0;
-    long passes = 0, chains = 0, hits = 0, misses = 0;
-
-    void run(const std::vector<int>& leaf_sizes, double start, bool lookahead)
-    {
-        FMinSearch pfm;
-        pfm.init(1);
-        pfm.tolx = 1e-6;
-        pfm.tolf = 1e-6;
-        PoissonChains ch;
-        ch.set(leaf_sizes);
-        pfm.eq = [&](const double* pl) { return ch.value(pl[0]); };   // __lnLPoisson :771-787
-        bool looked_ahead = false;
-        if (lookahead)
-            pfm.prefetch = [&](const std::vector<std::vector<double>>& pts) {
-                std::vector<double> want;
-                for (auto& p_ : pts) want.push_back(p_[0]);
-                if (pts.size() == 4) {
-                    // the four candidates of this iteration; every second time also those of the NEXT one, for each ordered
-                    // simplex this iteration can end in: the best vertex a with one of {reflection, expansion, the two
-                    // contractions, the shrunk worst vertex} on either side of it (FMinSearch::candidates: same arithmetic)
-                    bool known = true;
-                    double f_;
-                    for (double x : want) known = known && ch.lookup(x, &f_);
-                    if (!(known && looked_ahead)) {
-                        const double a = pfm.v[0][0], b = pfm.v[1][0];
-                        const double shrunk = a + pfm.sigma * (b - a);
-                        want.push_back(shrunk);
-                        const double fresh[5] = {pts[0][0], pts[1][0], pts[2][0], pts[3][0], shrunk};
-                        for (double x : fresh)
-                            for (int order = 0; order < 2; ++order) {
-                                const std::vector<std::vector<double>> simplex =
-                                    order ? std::vector<std::vector<double>>{{a}, {x}} : std::vector<std::vector<double>>{{x}, {a}};
-                                for (auto& c_ : pfm.candidates(simplex)) want.push_back(c_[0]);
-                            }
-                        looked_ahead = true;
-                    } else {
-                        looked_ahead = false;   // everything this iteration needs came from the last look-ahead: no pass
-                    }
-                }
-                ch.prefetch(want);
-            };
-        pfm.minimize(&start);
-        lambda = pfm.v[0][0];
-        score = pfm.fv[0];
-        iters = pfm.iters;
-        passes = ch.passes;
-        chains = ch.chains;
-        hits = ch.hits;
-        misses = ch.misses;
-    }
-};
-
-struct Argument {
-    std::string opt;
-    std::vector<std::string> argv;
-};
-
-bool is_number(const std::string& s)
-{
-    char* end = nullptr;
-    strtod(s.c_str(), &end);
-    return end != s.c_str() && *end == '\0';
-}
-
-// build_argument_list, cafe/cafe_commands.cpp:476-502: "-x" starts an option unless it is a number
-std::vector<Argument> build_argument_list(const std::vector<std::string>& tokens)
-{
-    std::vector<Argument> out;
-    for (size_t i = 1; i < tokens.size(); ++i) {
-        const std::string& t = tokens[i];
-        if (t.size() > 1 && t[0] == '-' && !is_number(t)) {
-            out.push_back(Argument{t, {}});
-        } else if (!out.empty()) {
-            out.back().argv.push_back(t);
-        }
-    }
-    return out;
-}
+using namespace cafehost_impl;
 
 }  // namespace
 
