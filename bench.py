@@ -336,6 +336,7 @@ def roofline_of(leg, F_local):
                                % MIN_KERNEL_SAMPLES if leg.samples_in_region < MIN_KERNEL_SAMPLES else "all inside the timed region",
         "min_launch_ms": float((km[:, 1] - km[:, 3]).min()),
         "max_launch_ms": float((km[:, 1] - km[:, 3]).max()),
+        "median_launch_ms": float(np.median(km[:, 1] - km[:, 3])),   # (a box hiccup of tens of ms in one sample moves the mean, not this)
         "families_per_launch": F_local,
         "factor_tables": None if not compressed else {
             "kernel": "k2c_nodes (v_mfma_f64_16x16x4): one launch per compression level, 16 states per workgroup",
