@@ -240,7 +240,9 @@ int cafehip_viterbi(cafehip_ctx *ctx, int B, const int32_t *counts, const int32_
  * Rendezvous, barriers and the all-gather of host blocks (report phase) run over a POSIX shared-memory segment named
  * by the 128-byte id: rank 0 obtains one and hands it to the others by any means (file, environment, pipe).
  * Every call below except cafehip_comm_unique_id / cafehip_comm_info is collective: all ranks make it, in the same
- * order.  No reference counterpart (the reference is one process; its threads split the same loop). */
+ * order.  No reference counterpart (the reference is one process; its threads split the same loop).
+ * Status: exercised with 1-3 processes sharing one GPU (bit-identical to one context) and with injected failures; not
+ * yet run between two physical GPUs -- tests/test_gpu_comm.py holds the rank-per-device test for the first node. */
 #define CAFEHIP_COMM_ID_BYTES 128
 int cafehip_comm_unique_id(void *out_id /* CAFEHIP_COMM_ID_BYTES */);
 /* Joins the ranks: rendezvous, buffers mapped, then a FUNCTIONAL probe -- every rank's one-workgroup kernel stores a
