@@ -88,6 +88,9 @@ def gpu(rank, world, idfile, out, cfg_name, F_total, mode, steps):
     init_seconds = time.time() - t0
     delay = os.environ.get("COMM_WORKER_DELAY", "")   # "rank:step:seconds": that rank is late for that evaluation
     d_rank, d_step, d_sec = (int(delay.split(":")[0]), int(delay.split(":")[1]), float(delay.split(":")[2])) if delay else (-1, -1, 0.0)
+    skip = os.environ.get("COMM_WORKER_SKIP", "")     # "rank:step": that rank leaves one evaluation out (its peers time out)
+    s_rank, s_step = (int(skip.split(":")[0]), int(skip.split(":")[1])) if skip else (-1, -1)
+    failures = []
     tree.apply(eng)
     eng.set_families(counts[lo:hi], rng)
     eng.comm_set_blocks(bounds)
@@ -98,6 +101,20 @@ def gpu(rank, world, idfile, out, cfg_name, F_total, mode, steps):
             nl = nl * 400.0        # absurd rates: some family gets zero likelihood -> -inf and a first-zero index
         if rank == d_rank and s == d_step:
             time.sleep(d_sec)
+        if s == s_step and s_rank >= 0:
+            # one rank skips this evaluation: the others' call must FAIL (not hang), and a collective resync must put
+            # every rank back in step (the sequence numbers differ by one from here on otherwise: ADVICE r03)
+            if rank == s_rank:
+                time.sleep(2.0)
+            else:
+                try:
+                    eng.get_posterior_sharded(nl, nm, prior)
+                    failures.append("no error")
+                except Exception as e:   # noqa: BLE001
+                    failures.append(str(e))
+            eng.comm_resync()
+            scores.append(("skipped", -2))
+            continue
         sc, fz = eng.get_posterior_sharded(nl, nm, prior)
         scores.append((float(sc).hex(), int(fz)))
     # a second table through the same communicator (re-wiring)
@@ -111,7 +128,7 @@ def gpu(rank, world, idfile, out, cfg_name, F_total, mode, steps):
     info = eng.comm_info()
     status = eng.comm_status()
     eng.close()
-    json.dump({"rank": rank, "scores": scores, "info": info, "status": status, "init_seconds": init_seconds}, open(out, "w"))
+    json.dump({"rank": rank, "scores": scores, "info": info, "status": status, "init_seconds": init_seconds, "failures": failures}, open(out, "w"))
 
 
 if __name__ == "__main__":

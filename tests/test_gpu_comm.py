@@ -111,6 +111,30 @@ def test_a_late_peer_is_waited_for_in_slices_not_inside_one_kernel(tmp_path, sin
     assert res[0]["status"]["host_paced_repolls"] >= 2 and res[1]["status"]["host_paced_repolls"] == 0
 
 
+def test_ranks_out_of_step_are_realigned_by_a_collective_resync(tmp_path, single):
+    # rank 1 leaves the second evaluation out: rank 0's call fails after its patience (4 s here: four 1 s slices, the GPU is
+    # never inside one kernel for longer) instead of hanging; cafehip_comm_resync on both ranks clears the exchange buffers
+    # and restarts the sequence numbers, and every later evaluation carries the single-context bits again
+    idfile = tmp_path / "id"
+    idfile.write_bytes(os.urandom(128))
+    procs = []
+    for r in range(2):
+        out = tmp_path / ("r%d.json" % r)
+        procs.append((out, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_comm_worker.py"), "gpu", str(r), "2", str(idfile), str(out),
+                                             CFG, str(F_TOTAL), "direct", str(STEPS)], cwd=ROOT,
+                                            env=dict(os.environ, CAFEHIP_COMM_TIMEOUT_S="4", COMM_WORKER_SKIP="1:1"))))
+    res = []
+    for out, p in procs:
+        assert p.wait(timeout=600) == 0
+        res.append(json.load(open(out)))
+    assert len(res[0]["failures"]) == 1 and "did not deliver its row" in res[0]["failures"][0], res[0]["failures"]
+    assert res[1]["failures"] == []
+    for r in res:
+        got = [tuple(x) for x in r["scores"]]
+        assert got[1] == ("skipped", -2)
+        assert got[:1] + got[2:] == single[:1] + single[2:], r["rank"]
+
+
 def _device_count():
     import ctypes as C
     n = C.c_int(0)
