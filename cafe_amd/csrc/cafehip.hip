@@ -1,4 +1,4 @@
-// cafehip.hip -- context and C ABI of the MI355X (gfx950) engine for CAFE's per-family likelihood hot path.
+// cafehip.hip -- context (context.hpp) and C ABI of the MI355X (gfx950) engine for CAFE's per-family likelihood hot path.
 // See include/cafehip.h for the boundary and DESIGN.md for the layout.  The kernels live in their own translation
 // units (kernels.hpp):
 //
@@ -14,299 +14,7 @@
 //   K4  k_misc.hip          max-product walk + backtrack == cafe_tree_viterbi, cafe/viterbi.cpp:208-351
 //
 // gfx950 only.  No CPU fallback: every entry point fails if the device work fails.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <thread>
-#include <climits>
-#include <cmath>
-#include <cstdarg>
-#include <cstddef>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <tuple>
-#include <unordered_map>
-#include <mutex>
-#include <map>
-#include <array>
-#include <vector>
-
-#include "../../include/cafehip.h"
-#include "host_math.hpp"
-#include "comm.hpp"
-#include "kernels.hpp"
-
-using namespace cafehip;
-
-// Debug aid (CAFEHIP_POISON=1 in the environment when the library is loaded): every device allocation is filled with
-// 0xFF bytes -- NaN as a double, -1 as an int -- before anything else touches it and sits between two 64 KiB guard
-// zones of the same bytes, so that a read of memory the library never wrote, or a little outside a buffer, shows up
-// in the outputs instead of depending on what the allocator handed back.
-static const bool g_poison = getenv("CAFEHIP_POISON") != nullptr;
-constexpr size_t kPoisonGuard = 64 * 1024;
-template <class T>
-static hipError_t poison_malloc(T** p, size_t bytes)
-{
-    if (!g_poison) return hipMalloc(reinterpret_cast<void**>(p), bytes);
-    char* raw = nullptr;
-    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&raw), bytes + 2 * kPoisonGuard);
-    if (e != hipSuccess) return e;
-    (void)hipMemset(raw, 0xFF, bytes + 2 * kPoisonGuard);
-    (void)hipDeviceSynchronize();
-    *p = reinterpret_cast<T*>(raw + kPoisonGuard);
-    return hipSuccess;
-}
-template <class T>
-static hipError_t poison_free(T* p)
-{
-    if (!g_poison || !p) return hipFree(const_cast<void*>(static_cast<const volatile void*>(p)));
-    return hipFree(reinterpret_cast<char*>(const_cast<void*>(static_cast<const volatile void*>(p))) - kPoisonGuard);
-}
-#define hipMalloc(p, n) poison_malloc(p, n)
-#define hipFree(p) poison_free(p)
-
-namespace {
-
-thread_local std::string g_err;
-
-int fail(const char* fmt, ...)
-{
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return -1;
-}
-
-#define HIP_TRY(expr)                                                                     \
-    do {                                                                                  \
-        hipError_t e_ = (expr);                                                           \
-        if (e_ != hipSuccess)                                                             \
-            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
-                        __LINE__);                                                        \
-    } while (0)
-
-// one argument struct per kernel (device_types.hpp): every launch is hipLaunchKernel(address, ..., &args)
-template <class Args>
-int launch_kernel(const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const Args& args)
-{
-    if (!fn) return fail("internal: kernel shape not built");
-    void* argv[1] = {const_cast<Args*>(&args)};
-    HIP_TRY(hipLaunchKernel(fn, grid, block, argv, lds, stream));
-    return 0;
-}
-
-}  // namespace
-
-// ====================================================================================
-// context
-// ====================================================================================
-// wave grid of a K2 launch (16x16x4 shape: nft_w family tiles per wave; 4x4x4 shape: nft_w carries G)
-struct K2Cfg {
-    int nft_w, nrt_w, wf, wr;
-};
-struct K2Cand {
-    double cost;
-    bool use4;
-    K2Cfg cfg;
-};
-
-struct cafehip_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t own_stream = nullptr;
-    int lds_limit = 64 * 1024;
-    int n_cu = 0;
-
-    // tree
-    int n_nodes = 0, root = -1;
-    std::vector<int> parent, left, right, bl_int;
-    std::vector<double> bl;
-    cafehip::Schedule sched;
-    cafehip::PruneOp* d_ops = nullptr;
-    cafehip::MfmaSchedule msched;
-    cafehip::MfmaOp* d_mops = nullptr;
-    double* d_park = nullptr;
-    size_t park_cap = 0;
-    int32_t *d_parent = nullptr, *d_prefix = nullptr, *d_vit_slot = nullptr;
-    int n_vit_tables = 0;
-    int k2_cfg[4] = {0, 0, 0, 0};  // NFT_W, NRT_W, Wf, Wr of the last MFMA launch
-    bool k2_used_mfma = false;
-    bool k2_shape4 = false;
-
-    // subtree-state compression of the objective path (schedule.hpp, CTile; rebuilt by set_tree / set_families)
-    struct CompressPlan {
-        bool valid = false;
-        cafehip::MfmaSchedule sched;        // walk of the reduced tree (compressed subtrees are leaves)
-        cafehip::MfmaOp* d_ops = nullptr;
-        int n_cols = 0;                     // index columns of the walk: surviving leaves + compressed subtree roots
-        std::vector<int> col_leaf;          // per column: count-table column of the leaf, or -1 (compressed subtree)
-        int32_t* d_counts = nullptr;        // [Fu][n_cols]
-        uint8_t* d_col_has_err = nullptr;   // [n_cols]
-        int n_nodes = 0;                    // compressed nodes
-        std::vector<cafehip::CTile> tiles;
-        std::vector<int> level_first;       // tiles of level l: [level_first[l], level_first[l + 1])
-        std::vector<int> level_nft;         // ... of 16 * level_nft[l] states each
-        cafehip::CTile* d_tiles = nullptr;
-        int32_t* d_table_off = nullptr;     // [n_nodes]
-        size_t table_elems = 0;             // per parameter set
-        double* d_tables = nullptr;
-        size_t tables_cap = 0;              // elements
-        long states = 0;                    // sum of D over the compressed nodes
-    } cp;
-    // run-time switches (cafehip_set_option; CAFEHIP_<NAME> in the environment is read ONCE, by cafehip_create)
-    struct Options {
-        int compress = 1;             // subtree-state compression of the objective path
-        double compress_theta = -1;   // < 0: by table size and matrix side (rebuild_compression)
-        int compress_min = 64;        // unique rows below which a table is left alone
-        int errfold = 1;              // error model folded into the matrices (posterior mode)
-        int errband = 1;              // banded error models as short sums of gathers
-        int k1 = 0;                   // 0 auto, 1 exact form, 2 per-term product form
-        int k1_kpb = 1;               // keys per K1 workgroup
-        int k2 = 0;                   // 0 matrix cores, 1 row-per-thread kernel (k2_prune_v1)
-        int mfma = 0;                 // 0 either shape, 4 / 16: only that one
-        bool have_cfg16 = false, have_cfg4 = false;
-        int cfg16[4] = {0, 0, 0, 0}, cfg4[4] = {0, 0, 0, 0};   // pinned wave grids "nftw|G,nrtw,wf,wr"
-        int k2tune = 1;               // measured choice of the wave grid
-        int k2tune_log = 0;
-        int k2slots = 1;              // park scratch by resident workgroup (0: one region per family tile)
-        int ldspark = -1;             // park buffers kept in LDS (< 0: by residency)
-        int vitlds = 0;               // Viterbi argmax tables in LDS
-        int k2c_batch = 1;            // k2c_nodes: the child columns of a state gathered in one batch (round 3)
-        int batch_trim = 1;           // batch mode: a tile's products stop at its largest column limit (round 3)
-        int batch_lockstep = 1;       // batch mode: workgroups start generation by generation (L2 reuse of the edge matrices)
-        int walk_lockstep = 0;        // the same pacing for the family walk of an objective evaluation
-        int batch_lockstep_slack = 0; // ... a generation starts when all but this percentage of the previous ones have finished
-    } opt;
-    bool walk_compressed = false;           // the MFMA launcher walks the reduced tree (set around one launch)
-    bool last_compressed = false;           // ... and the last objective evaluation did
-    std::vector<int32_t> h_ucounts;         // unique rows, host copy
-    std::vector<uint8_t> h_leaf_has_err;    // by count-table column
-    double issued_walk = 0, issued_tables = 0;   // matrix-instruction flops issued by the last evaluation's pruning
-
-    // families
-    int F = 0, Fu = 0, n_leaves = 0;
-    int range_min = 0, range_max = 0, root_min = 0, root_max = 0;
-    int M = -1, S = 0, C = 0, R = 0, LD = 0, KP = 0, LDv = 0;
-    int32_t* d_counts = nullptr;  // unique rows
-    int32_t* d_fam2u = nullptr;
-    double *d_max_lik = nullptr, *d_max_post = nullptr;
-    int32_t* d_argmax = nullptr;
-    double* d_chunk_sums = nullptr;
-    int32_t* d_first_zero = nullptr;
-    int n_chunks = 0;
-    int out_sets = 1;             // parameter sets the per-family / per-chunk output buffers hold
-    std::vector<int32_t> fam2u;
-
-    // tables + matrices
-    cafehip::LnCTables lnc;
-    double *d_lncA = nullptr, *d_lncB = nullptr;
-    double *d_expA = nullptr, *d_expB = nullptr;
-    bool all_keys_fast = false, k1_product_form = false;
-    bool force_exact = false;   // cafehip_set_exact_matrices: the reference's per-term arithmetic for the next builds
-    // hipFuncAttributeMaxDynamicSharedMemorySize already granted, per kernel instantiation: the attribute is
-    // per DEVICE, so the high-water marks live in the context (several contexts of one process may sit on
-    // different GPUs)
-    std::unordered_map<const void*, size_t> lds_attr;
-    std::map<std::tuple<const void*, int, size_t>, int> k2_occ;   // resident workgroups per CU of a K2 launch shape
-    int k2_grid = 0, k2_park_slots = 0;                          // workgroups / park slots of the last MFMA K2 launch
-    int32_t* d_park_flags = nullptr;                             // park-slot ownership flags (0 = free)
-    int32_t* d_gen_done = nullptr;                               // batch mode: workgroups finished (lock-step generations)
-    int park_flags_cap = 0;
-    double* d_PT = nullptr;
-    unsigned short* d_vit = nullptr;   // Viterbi argmax tables (global scratch, grow-only)
-    size_t vit_cap = 0;
-    double* d_PTfold = nullptr;  // error model folded into the matrices (posterior mode), same shape as d_PT
-    size_t ptfold_cap = 0;
-    bool fold_current = false;
-    size_t pt_keys_cap = 0;
-
-    // per-evaluation parameters (ring of pinned staging buffers)
-    EvalHeader* h_params[kParamRing] = {};   // pinned, device-mapped; sized by the tree (eval_block_bytes)
-    hipEvent_t h_params_ev[kParamRing] = {};
-    int ring_pos = 0;
-    int key_cap = 0;                          // KeyParam slots of a ring block: kMaxSets x (n_nodes - 1)
-    size_t ring_bytes = 0;
-    const EvalHeader* cur_params = nullptr;   // staged block the next K1 launch reads
-    int cur_slot = 0, cur_sets = 1, cur_prior_n = 0;
-    bool prior_on_device = false;             // d_prior / d_logprior hold prior_seen
-    int32_t* d_node_key = nullptr;            // [kMaxSets][n_nodes] mirror of the staged node -> matrix map (K1 writes it)
-    double *d_prior = nullptr, *d_logprior = nullptr;   // [kMaxPrior] the prior of the evaluations and its logarithms
-    std::vector<int> node_key;
-    std::vector<double> stage_l, stage_m;   // key dedup scratch of stage_params (kept: no allocation per evaluation)
-    std::vector<int> stage_b;
-    std::vector<double> prior_seen, logprior_seen;   // the last prior staged and its logarithms
-    int nkeys = 0;
-    bool have_matrices = false;
-
-    // error model
-    double* d_err = nullptr;
-    int err_mfs = -1;
-    int err_banded = 0, err_dlo = 0, err_dhi = 0, err_band_width = 0;
-    uint8_t* d_leaf_has_err = nullptr;
-    int32_t* d_leaf_has_err32 = nullptr;   // the same flags as 32-bit words: k2c_nodes reads them with scalar loads
-
-    // pinned, device-visible result block of the synchronous path
-    HostResult* h_result = nullptr;
-    size_t h_result_chunks = 0;
-    uint64_t* h_fetch = nullptr;   // cafehip_fetch_small: [0] sequence word, [1..] data
-    size_t h_fetch_words = 0;
-    int32_t fetch_seq = 0;
-    int32_t* d_arrive = nullptr;
-    int32_t host_seq = 0;
-
-    // timing
-    bool timing = false, timing_pending = false;
-    hipEvent_t ev[4] = {};
-    double last_ms[3] = {0, 0, 0};
-    double last_tables_ms = 0;          // part of last_ms[1]: the k2c_nodes launches (compressed subtrees)
-    hipEvent_t ev_mid = nullptr;
-    bool ev_mid_used = false;
-    double last_batch_ms = 0;   // pruning launch of the last cafehip_eval_root_likelihoods call
-    int k2_nf = 0, k2_block = 0;
-    size_t k2_lds = 0;
-    // measured choice of the K2 wave grid (posterior path): see launch_k2_mfma
-    struct {
-        int n_items = -1;
-        std::vector<K2Cand> cands;
-        std::vector<float> best_ms;
-        int cur = 0, round = 0, locked = -1;
-        int reps_launched = 1;   // launches inside the pending measurement
-        bool pending = false;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-    } tune;
-    std::string desc;
-
-    // multi-GPU: one process per GPU of a node (comm.hpp).  Set by cafehip_comm_init / cafehip_comm_set_blocks.
-    CommLink* link = nullptr;
-    int comm_mode = 0;                          // option "comm": 0 auto (direct when every rank mapped every buffer), 1 rccl, 2 direct
-    std::vector<int32_t> blk_lo, blk_hi;        // every rank's block [lo, hi) of the global table
-    int x_slots = 0;                            // chunk slots of a rank's packed row
-    unsigned long long x_seq = 0;               // exchange sequence number (direct mode); re-aligned to 0 by every collective
-                                                // cafehip_comm_set_blocks / cafehip_comm_resync, advanced only by a launch that went out
-    K3xArgs x_last;                             // the last direct exchange's arguments: what a host-paced re-poll waits on
-    int comm_agreed_mode = 0;                   // what the ranks agreed on in cafehip_comm_init: 2 direct, 1 rccl
-    int comm_injected = 0;                      // CAFEHIP_COMM_INJECT made this rank mute in the probe (tests)
-    long x_repolls = 0;                         // k_x_collect launches (a peer was more than a wait slice late)
-    double *d_packed = nullptr, *d_gathered = nullptr;   // RCCL mode: [slots + 1] and [world][slots + 1]
-    int packed_slots = 0;
-    hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;
-    bool ev_x_pending = false;
-    double last_exchange_ms = 0;                // RCCL mode with timing on: all-gather + result pick-up, events on the stream
-    double x_host_seconds = 0;                  // host time inside the exchange step (RCCL mode: launch + pick-up)
-    long x_calls = 0;
-    int x_mode_used = 0;                        // exchange mode of the last sharded evaluation (1 rccl, 2 direct)
-    double setup_ms[4] = {0, 0, 0, 0};          // last cafehip_set_families: row dedup, compression plan, uploads + allocation, total
-#ifdef CAFE_K2_STAMPS
-    unsigned long long* d_stamps = nullptr;   // debug timeline of the last K2 launch (tools/k2_stamps.py)
-    size_t stamps_cap = 0;
-#endif
-};
+#include "context.hpp"
 
 namespace {
 
@@ -1492,9 +1200,6 @@ int check_ready(cafehip_ctx* c)
     return 0;
 }
 
-// one in-kernel wait of the direct exchange (the host repeats it until comm_timeout_s is over)
-static double x_wait_slice_s() { return std::min(1.0, comm_timeout_s()); }
-
 int ensure_output_sets(cafehip_ctx* c, int n_sets)
 {
     if (n_sets <= c->out_sets) return 0;
@@ -1524,9 +1229,11 @@ int ensure_output_sets(cafehip_ctx* c, int n_sets)
     return 0;
 }
 
-int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu,
-                const double* prior, double* d_chunk_sums, int32_t* d_first_zero, bool host_out = false, int n_sets = 1,
-                bool direct_exchange = false)
+}  // namespace
+
+// (declared in context.hpp: the multi-GPU entry points of cafehip_comm.hip run the same evaluation)
+int cafehip_impl::eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu, const double* prior, double* d_chunk_sums,
+                              int32_t* d_first_zero, bool host_out, int n_sets, bool direct_exchange)
 {
     if (check_ready(c)) return -1;
     HIP_TRY(hipSetDevice(c->device));
@@ -1622,7 +1329,7 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
 }
 
 // elapsed times of the last evaluation's three launches (blocks until its last event has completed)
-int collect_kernel_ms(cafehip_ctx* c)
+int cafehip_impl::collect_kernel_ms(cafehip_ctx* c)
 {
     if (!c->timing || !c->timing_pending) return 0;
     HIP_TRY(hipEventSynchronize(c->ev[3]));
@@ -1640,6 +1347,8 @@ int collect_kernel_ms(cafehip_ctx* c)
     c->timing_pending = false;
     return 0;
 }
+
+namespace {
 
 // ---- run-time switches ---------------------------------------------------------------------------------------
 // (name, what it selects) -- cafehip_set_option; the same names upper-cased behind CAFEHIP_ are read from the
@@ -2622,372 +2331,6 @@ int cafehip_fetch_small(cafehip_ctx* c, const void* d_src, size_t nbytes, const 
     std::atomic_thread_fence(std::memory_order_acquire);  // payload reads stay behind the flag read
     *host_ptr = c->h_fetch + 1;
     return 0;
-}
-
-// ---- multi-GPU exchange behind the ABI (comm.hpp) ---------------------------------------------------------------
-int cafehip_comm_unique_id(void* out_id)
-{
-    if (!out_id) return fail("null argument");
-    FILE* f = fopen("/dev/urandom", "rb");
-    const size_t got = f ? fread(out_id, 1, CAFEHIP_COMM_ID_BYTES, f) : 0;
-    if (f) fclose(f);
-    if (got != CAFEHIP_COMM_ID_BYTES) {
-        // no entropy source: time and pid are unique enough for a rendezvous name on one node
-        unsigned long long v[CAFEHIP_COMM_ID_BYTES / 8];
-        const unsigned long long t = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
-        for (size_t i = 0; i < CAFEHIP_COMM_ID_BYTES / 8; ++i) v[i] = t * (2 * i + 1) ^ ((unsigned long long)getpid() << 17) ^ (i * 0x9E3779B97F4A7C15ull);
-        memcpy(out_id, v, CAFEHIP_COMM_ID_BYTES);
-    }
-    return 0;
-}
-
-// Functional probe of the peer mappings (k_x_probe): this rank's kernel stores into every peer's probe words and waits
-// <= 1 s for theirs.  Returns how many peers' stores arrived here (world: all).
-static int run_comm_probe(cafehip_ctx* c, CommLink& L)
-{
-    L.probe_ran = false;
-    L.peers_seen = 0;
-    if (!L.p2p_ok) return 0;   // some rank could not even map: nobody launches (the peers' words would never be written)
-    const char* inj = getenv("CAFEHIP_COMM_INJECT");   // tests: "mute:<rank>" -- mapped, but its stores never leave
-    int mute = 0;
-    if (inj && !strncmp(inj, "mute:", 5) && atoi(inj + 5) == L.rank) mute = 1;
-    c->comm_injected = mute;
-    int32_t* d_seen = nullptr;
-    HIP_TRY(hipMalloc(&d_seen, sizeof(int32_t)));
-    HIP_TRY(hipMemsetAsync(d_seen, 0, sizeof(int32_t), c->stream));
-    XProbeArgs a;
-    memset(&a, 0, sizeof a);
-    for (int r = 0; r < L.world; ++r) a.probe[r] = reinterpret_cast<unsigned long long*>(CommLink::probe_of(L.peer_xbuf[r]));
-    a.rank = L.rank;
-    a.world = L.world;
-    a.mute = mute;
-    a.nonce = L.nonce;
-    a.timeout_ticks = (long long)(std::min(1.0, comm_timeout_s()) * 1e8);
-    a.seen = d_seen;
-    const auto t0 = std::chrono::steady_clock::now();
-    if (launch_kernel(kx_probe_kernel(), dim3(1), dim3(64), 0, c->stream, a)) {
-        hipFree(d_seen);
-        return -1;
-    }
-    int32_t seen = 0;
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(&seen, d_seen, sizeof seen, hipMemcpyDeviceToHost);
-    hipFree(d_seen);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        seen = 0;   // a faulting probe is a failed probe: the ranks fall back together
-    }
-    L.probe_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    L.probe_ran = true;
-    L.peers_seen = seen;
-    return seen;
-}
-
-int cafehip_comm_init(cafehip_ctx* c, int rank, int world, const void* unique_id)
-{
-    if (!c || !unique_id) return fail("null argument");
-    if (c->link) return fail("this context already belongs to a communicator");
-    HIP_TRY(hipSetDevice(c->device));
-    CommLink* L = new CommLink();
-    if (!L->init(c->device, rank, world, unique_id)) {
-        const std::string msg = L->error;
-        delete L;
-        return fail("communicator: %s", msg.c_str());
-    }
-    // "mapped" is not "reachable": every rank probes its peers with real stores and loads, and the ranks agree on ONE
-    // mode -- direct only if every rank saw every peer, else RCCL, else the communicator fails on every rank -- here,
-    // not inside the first evaluation.  (Everybody has zeroed its buffer and passed two barriers since: setup_p2p.)
-    const int seen = run_comm_probe(c, *L);
-    if (seen < 0) {
-        L->fail(cafehip_last_error());
-        delete L;
-        return -1;
-    }
-    const int mode = L->decide_mode(seen == world, [&] { return c->comm_mode != 2 && L->ensure_rccl(); });
-    if (mode <= 0) {
-        const std::string msg = mode < 0 ? L->error
-                                         : "no exchange mode works on every rank: direct refused (this rank mapped " + std::to_string(L->peers_mapped) +
-                                               " and heard " + std::to_string(L->peers_seen) + " of " + std::to_string(world) +
-                                               " ranks; at least one rank did not hear all)" +
-                                               (c->comm_mode == 2 ? ", and option comm=direct rules out RCCL" : ", RCCL: " + (L->error.empty() ? std::string("unavailable on some rank") : L->error));
-        delete L;
-        return fail("communicator: %s", msg.c_str());
-    }
-    if (mode == 1 && world > 1)
-        fprintf(stderr, "cafehip: rank %d: direct exchange refused by the probe (mapped %d, heard %d of %d ranks) -- all ranks use RCCL\n", rank,
-                L->peers_mapped, L->peers_seen, world);
-    c->comm_agreed_mode = mode;
-    c->link = L;
-    c->x_seq = 0;
-    c->blk_lo.clear();
-    c->blk_hi.clear();
-    return 0;
-}
-
-// exchange mode a sharded evaluation will use: 2 direct (peer buffers mapped on every rank) unless RCCL was asked for
-static int comm_pick_mode(cafehip_ctx* c)
-{
-    if (c->comm_mode == 1) return 1;
-    if (c->link->direct_ok) return 2;   // the verdict every rank agreed on after the functional probe
-    return c->comm_mode == 2 ? -1 : 1;
-}
-
-// collective: everybody is between evaluations; clear my exchange buffer between two barriers and restart the sequence
-static int comm_realign(cafehip_ctx* c)
-{
-    CommLink& L = *c->link;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (!L.barrier()) return fail("communicator: %s", L.error.c_str());
-    if (L.xbuf) {
-        HIP_TRY(hipMemset(L.xbuf, 0, 2 * CommLink::parity_stride_bytes()));
-        HIP_TRY(hipDeviceSynchronize());
-    }
-    c->x_seq = 0;   // ranks that fell out of step (one failed or skipped an evaluation) are in step again from here
-    if (!L.barrier()) return fail("communicator: %s", L.error.c_str());
-    return 0;
-}
-
-int cafehip_comm_set_blocks(cafehip_ctx* c, const int32_t* block_lo, const int32_t* block_hi)
-{
-    if (!c || !block_lo || !block_hi) return fail("null argument");
-    if (!c->link) return fail("cafehip_comm_init has not been called");
-    CommLink& L = *c->link;
-    HIP_TRY(hipSetDevice(c->device));
-    int slots = 1;
-    for (int r = 0; r < L.world; ++r) {
-        if (block_hi[r] < block_lo[r] || (r > 0 && block_lo[r] != block_hi[r - 1]) ||
-            (block_lo[r] % CAFEHIP_CHUNK != 0 && block_hi[r] != block_lo[r]))   // (an empty block may sit at the table's ragged end)
-            return fail("rank %d: block [%d, %d) must be contiguous with its neighbour's and start on a multiple of %d", r, block_lo[r], block_hi[r], CAFEHIP_CHUNK);
-        slots = std::max(slots, (block_hi[r] - block_lo[r] + CAFEHIP_CHUNK - 1) / CAFEHIP_CHUNK);
-    }
-    if (block_hi[L.rank] - block_lo[L.rank] != c->F)
-        return fail("this rank's block holds %d families but its table has %d", block_hi[L.rank] - block_lo[L.rank], c->F);
-    if (slots > kCommSlotCap) return fail("%d chunks per rank exceed the exchange buffer (%d)", slots, kCommSlotCap);
-    c->blk_lo.assign(block_lo, block_lo + L.world);
-    c->blk_hi.assign(block_hi, block_hi + L.world);
-    c->x_slots = slots;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    // host mirror: world rows of slots + 1 doubles
-    const size_t need = (size_t)L.world * (slots + 1);
-    if (!c->h_result || need > c->h_result_chunks) {
-        hipHostFree(c->h_result);
-        c->h_result = nullptr;
-        const size_t bytes = sizeof(HostResult) + need * sizeof(double);
-        HIP_TRY(hipHostMalloc((void**)&c->h_result, bytes, hipHostMallocMapped | hipHostMallocCoherent));
-        memset((void*)c->h_result, 0, bytes);
-        c->h_result_chunks = need;
-        c->host_seq = 0;
-    }
-    // direct mode: rows of ranks with fewer chunks must read 0 in the slots they never write.  Everybody is between
-    // evaluations here (collective call): clear my buffer between two barriers, sequence numbers back to 0
-    if (comm_realign(c)) return -1;
-    // RCCL mode buffers
-    if (slots != c->packed_slots || !c->d_packed) {
-        hipFree(c->d_packed);
-        hipFree(c->d_gathered);
-        c->d_packed = c->d_gathered = nullptr;
-        HIP_TRY(hipMalloc(&c->d_packed, (size_t)(slots + 1) * sizeof(double)));
-        HIP_TRY(hipMalloc(&c->d_gathered, need * sizeof(double)));
-        c->packed_slots = slots;
-    }
-    HIP_TRY(hipMemset(c->d_packed, 0, (size_t)(slots + 1) * sizeof(double)));   // unused chunk slots read 0 on every rank
-    HIP_TRY(hipDeviceSynchronize());
-    if (!L.barrier()) return fail("communicator: %s", L.error.c_str());
-    return 0;
-}
-
-static int wait_host_seq(cafehip_ctx* c, int32_t want, bool* peer_timeout)
-{
-    // spin on the sequence number the last score block publishes (a few microseconds after the kernel ends); fall
-    // back to a stream query now and then so that a faulted launch cannot hang us
-    unsigned long spins = 0;
-    if (peer_timeout) *peer_timeout = false;
-    for (;;) {
-        const int32_t seen = c->h_result->done_seq;
-        if (seen == want) break;
-        if (peer_timeout && seen == -want) {
-            *peer_timeout = true;
-            break;
-        }
-        if ((++spins & 0x3FFFF) == 0) {
-            hipError_t q = hipStreamQuery(c->stream);
-            if (q == hipSuccess) {
-                if (c->h_result->done_seq != want && !(peer_timeout && c->h_result->done_seq == -want)) HIP_TRY(hipStreamSynchronize(c->stream));
-                const int32_t now = c->h_result->done_seq;
-                if (peer_timeout && now == -want) *peer_timeout = true;
-                else if (now != want) return fail("score kernel finished without publishing its result");
-                break;
-            }
-            if (q != hipErrorNotReady) return fail("stream error while waiting: %s", hipGetErrorString(q));
-        }
-    }
-    // the payload was written before the sequence number (device-side system fence): order our reads after the flag read
-    std::atomic_thread_fence(std::memory_order_acquire);
-    return 0;
-}
-
-int cafehip_eval_posterior_sharded(cafehip_ctx* c, const double* node_lambda, const double* node_mu, const double* prior,
-                                   double* score, int32_t* first_zero_global)
-{
-    if (!c) return fail("null context");
-    if (!node_lambda || !node_mu || !prior || !score) return fail("null argument");
-    if (!c->link || c->blk_lo.empty()) return fail("cafehip_comm_init / cafehip_comm_set_blocks have not been called");
-    if (c->d_err && c->err_mfs < c->range_max)
-        return fail("error model covers sizes 0..%d but range_max is %d", c->err_mfs, c->range_max);
-    CommLink& L = *c->link;
-    if (c->blk_hi[L.rank] - c->blk_lo[L.rank] != c->F) return fail("the table changed: call cafehip_comm_set_blocks again");
-    const int mode = comm_pick_mode(c);
-    if (mode < 0) return fail("direct exchange asked for but the peer buffers could not be mapped on every rank");
-    const int slots = c->x_slots, row_len = slots + 1;
-    const double* rows = nullptr;
-    if (mode == 2) {
-        if (eval_device(c, node_lambda, node_mu, prior, nullptr, c->d_first_zero, true, 1, true)) return -1;
-        bool peer_timeout = false;
-        if (wait_host_seq(c, c->host_seq, &peer_timeout)) return -1;
-        const auto t_wait0 = std::chrono::steady_clock::now();
-        while (peer_timeout) {
-            // the score kernel gave up after one slice: wait on in slices of the same length (k_x_collect, one workgroup)
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait0).count() + x_wait_slice_s() > comm_timeout_s())
-                return fail("direct exchange: a rank did not deliver its row within %.0f s", comm_timeout_s());
-            K3xArgs x = c->x_last;
-            x.seq = ++c->host_seq;
-            ++c->x_repolls;
-            if (launch_kernel(kx_collect_kernel(), dim3(1), dim3(CAFEHIP_CHUNK), 0, c->stream, x)) return -1;
-            if (wait_host_seq(c, c->host_seq, &peer_timeout)) return -1;
-        }
-        rows = c->h_result->chunk_sums;
-    } else {
-        if (!L.rccl && !L.ensure_rccl()) return fail("RCCL exchange: %s", L.error.c_str());
-        int32_t* d_fz = reinterpret_cast<int32_t*>(c->d_packed + slots);
-        if (eval_device(c, node_lambda, node_mu, prior, c->d_packed, d_fz)) return -1;
-        const auto t0 = std::chrono::steady_clock::now();
-        if (c->timing) {
-            if (!c->ev_x0) {
-                HIP_TRY(hipEventCreate(&c->ev_x0));
-                HIP_TRY(hipEventCreate(&c->ev_x1));
-            }
-            HIP_TRY(hipEventRecord(c->ev_x0, c->stream));
-        }
-        // the one exchange step: ONE ncclAllGather of the packed rows on the context's stream, picked up without a
-        // copy command or a stream synchronisation
-        const int rc = rccl_api().AllGather(c->d_packed, c->d_gathered, (size_t)row_len, ncclDouble, L.rccl, c->stream);
-        if (rc != ncclSuccess) return fail("ncclAllGather: %s", rccl_api().GetErrorString(rc));
-        const void* host = nullptr;
-        if (cafehip_fetch_small(c, c->d_gathered, (size_t)row_len * L.world * sizeof(double), &host)) return -1;
-        if (c->timing) {
-            HIP_TRY(hipEventRecord(c->ev_x1, c->stream));
-            HIP_TRY(hipEventSynchronize(c->ev_x1));
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, c->ev_x0, c->ev_x1));
-            c->last_exchange_ms = ms;
-        }
-        c->x_host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        rows = static_cast<const double*>(host);
-    }
-    ++c->x_calls;
-    c->x_mode_used = mode;
-    if (collect_kernel_ms(c)) return -1;
-    // the same fixed-order sum on every rank: chunk order == family order; empty slots add 0
-    double s = 0.0;
-    int fz = -1;
-    for (int r = 0; r < L.world; ++r) {
-        const double* row = rows + (size_t)r * row_len;
-        for (int k = 0; k < slots; ++k) s += row[k];
-        long long local;
-        if (mode == 2) {
-            memcpy(&local, row + slots, sizeof local);
-        } else {
-            int32_t l32;
-            memcpy(&l32, row + slots, sizeof l32);
-            local = l32;
-        }
-        if (local >= 0 && local < c->blk_hi[r] - c->blk_lo[r] && fz < 0) fz = c->blk_lo[r] + (int)local;
-    }
-    *score = fz >= 0 ? -INFINITY : s;   // cafe/lambda.cpp:753-760
-    if (first_zero_global) *first_zero_global = fz;
-    return 0;
-}
-
-int cafehip_comm_resync(cafehip_ctx* c)
-{
-    if (!c) return fail("null context");
-    if (!c->link) return fail("cafehip_comm_init has not been called");
-    HIP_TRY(hipSetDevice(c->device));
-    return comm_realign(c);
-}
-
-int cafehip_comm_status(cafehip_ctx* c, int32_t out[CAFEHIP_COMM_STATUS_WORDS], double* probe_ms)
-{
-    if (!c || !out) return fail("null argument");
-    memset(out, 0, sizeof(int32_t) * CAFEHIP_COMM_STATUS_WORDS);
-    if (probe_ms) *probe_ms = 0.0;
-    if (!c->link) return 0;
-    const CommLink& L = *c->link;
-    out[0] = L.world;
-    out[1] = c->comm_agreed_mode;
-    out[2] = c->x_mode_used ? c->x_mode_used : std::max(comm_pick_mode(c), 0);
-    out[3] = L.direct_ok ? 1 : 0;
-    out[4] = L.peers_mapped;
-    out[5] = L.probe_ran ? L.peers_seen : -1;
-    out[6] = L.rccl != nullptr ? 1 : 0;
-    out[7] = L.rccl_count;
-    out[8] = c->comm_injected;
-    out[9] = (int32_t)std::min<long>(c->x_repolls, INT32_MAX);
-    if (probe_ms) *probe_ms = L.probe_ms;
-    return 0;
-}
-
-int cafehip_comm_cleanup(const void* unique_id)
-{
-    if (!unique_id) return fail("null argument");
-    return CommLink::unlink_names(unique_id);
-}
-
-int cafehip_comm_mode_selftest(int rank, int world, const void* unique_id, int my_probe_ok, int my_rccl_ok, int* mode)
-{
-    // the mode agreement alone (CommLink::decide_mode over the shared-memory mailboxes), the local outcomes injected:
-    // what the CPU test suite runs with several processes, one of them "mapped but unreachable"
-    if (!unique_id || !mode) return fail("null argument");
-    CommLink L;
-    if (!L.init(-1, rank, world, unique_id)) return fail("communicator: %s", L.error.c_str());
-    *mode = L.decide_mode(my_probe_ok != 0, [&] { return my_rccl_ok != 0; });
-    if (*mode < 0) return fail("communicator: %s", L.error.c_str());
-    return L.barrier() ? 0 : fail("communicator: %s", L.error.c_str());
-}
-
-int cafehip_comm_allgather(cafehip_ctx* c, const void* mine, size_t nbytes_mine, void* all, size_t nbytes_slot)
-{
-    if (!c || !all) return fail("null argument");
-    if (!c->link) return fail("cafehip_comm_init has not been called");
-    if (nbytes_mine > nbytes_slot) return fail("block of %zu bytes does not fit its %zu-byte slot", nbytes_mine, nbytes_slot);
-    if (!c->link->host_allgather(mine, nbytes_mine, all, nbytes_slot)) return fail("communicator: %s", c->link->error.c_str());
-    return 0;
-}
-
-int cafehip_comm_info(cafehip_ctx* c, int* rank, int* world, int* mode, double* exchange_ms, double* host_seconds, long* calls)
-{
-    if (!c) return fail("null context");
-    if (rank) *rank = c->link ? c->link->rank : 0;
-    if (world) *world = c->link ? c->link->world : 1;
-    if (mode) *mode = c->link ? (c->x_mode_used ? c->x_mode_used : std::max(comm_pick_mode(c), 0)) : 0;
-    if (exchange_ms) *exchange_ms = c->last_exchange_ms;
-    if (host_seconds) *host_seconds = c->x_host_seconds;
-    if (calls) *calls = c->x_calls;
-    return 0;
-}
-
-int cafehip_comm_host_selftest(int rank, int world, const void* unique_id, const void* mine, size_t nbytes_mine, void* all,
-                               size_t nbytes_slot)
-{
-    // the host half of the communicator alone (rendezvous, mailboxes, barrier, host all-gather): no context, no
-    // device needed -- exercised by the CPU test suite with several processes
-    if (!unique_id || !all) return fail("null argument");
-    CommLink L;
-    if (!L.init(-1, rank, world, unique_id)) return fail("communicator: %s", L.error.c_str());
-    for (int round = 0; round < 3; ++round)
-        if (!L.barrier()) return fail("communicator: %s", L.error.c_str());
-    if (!L.host_allgather(mine, nbytes_mine, all, nbytes_slot)) return fail("communicator: %s", L.error.c_str());
-    return L.barrier() ? 0 : fail("communicator: %s", L.error.c_str());
 }
 
 int cafehip_enable_timing(cafehip_ctx* c, int on)
