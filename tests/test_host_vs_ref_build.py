@@ -106,6 +106,8 @@ def test_poisson_prior_fit_with_lookahead_is_the_plain_fit_bit_for_bit():
         xs = np.ascontiguousarray(rs.poisson(lam_true, n).astype(np.int32))
         if n == 5000:
             xs[17] = 400        # poisspdf underflows: log(0) = -inf terms, the fit must walk through them identically
+        if n == 60000:
+            xs[123] = 70000     # one size beyond 16 bits: the chains fall back to 32-bit sizes, same values
         out = {}
         for la in (0, 1):
             lam, sc, it, ps = C.c_double(), C.c_double(), C.c_int(), C.c_long()
