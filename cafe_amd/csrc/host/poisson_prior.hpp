@@ -170,6 +170,7 @@ struct PoissonChains {
 
 // find_poisson_lambda (cafe/lambda.cpp:808-838): 1-D Nelder-Mead on the objective above from the given start
 struct PoissonFit {
+    static constexpr size_t kLookaheadMinSizes = 500000;
     double lambda = 0, score = 0;
     int iters = 0;
     long passes = 0, chains = 0, hits = 0, misses = 0;
@@ -184,7 +185,9 @@ struct PoissonFit {
         ch.set(leaf_sizes);
         pfm.eq = [&](const double* pl) { return ch.value(pl[0]); };   // __lnLPoisson :771-787
         bool looked_ahead = false;
-        if (lookahead)
+        // (below ~half a million sizes a sweep is tens of microseconds: one chain per call is as fast as it gets --
+        // measured 4.1 ms plain against 5.4 ms with look-ahead at 160 k sizes, 46 against 25 ms at 1.2 M)
+        if (lookahead && leaf_sizes.size() >= kLookaheadMinSizes)
             pfm.prefetch = [&](const std::vector<std::vector<double>>& pts) {
                 std::vector<double> want;
                 for (auto& p_ : pts) want.push_back(p_[0]);

@@ -116,7 +116,10 @@ def test_poisson_prior_fit_with_lookahead_is_the_plain_fit_bit_for_bit():
                                                    C.byref(it), C.byref(ps)) == 0
             out[la] = (lam.value, sc.value, it.value, ps.value, time.time() - t0)
         assert out[0][:3] == out[1][:3], (n, out)
-        assert out[1][3] < 0.75 * out[0][3], (n, out)       # sweeps over the table: at most three quarters, typically a third
+        if n >= 500000:
+            assert out[1][3] < 0.75 * out[0][3], (n, out)   # sweeps over the table: at most three quarters, typically a third
+        else:
+            assert out[1][3] == out[0][3]                   # small tables: a sweep is microseconds, the plain fit is the fast one
         if n <= 5000:
             # ... and the plain fit is the reference's: its fminsearch, its poisspdf, the same sum
             def cb(xp, _):
