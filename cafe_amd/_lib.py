@@ -49,6 +49,7 @@ SIGNATURES = {
     "cafehip_comm_status": (C.c_int, [C.c_void_p, _ip, _dp]),
     "cafehip_comm_cleanup": (C.c_int, [C.c_void_p]),
     "cafehip_comm_mode_selftest": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "cafehip_exp_like_host_selftest": (C.c_int, [C.c_long, C.c_uint, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "cafehip_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cafehip_fetch_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "cafehip_last_kernel_ms": (C.c_int, [C.c_void_p, _dp]),

@@ -15,6 +15,7 @@
 //
 // gfx950 only.  No CPU fallback: every entry point fails if the device work fails.
 #include "context.hpp"
+#include "exp_like_host.hpp"
 
 namespace {
 
@@ -242,6 +243,10 @@ int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr, bool defer_ring_e
     a.prior_offset = eval_prior_offset(c->key_cap, c->n_nodes);
     a.prior_dev = c->d_prior;
     a.logprior_dev = c->d_logprior;
+    {
+        static const int variant = host_exp_variant();   // which build of exp() this host's libm runs (exp_like_host.hpp); once
+        a.exp_variant = c->opt.exp_like_host ? variant : 0;
+    }
     if (c->cur_prior_n > 0) c->prior_on_device = true;
     c->cur_prior_n = 0;   // (this launch mirrors it)
     dim3 grid((c->S + 15) / 16, (c->S + 15) / 16, (c->nkeys + kpb - 1) / kpb);
@@ -1355,7 +1360,7 @@ namespace {
 // environment ONCE, when the context is created (tools/ sweeps), never during an evaluation
 const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
                                     "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch",
-                                    "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "comm"};
+                                    "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "exp_like_host", "comm"};
 
 int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
 {
@@ -1403,6 +1408,7 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     else if (key == "batch_lockstep") o.batch_lockstep = iv != 0;
     else if (key == "walk_lockstep") o.walk_lockstep = iv != 0;
     else if (key == "batch_lockstep_slack") o.batch_lockstep_slack = std::min(std::max(iv, 0), 100);
+    else if (key == "exp_like_host") o.exp_like_host = iv != 0;
     else if (key == "comm") {
         if (val == "rccl") c->comm_mode = 1;
         else if (val == "direct") c->comm_mode = 2;
@@ -2331,6 +2337,13 @@ int cafehip_fetch_small(cafehip_ctx* c, const void* d_src, size_t nbytes, const 
     std::atomic_thread_fence(std::memory_order_acquire);  // payload reads stay behind the flag read
     *host_ptr = c->h_fetch + 1;
     return 0;
+}
+
+int cafehip_exp_like_host_selftest(long n, unsigned seed, long* mismatches_fused, long* mismatches_plain)
+{
+    // host only: both restated forms of exp() against this host's std::exp on n arguments; returns the variant K1's exact
+    // form would use (1 fused, 2 plain, 0 neither)
+    return host_exp_variant(mismatches_fused, mismatches_plain, n, seed);
 }
 
 int cafehip_enable_timing(cafehip_ctx* c, int on)

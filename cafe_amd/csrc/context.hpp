@@ -171,6 +171,7 @@ struct cafehip_ctx {
         int batch_lockstep = 1;       // batch mode: workgroups start generation by generation (L2 reuse of the edge matrices)
         int walk_lockstep = 0;        // the same pacing for the family walk of an objective evaluation
         int batch_lockstep_slack = 0; // ... a generation starts when all but this percentage of the previous ones have finished
+        int exp_like_host = 1;        // K1 exact form: exp() as this host's libm computes it, when recognised (exp_like_host.hpp)
     } opt;
     bool walk_compressed = false;           // the MFMA launcher walks the reduced tree (set around one launch)
     bool last_compressed = false;           // ... and the last objective evaluation did

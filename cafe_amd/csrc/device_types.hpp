@@ -70,6 +70,7 @@ struct K1Args {
     size_t prior_offset;         // of the two kMaxPrior-long arrays inside the pinned block
     double* prior_dev;
     double* logprior_dev;
+    int exp_variant;             // exact form: 1 / 2 = the host libm's exp restated (fused / plain build), 0 = the device library's
 };
 
 struct FoldArgs {   // k1e_fold_error

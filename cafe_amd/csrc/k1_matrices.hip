@@ -1,6 +1,7 @@
 // k1_matrices.hip -- K1: birth-death transition matrices for every unique (int branch length, lambda, mu) key of one
 // evaluation == compute_birthdeath_rates, libtree/birthdeath.c:238-286; k1e_fold_error: the error model folded
 // into those matrices (posterior path), cafe/cafe_tree.c:196-203.  gfx950 only.
+#include "exp_like_host.hpp"
 #include "kernels.hpp"
 
 namespace {
@@ -37,10 +38,20 @@ __device__ __forceinline__ void k1_mirror_node_keys(const K1Args& a)
 // running product for coeff^j, clamp to [0,1]; contraction is off so each term is the
 // same sequence of IEEE operations as the reference's x86-64 build.
 // ------------------------------------------------------------------------------------
+// exp() of a term in the exact form: the host libm's own operation sequence where it was recognised (exp_like_host.hpp), so
+// that the matrices of the report phase carry the bits the reference's build would produce on this machine
+__device__ __forceinline__ double k1_exp(double t, int variant)
+{
+    if (variant == 1) return exp_like_host<true>(t);
+    if (variant == 2) return exp_like_host<false>(t);
+    return exp(t);
+}
+
 #pragma clang fp contract(off)
 template <bool USE_LDS, bool PRODUCT_FORM>
 __global__ __launch_bounds__(256) void k1_build_matrices(K1Args ka)
 {
+    const int exp_variant = ka.exp_variant;
     // `ep` is this evaluation's parameter block in PINNED HOST memory (read over the fabric: one 56-byte
     // KeyParam per workgroup); block (0,0,0) mirrors the node -> key map into device memory for the later
     // launches, so an evaluation needs no separate host-to-device copy.
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256) void k1_build_matrices(K1Args ka)
 #pragma unroll 4
                 for (int j = 0; j <= m; ++j) {
                     const double t = a[j] + b[c - j] + (double)(s_add_c - 2 * j) * kp.log_alpha;
-                    p += exp(t) * lastterm;
+                    p += k1_exp(t, exp_variant) * lastterm;
                     lastterm *= kp.coeff;
                 }
             } else {
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256) void k1_build_matrices(K1Args ka)
                 for (int j = 0; j <= m; ++j) {
                     const double t = a[j] + b[c - j] + (double)(s - j) * kp.log_alpha +
                                      (double)(c - j) * kp.log_beta + (double)j * kp.log_coeff;
-                    p += exp(t);
+                    p += k1_exp(t, exp_variant);
                 }
             }
             p = fmax(fmin(p, 1.0), 0.0);  // MAX(MIN(p,1),0)

@@ -306,6 +306,13 @@ int cafehip_comm_mode_selftest(int rank, int world, const void *unique_id, int m
  * (No reference counterpart: the reference's reduction is a host loop, cafe/lambda.cpp:698-722.) */
 int cafehip_fetch_small(cafehip_ctx *ctx, const void *d_src, size_t nbytes, const void **host_ptr);
 
+/* Test hook (host only): the two restated forms of the host libm's exp() (cafe_amd/csrc/exp_like_host.hpp) against this
+ * host's exp() on n pseudo-random arguments; returns the form K1's exact arithmetic uses for the report phase's matrices
+ * (1: the fused-multiply-add build, 2: the plain build, 0: neither matched -- the device library's exp), and how many
+ * arguments each form missed.  Replaces nothing: it is how "the same bits as the reference's build on this machine" is kept
+ * for the comparisons of cafe/viterbi.cpp:60-67 and cafe/cafe_tree.c:533-569. */
+int cafehip_exp_like_host_selftest(long n, unsigned seed, long *mismatches_fused, long *mismatches_plain);
+
 /* Timing of the kernels of the last cafehip_eval_posterior call, measured with HIP
  * events on the context's stream: ms[0] = matrix build, ms[1] = pruning+posterior,
  * ms[2] = score reduction.  Enabled by cafehip_enable_timing(ctx, 1). */
