@@ -74,6 +74,8 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *                              chip holds at once, so that co-resident tiles stream the same edge matrix through L2 (1)
  *   batch_lockstep_slack 0..100  ... a generation starts when all but this percentage of the earlier ones finished (0)
  *   walk_lockstep   0|1        the same pacing for the family walk of an objective evaluation (0: measured slower)
+ *   exp_like_host   0|1        exact-form matrices call exp() as THIS HOST's libm computes it, restated for the device, when
+ *                              one of its two builds matches std::exp at first use (1); 0: the device library's exp
  *   comm            auto|direct|rccl   exchange mode of sharded evaluations (multi-GPU section below)
  * The same names, upper-cased behind CAFEHIP_ (CAFEHIP_COMPRESS=0 ...), are read from the environment ONCE, by
  * cafehip_create; nothing reads the environment during an evaluation.  Options that change the compression plan
