@@ -105,7 +105,7 @@ def gpu(rank, world, idfile, out, cfg_name, F_total, mode, steps):
             # one rank skips this evaluation: the others' call must FAIL (not hang), and a collective resync must put
             # every rank back in step (the sequence numbers differ by one from here on otherwise: ADVICE r03)
             if rank == s_rank:
-                time.sleep(2.0)
+                time.sleep(3.0)
             else:
                 try:
                     eng.get_posterior_sharded(nl, nm, prior)
