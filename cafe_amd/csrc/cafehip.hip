@@ -302,7 +302,7 @@ int launch_k2_v1(cafehip_ctx* c, K2Args& a, int n_items)
     c->k2_block = block;
     c->k2_lds = lds;
     a.n_slots = c->sched.n_slots;
-    const void* fn = k2_v1_kernel(nf);
+    const void* fn = k2_v1_kernel(nf, c->opt.k2 == 2);
     if (grant_lds(c, fn, lds, 64 * 1024)) return -1;
     return launch_kernel(fn, dim3((n_items + nf - 1) / nf), dim3(block), lds, c->stream, a);
 }
@@ -1167,7 +1167,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
 
 int launch_k2(cafehip_ctx* c, K2Args& a, int n_items, int n_sets = 1)
 {
-    if (c->opt.k2 == 1) {
+    if (c->opt.k2 != 0) {
         c->k2_used_mfma = false;
         if (n_sets > 1) return fail("several parameter sets per pass need the matrix-core kernel");
         return launch_k2_v1(c, a, n_items);
@@ -1268,7 +1268,7 @@ int cafehip_impl::eval_device(cafehip_ctx* c, const double* node_lambda, const d
     {
         // the objective path walks the reduced tree when the table compresses (matrix-core kernels; an error model
         // only in its folded form, so that every leaf stays a column gather)
-        const bool use_c = c->cp.valid && c->opt.k2 != 1 && (!c->d_err || c->fold_current);
+        const bool use_c = c->cp.valid && c->opt.k2 == 0 && (!c->d_err || c->fold_current);
         c->issued_tables = 0;
         if (use_c && launch_compressed_levels(c, n_sets)) return -1;
         c->ev_mid_used = false;
@@ -1382,8 +1382,9 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     } else if (key == "k1kpb") o.k1_kpb = std::max(1, iv);
     else if (key == "k2") {
         if (val == "v1") o.k2 = 1;
+        else if (val == "v1ref") o.k2 = 2;   // ... in the reference's arithmetic (separate multiply and add per term)
         else if (val.empty() || val == "auto" || val == "mfma") o.k2 = 0;
-        else return fail("option k2: auto | mfma | v1, got '%s'", val.c_str());
+        else return fail("option k2: auto | mfma | v1 | v1ref, got '%s'", val.c_str());
     } else if (key == "mfma") {
         if (val == "4") o.mfma = 4;
         else if (val == "16") o.mfma = 16;

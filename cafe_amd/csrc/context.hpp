@@ -157,7 +157,7 @@ struct cafehip_ctx {
         int errband = 1;              // banded error models as short sums of gathers
         int k1 = 0;                   // 0 auto, 1 exact form, 2 per-term product form
         int k1_kpb = 1;               // keys per K1 workgroup
-        int k2 = 0;                   // 0 matrix cores, 1 row-per-thread kernel (k2_prune_v1)
+        int k2 = 0;                   // 0 matrix cores, 1 row-per-thread kernel (k2_prune_v1), 2 the same in the reference's arithmetic
         int mfma = 0;                 // 0 either shape, 4 / 16: only that one
         bool have_cfg16 = false, have_cfg4 = false;
         int cfg16[4] = {0, 0, 0, 0}, cfg4[4] = {0, 0, 0, 0};   // pinned wave grids "nftw|G,nrtw,wf,wr"

@@ -418,6 +418,22 @@ struct cafehost_session {
     bool opt_timing = false;     // "timing": phase times of report / the Monte-Carlo null on stderr
     std::string opt_prior_file;  // "prior_file": root-size prior of the searches read from a file instead of fitted
     int opt_prior_lookahead = 1; // "prior_lookahead": the Poisson fit evaluates the points Nelder-Mead may ask for several per pass
+    // "report_arith" = reference: the likelihood vectors of the report phase (Monte-Carlo null, observed families) in the
+    // reference's own arithmetic -- the row-per-thread kernel with a separate multiply and add per term (cafehip option
+    // k2=v1ref) on the exact-form matrices: bit for bit what the reference's build computes on this machine, so every
+    // likelihood's rank in its sorted null is the reference's for any input; slower than the matrix cores (default: fast)
+    bool opt_report_reference = false;
+    struct ReportArith {   // scope guard around the likelihood launches of a report-phase command
+        cafehost_session* s;
+        explicit ReportArith(cafehost_session* s_) : s(s_)
+        {
+            if (s->opt_report_reference && cafehip_set_option(s->ctx, "k2", "v1ref") != 0) throw std::runtime_error(std::string("cafehip: ") + cafehip_last_error());
+        }
+        ~ReportArith()
+        {
+            if (s->opt_report_reference) (void)cafehip_set_option(s->ctx, "k2", "auto");
+        }
+    };
 
     bool speculation_pays()
     {
@@ -1385,6 +1401,7 @@ struct cafehost_session {
                                      "branchcutting, likelihood and lh2 are SURVEY.md section 2 OUT OF SCOPE)");
         }
         const std::string name = tokens[1];
+        ReportArith arith(this);
         if (just_save) {
             if (rep_sizes.size() != (size_t)fam.F() * tree.n || rep_max_p.size() != (size_t)fam.F() || rep_expand.size() != (size_t)tree.n - 1)
                 throw std::runtime_error("ERROR(report): nothing to save -- run `report <name>` on this table first");
@@ -2193,6 +2210,7 @@ struct cafehost_session {
             if (a.opt == "-i") infile = a.argv[0];
             if (a.opt == "-idx") index = atoi(a.argv[0].c_str());
         }
+        ReportArith arith(this);
         if (!outfile.empty()) {
             std::vector<std::vector<double>> mats;
             const int S = fetch_matrices(mats);
@@ -2375,6 +2393,7 @@ int cafehost_create(cafehost_session** out, int device_id, const char* log_path)
     if (getenv("CAFEHOST_TIMING")) s->opt_timing = true;
     if (const char* e = getenv("CAFEHOST_LHTEST_DEAL")) s->opt_lhtest_deal = atoi(e);
     if (const char* e = getenv("CAFEHOST_PRIOR_LOOKAHEAD")) s->opt_prior_lookahead = atoi(e);
+    if (const char* e = getenv("CAFEHOST_REPORT_ARITH")) s->opt_report_reference = std::string(e) == "reference";
     *out = s;
     return 0;
 }
@@ -2389,6 +2408,11 @@ int cafehost_set_option(cafehost_session* s, const char* key, const char* value)
     }
     if (k == "timing") {
         s->opt_timing = atoi(v.c_str()) != 0;
+        return 0;
+    }
+    if (k == "report_arith") {
+        if (v != "reference" && v != "fast" && !v.empty()) return host_fail("option report_arith: fast | reference, got '" + v + "'");
+        s->opt_report_reference = v == "reference";
         return 0;
     }
     if (k == "prior_lookahead") {

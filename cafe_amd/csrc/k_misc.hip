@@ -22,8 +22,14 @@ using namespace cafehip;
 // LDS broadcasts.  k runs ascending, i.e. in the reference's summation order
 // (libtree/birthdeath.c:173-180).  A one-hot leaf (cafe/cafe_tree.c:208-209) turns
 // the product into the gather PT[count][row].
+// REF (option k2=v1ref): the REFERENCE's arithmetic, not only its order -- every term a separate multiplication and a separate
+// addition (square_matrix_multiply, libtree/birthdeath.c:163-182, as gcc builds it for x86-64: no fused multiply-add), the
+// vector of a node the product of its two factors (cafe/cafe_tree.c:261-266).  On matrices built in K1's exact form (the host
+// libm's exp(), exp_like_host.hpp) the node vectors then carry the reference build's bits: what the report phase can ask for
+// when its comparisons -- a likelihood's rank in a sorted null -- are to be the reference's for every input, at the price of
+// the vector unit's speed.
 // ------------------------------------------------------------------------------------
-template <int NF>
+template <int NF, bool REF>
 __global__ __launch_bounds__(1024) void k2_prune_v1(K2Args a)
 {
     // dynamic LDS: [n_slots (+1 with an error model)][NF][LDv] node vectors, then the tile's counts and column limits
@@ -87,14 +93,26 @@ __global__ __launch_bounds__(1024) void k2_prune_v1(K2Args a)
 #pragma unroll
                 for (int f = 0; f < NF; ++f) y[ch][f] = 0.0;
                 if (r < rows) {
-                    for (int k = 0; k < a.C; k += 2) {
-                        const double p0 = PTc[(size_t)k * a.LD];
-                        const double p1 = PTc[(size_t)(k + 1) * a.LD];
+                    if constexpr (REF) {
+#pragma clang fp contract(off)
+                        for (int k = 0; k < a.C; ++k) {   // (k < C exactly: the padding column is not a term of the reference's sum)
+                            const double p0 = PTc[(size_t)k * a.LD];
 #pragma unroll
-                        for (int f = 0; f < NF; ++f) {
-                            const double2 l = *reinterpret_cast<const double2*>(src + f * a.LDv + k);
-                            y[ch][f] = fma(p0, l.x, y[ch][f]);
-                            y[ch][f] = fma(p1, l.y, y[ch][f]);
+                            for (int f = 0; f < NF; ++f) {
+                                const double term = p0 * src[f * a.LDv + k];
+                                y[ch][f] = y[ch][f] + term;
+                            }
+                        }
+                    } else {
+                        for (int k = 0; k < a.C; k += 2) {
+                            const double p0 = PTc[(size_t)k * a.LD];
+                            const double p1 = PTc[(size_t)(k + 1) * a.LD];
+#pragma unroll
+                            for (int f = 0; f < NF; ++f) {
+                                const double2 l = *reinterpret_cast<const double2*>(src + f * a.LDv + k);
+                                y[ch][f] = fma(p0, l.x, y[ch][f]);
+                                y[ch][f] = fma(p1, l.y, y[ch][f]);
+                            }
                         }
                     }
                 }
@@ -599,14 +617,24 @@ __global__ __launch_bounds__(1024) void k4_viterbi(K4Args a)
 
 namespace cafehip {
 
-const void* k2_v1_kernel(int nf)
+const void* k2_v1_kernel(int nf, bool reference_arithmetic)
 {
+    if (reference_arithmetic) {
+        switch (nf) {
+            case 16: return reinterpret_cast<const void*>(&k2_prune_v1<16, true>);
+            case 8: return reinterpret_cast<const void*>(&k2_prune_v1<8, true>);
+            case 4: return reinterpret_cast<const void*>(&k2_prune_v1<4, true>);
+            case 2: return reinterpret_cast<const void*>(&k2_prune_v1<2, true>);
+            case 1: return reinterpret_cast<const void*>(&k2_prune_v1<1, true>);
+        }
+        return nullptr;
+    }
     switch (nf) {
-        case 16: return reinterpret_cast<const void*>(&k2_prune_v1<16>);
-        case 8: return reinterpret_cast<const void*>(&k2_prune_v1<8>);
-        case 4: return reinterpret_cast<const void*>(&k2_prune_v1<4>);
-        case 2: return reinterpret_cast<const void*>(&k2_prune_v1<2>);
-        case 1: return reinterpret_cast<const void*>(&k2_prune_v1<1>);
+        case 16: return reinterpret_cast<const void*>(&k2_prune_v1<16, false>);
+        case 8: return reinterpret_cast<const void*>(&k2_prune_v1<8, false>);
+        case 4: return reinterpret_cast<const void*>(&k2_prune_v1<4, false>);
+        case 2: return reinterpret_cast<const void*>(&k2_prune_v1<2, false>);
+        case 1: return reinterpret_cast<const void*>(&k2_prune_v1<1, false>);
     }
     return nullptr;
 }

@@ -27,7 +27,7 @@ const void* k2_mfma4_kernel(int G, int nrt_w);
 const void* k2c_kernel(int nft_w, int nrt_w, bool batch_gathers);
 
 // k_misc.hip
-const void* k2_v1_kernel(int nf);          // k2_prune_v1<NF>(K2Args), NF in {1, 2, 4, 8, 16}
+const void* k2_v1_kernel(int nf, bool reference_arithmetic = false);   // k2_prune_v1<NF, REF>(K2Args), NF in {1, 2, 4, 8, 16}
 const void* k3_kernel(bool host_out);      // k3_score<HOST_OUT>(K3Args)
 const void* k3x_kernel();                  // k3_score_x(K3xArgs): score + direct multi-GPU exchange
 const void* kx_collect_kernel();           // k_x_collect(K3xArgs): the exchange's wait alone (host-paced re-poll)

@@ -1,0 +1,105 @@
+"""The report phase in the REFERENCE's arithmetic (round 4): K1's exact form with the host libm's exp() (exp_like_host.hpp) +
+the row-per-thread kernel with a separate multiply and add per term (option k2=v1ref) -- the operation sequence of
+libtree/birthdeath.c:163-182 and cafe/cafe_tree.c:191-323 as gcc builds it for x86-64.  The likelihood vectors must then be
+the oracle's BIT FOR BIT (== on doubles, not a tolerance): per-row extents as the Monte-Carlo null and the report use them,
+lambda-only and lambda/mu matrices, and -- through the host driver, option report_arith=reference -- the null distribution
+itself, whose sorted samples decide every p-value."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import _orc as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+NEWICK = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+
+
+def _host_exp_recognised():
+    from cafe_amd import _lib
+    a, b = C.c_long(), C.c_long()
+    return _lib.load().cafehip_exp_like_host_selftest(200000, 3, C.byref(a), C.byref(b)) != 0
+
+
+@pytest.mark.parametrize("lam,mu", [(0.0017, -1.0), (0.01075268816939, -1.0), (0.002, 0.0015)])
+def test_root_likelihood_vectors_are_the_oracles_bits(lam, mu):
+    import cafe_amd
+    if not _host_exp_recognised():
+        pytest.skip("this host's exp() is neither restated form: the matrices are not the host's bit for bit")
+    t = O.PyTree(NEWICK)
+    mx = 60
+    rng = O.make_range(0, mx + 50, 1, 75)
+    rs = np.random.RandomState(5)
+    B = 700
+    rows = rs.poisson(6, size=(B, t.n_leaves)).astype(np.int32)
+    rows[:50] = rs.randint(0, mx, size=(50, t.n_leaves))
+    col_max = np.minimum(rows.max(axis=1) + np.maximum(50, rows.max(axis=1) // 5), rng.max).astype(np.int32)
+    lo = rs.randint(1, 40, size=B).astype(np.int32)
+    hi = np.minimum(lo + rs.randint(0, 12, size=B), 75).astype(np.int32)
+    nl, nm = np.full(t.n_nodes, lam), np.full(t.n_nodes, mu)
+    eng = cafe_amd.Engine(0)
+    try:
+        eng.set_option("k1", "exact")
+        eng.set_option("k2", "v1ref")
+        eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+        eng.set_families(rows[:64], cafe_amd.FamilySizeRange(rng.min, rng.max, rng.root_min, rng.root_max))
+        eng.reset_birthdeath_cache(nl, nm)
+        got = eng.eval_root_likelihoods(rows, lo, hi, col_max)
+        eng.set_option("k2", "auto")
+        fast = eng.eval_root_likelihoods(rows, lo, hi, col_max)
+    finally:
+        eng.close()
+    mats = O.build_matrices(t, rng, nl, nm, nthreads=2)
+    try:
+        ref = O.eval_root_likelihoods(t, mats, rows, lo, hi, col_max, nthreads=os.cpu_count() or 1)
+    finally:
+        O.free_matrices(mats)
+    assert np.array_equal(got, ref)                       # every double, bit for bit
+    nz = ref > 0
+    assert np.max(np.abs(fast[nz] - ref[nz]) / ref[nz]) < 1e-9 and not np.array_equal(fast, ref)   # (the matrix cores agree to ~1e-15, not to the bit)
+
+
+def test_null_distribution_of_the_report_in_reference_arithmetic(tmp_path):
+    # the host driver's Monte-Carlo null (draws in the reference's rand() order, likelihoods on the GPU) under
+    # report_arith=reference: every one of the R x 1000 sorted likelihoods equals the oracle's conditional distribution,
+    # so every family p-value (a rank in that distribution) is the reference's; the report equals the fast one's text
+    from cafe_amd.shell import CafeShell
+    if not _host_exp_recognised():
+        pytest.skip("this host's exp() is neither restated form")
+    sp, ids, counts = O.load_family_table(os.path.join(GOLD, "example_data.tab"))
+    t = O.PyTree(NEWICK)
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    outs = {}
+    for arith in ("reference", "fast"):
+        sh = CafeShell(0, os.devnull)
+        sh.set_option("report_arith", arith)
+        for line in ("seed 10", "load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"), "tree " + NEWICK, "lambda -l 0.0017"):
+            sh.dispatch(line)
+        pv = str(tmp_path / ("null_%s.txt" % arith))
+        sh.dispatch("pvalue -o " + pv)
+        rep = str(tmp_path / ("rep_%s" % arith))
+        sh.dispatch("report " + rep)
+        sh.close()
+        outs[arith] = (np.loadtxt(pv), open(rep + ".cafe").read())
+    # oracle: the same draws (seed 10; `lambda -l` fits the Poisson prior, whose random start consumes one), same matrices
+    libc = C.CDLL(None)
+    L = O.lib()
+    lam, mu = np.full(t.n_nodes, 0.0017), np.full(t.n_nodes, -1.0)
+    ct = t.ctree()
+    h = L.orc_matrices_build(C.byref(ct), O.dptr(lam), O.dptr(mu), max(rng.max, rng.root_max), 1)
+    libc.srand(10)
+    libc.rand()
+    R = rng.root_max - rng.root_min + 1
+    cd = np.zeros((R, 1000))
+    L.orc_conditional_distribution(C.byref(ct), C.byref(rng), h, 1000, O.dptr(cd))
+    O.free_matrices(h)
+    # the file holds 9 significant digits: compare what was written, digit for digit, with the oracle's values written the same way
+    want = np.array([[float("%.9g" % v) for v in row] for row in cd])
+    assert outs["reference"][0].shape == want.shape
+    assert np.array_equal(outs["reference"][0], want)
+    assert outs["reference"][1] == outs["fast"][1]        # and the report text does not move
