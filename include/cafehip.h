@@ -60,7 +60,8 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *   errband         0|1        banded error models as short sums of column gathers (1)
  *   k1              auto|exact|perterm   arithmetic form of the matrix build (auto: register-blocked product form)
  *   k1kpb           n          matrices per K1 workgroup (1)
- *   k2              auto|v1    pruning kernel: matrix cores | row-per-thread vector FMA
+ *   k2              auto|v1|v1ref   pruning kernel: matrix cores | row-per-thread vector FMA | row-per-thread in the
+ *                              reference's arithmetic (separate multiply and add per term: with k1=exact the oracle's bits)
  *   mfma            auto|4|16  matrix instruction shape of the walk
  *   k2cfg, k2cfg4   "a,b,wf,wr"  pin the wave grid of the 16x16x4 / 4x4x4 kernel (empty: measured choice)
  *   k2tune          0|1        measure the wave grids on the first evaluations of a table (1)

@@ -117,7 +117,12 @@ double cafehost_poisson_lambda(cafehost_session *s);
 /* Run-time switches: "speculate" (auto|0|1: batched candidate evaluation, below), "timing" (0|1: phase times of
  * report / the Monte-Carlo null on stderr), "prior_file" (path, "" = off: the searches take the root-size prior from
  * this file -- one probability per line for root sizes root_min, root_min + 1, ... -- instead of fitting the
- * reference's empirical Poisson, cafe/lambda.cpp:808-870; an extension for tables whose root distribution is known);
+ * reference's empirical Poisson, cafe/lambda.cpp:808-870; an extension for tables whose root distribution is known),
+ * "report_arith" (fast|reference: the likelihood vectors of report / pvalue on the matrix cores, or in the reference's
+ * own arithmetic -- exact-form matrices with the host libm's exp() and a separate multiply and add per term -- which
+ * returns the oracle's bits, Monte-Carlo null included, at about 2.7x the report time), "prior_lookahead" (0|1: the Poisson
+ * fit evaluates Nelder-Mead's candidate points several per sweep, same bits), "lhtest_deal" (0|1: a sharded job deals
+ * lhtest's files to the ranks);
  * every other key is handed to cafehip_set_option on the session's device
  * context(s) (include/cafehip.h).  CAFEHOST_SPECULATE / CAFEHOST_TIMING in the environment are read once, by
  * cafehost_create. */
