@@ -114,6 +114,61 @@ def test_oracle_spot_check_on_a_sample(problem):
     assert np.max(np.abs(ml[idx] - mlo) / mlo) < 1e-9
     assert np.max(np.abs(mp[idx] - mpo) / mpo) < 1e-9
     assert np.array_equal(am[idx], amo)
+    # round 4: ALL 499,712 families against the reference's own arithmetic run on the GPU (k1=exact, k2=v1ref: pinned to the
+    # oracle bit for bit, here on the same sample) -- the sample is no longer the only thing standing behind the other 99 %
+    eng = cafe_amd.Engine(0)
+    try:
+        eng.set_option("k1", "exact")
+        eng.set_option("k2", "v1ref")
+        p["tree"].apply(eng)
+        eng.set_families(p["counts"], p["fr"])
+        s1, fz1, ml1, am1, mp1 = eng.get_posterior(p["lam"], p["mu"], p["prior"], per_family=True)
+    finally:
+        eng.close()
+    assert fz1 == -1
+    assert np.max(np.abs(ml - ml1) / ml1) < 1e-9 and np.max(np.abs(mp - mp1) / mp1) < 1e-9 and np.array_equal(am, am1)
+    assert np.max(np.abs(ml1[idx] - mlo) / mlo) < 1e-12
+
+
+def test_every_family_against_the_reference_arithmetic(problem):
+    # Round 4: not a sample.  The library can run the reference's OWN arithmetic on the GPU -- exact-form matrices with the
+    # host libm's exp() and a separate multiply and add per term (options k1=exact, k2=v1ref), pinned to the oracle BIT FOR
+    # BIT (tests/test_gpu_reference_arithmetic.py, and on this table's oracle sample below).  Every family of the
+    # full-size table is compared with that run: likelihood and posterior to 1e-9 relative (measured ~1e-12: the product
+    # form of the search path), root argmax exactly.
+    import cafe_amd
+    import ctypes as C
+    from cafe_amd import _lib
+    p = problem
+    score, fz, ml, am, mp = p["full"]
+    eng = cafe_amd.Engine(0)
+    try:
+        eng.set_option("k1", "exact")
+        eng.set_option("k2", "v1ref")
+        eng.set_tree(p["t"].parent, p["t"].left, p["t"].right, p["t"].branchlength)
+        eng.set_families(p["counts"], p["fr"])
+        if p["err"] is not None:
+            eng.set_error_model(p["err"])
+        s1, fz1, ml1, am1, mp1 = eng.get_posterior(p["lam"], p["mu"], p["prior"], per_family=True)
+    finally:
+        eng.close()
+    assert fz1 == fz
+    assert np.max(np.abs(ml - ml1) / ml1) < 1e-9 and np.max(np.abs(mp - mp1) / mp1) < 1e-9
+    assert np.array_equal(am, am1)
+    assert abs(score - s1) < 1e-9 * abs(s1)
+    # ... and the reference-arithmetic run IS the oracle on the sample (bit for bit where the host's exp() is recognised)
+    a, b = C.c_long(), C.c_long()
+    recognised = _lib.load().cafehip_exp_like_host_selftest(200000, 5, C.byref(a), C.byref(b)) != 0
+    idx = _oracle_sample(p["counts"], 512, 29)
+    ekw = (dict(errormatrix=p["err"], err_mfs=p["rng"].max, leaf_has_err=np.ones(p["t"].n_nodes, np.uint8))
+           if p["err"] is not None else {})
+    so, fzo, mlo, amo, mpo = O.eval_posterior(p["t"], p["counts"][idx], p["rng"], p["lam"], p["mu"], p["prior"],
+                                              nthreads=os.cpu_count() or 1, **ekw)
+    if recognised:
+        assert np.array_equal(ml1[idx], mlo)
+    else:
+        assert np.max(np.abs(ml1[idx] - mlo) / mlo) < 1e-12
+    assert np.array_equal(am1[idx], amo)
 
 
 def test_identity_error_model_is_a_no_op(problem):
