@@ -114,20 +114,6 @@ def test_oracle_spot_check_on_a_sample(problem):
     assert np.max(np.abs(ml[idx] - mlo) / mlo) < 1e-9
     assert np.max(np.abs(mp[idx] - mpo) / mpo) < 1e-9
     assert np.array_equal(am[idx], amo)
-    # round 4: ALL 499,712 families against the reference's own arithmetic run on the GPU (k1=exact, k2=v1ref: pinned to the
-    # oracle bit for bit, here on the same sample) -- the sample is no longer the only thing standing behind the other 99 %
-    eng = cafe_amd.Engine(0)
-    try:
-        eng.set_option("k1", "exact")
-        eng.set_option("k2", "v1ref")
-        p["tree"].apply(eng)
-        eng.set_families(p["counts"], p["fr"])
-        s1, fz1, ml1, am1, mp1 = eng.get_posterior(p["lam"], p["mu"], p["prior"], per_family=True)
-    finally:
-        eng.close()
-    assert fz1 == -1
-    assert np.max(np.abs(ml - ml1) / ml1) < 1e-9 and np.max(np.abs(mp - mp1) / mp1) < 1e-9 and np.array_equal(am, am1)
-    assert np.max(np.abs(ml1[idx] - mlo) / mlo) < 1e-12
 
 
 def test_every_family_against_the_reference_arithmetic(problem):
@@ -447,3 +433,17 @@ def test_configs3_500k_whole_table_8_way_split_and_oracle_sample(cfg4_500k):
     assert np.max(np.abs(ml[idx] - mlo) / mlo) < 1e-9
     assert np.max(np.abs(mp[idx] - mpo) / mpo) < 1e-9
     assert np.array_equal(am[idx], amo)
+    # round 4: ALL 499,712 families against the reference's own arithmetic run on the GPU (k1=exact, k2=v1ref: pinned to the
+    # oracle bit for bit, here on the same sample) -- the sample is no longer the only thing standing behind the other 99 %
+    eng = cafe_amd.Engine(0)
+    try:
+        eng.set_option("k1", "exact")
+        eng.set_option("k2", "v1ref")
+        p["tree"].apply(eng)
+        eng.set_families(p["counts"], p["fr"])
+        s1, fz1, ml1, am1, mp1 = eng.get_posterior(p["lam"], p["mu"], p["prior"], per_family=True)
+    finally:
+        eng.close()
+    assert fz1 == -1
+    assert np.max(np.abs(ml - ml1) / ml1) < 1e-9 and np.max(np.abs(mp - mp1) / mp1) < 1e-9 and np.array_equal(am, am1)
+    assert np.max(np.abs(ml1[idx] - mlo) / mlo) < 1e-12
