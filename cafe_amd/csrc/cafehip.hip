@@ -218,6 +218,14 @@ struct RingGuard {
     }
 };
 
+// which build of exp() this host's libm runs (exp_like_host.hpp): decided once per process, at the first context's creation
+// (200,000 calls of std::exp: a few milliseconds that do not belong inside an evaluation)
+int host_exp_variant_once()
+{
+    static const int variant = host_exp_variant();
+    return variant;
+}
+
 int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr, bool defer_ring_event = false)
 {
     if (c->nkeys == 0) return 0;
@@ -243,10 +251,7 @@ int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr, bool defer_ring_e
     a.prior_offset = eval_prior_offset(c->key_cap, c->n_nodes);
     a.prior_dev = c->d_prior;
     a.logprior_dev = c->d_logprior;
-    {
-        static const int variant = host_exp_variant();   // which build of exp() this host's libm runs (exp_like_host.hpp); once
-        a.exp_variant = c->opt.exp_like_host ? variant : 0;
-    }
+    a.exp_variant = c->opt.exp_like_host ? host_exp_variant_once() : 0;
     if (c->cur_prior_n > 0) c->prior_on_device = true;
     c->cur_prior_n = 0;   // (this launch mirrors it)
     dim3 grid((c->S + 15) / 16, (c->S + 15) / 16, (c->nkeys + kpb - 1) / kpb);
@@ -1467,6 +1472,7 @@ int cafehip_create(cafehip_ctx** out, int device_id)
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     if (device_id < 0 || device_id >= ndev) return fail("device %d out of range [0,%d)", device_id, ndev);
     HIP_TRY(hipSetDevice(device_id));
+    (void)host_exp_variant_once();
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     cafehip_ctx* c = new cafehip_ctx();
