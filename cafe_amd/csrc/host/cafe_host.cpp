@@ -317,6 +317,8 @@ struct cafehost_session {
                 if (species_index[s] >= 0)
                     counts[(size_t)i * nl + species_index[s] / 2] = fam.counts[(size_t)(shard_lo + i) * ns + s];
         hip_check(cafehip_set_families(ctx, F, nl, counts.data(), nullptr, range.min, range.max, range.root_min, range.root_max));
+        if (opt_objective_reference) device_rows = counts;   // (the reference-arithmetic objective scores the rows one by one)
+        else device_rows.clear();
         if (err_mfs >= 0)
             hip_check(cafehip_set_error_model(ctx, err_mfs, err_matrix.data(), err_leaf.data()));
         else
@@ -423,6 +425,14 @@ struct cafehost_session {
     // k2=v1ref) on the exact-form matrices: bit for bit what the reference's build computes on this machine, so every
     // likelihood's rank in its sorted null is the reference's for any input; slower than the matrix cores (default: fast)
     bool opt_report_reference = false;
+    // "objective_arith" = reference: every objective evaluation of a search in the reference's own arithmetic AND order --
+    // exact-form matrices, root likelihood vectors from the row-per-thread kernel with a separate multiply and add per
+    // term, then on the host, with the host's libm, exp(log L + log prior), the maximum, and the sum of logs in family
+    // order (cafe/lambda.cpp:657-724 line by line): the score carries the reference build's bits, so the Nelder-Mead
+    // trajectory is the reference's to the last digit.  One GPU, no error model; far slower than the matrix cores
+    // (a proof and a debugging aid, not a mode to search in).
+    bool opt_objective_reference = false;
+    std::vector<int32_t> device_rows;   // the uploaded table in tree-leaf order (kept only for that mode)
     struct ReportArith {   // scope guard around the likelihood launches of a report-phase command
         cafehost_session* s;
         explicit ReportArith(cafehost_session* s_) : s(s_)
@@ -438,6 +448,7 @@ struct cafehost_session {
     bool speculation_pays()
     {
         if (exchange || (native_comm && !solo)) return false;   // sharded: every evaluation already ends in an exchange
+        if (opt_objective_reference) return false;
         if (opt_speculate >= 0) return opt_speculate != 0;
         int wg = 0, cu = 0;
         if (cafehip_launch_info(ctx, &wg, &cu) != 0) return false;
@@ -490,9 +501,52 @@ struct cafehost_session {
             int z = -1;
             score = exchange(exchange_user, &z);
             zero = z;
+        } else if (opt_objective_reference) {
+            score = evaluate_reference(nl, nm, pr, zero);
         } else {
             hip_check(cafehip_eval_posterior(ctx, nl.data(), nm.data(), pr.data(), &score, &zero, nullptr, nullptr, nullptr));
             if (zero >= 0) zero += shard_lo;
+        }
+        return score;
+    }
+
+    // get_posterior in the reference's arithmetic and order (option objective_arith=reference, see above)
+    double evaluate_reference(const std::vector<double>& nl, const std::vector<double>& nm, const std::vector<double>& pr, int32_t& zero)
+    {
+        if (err_mfs >= 0) throw std::runtime_error("objective_arith=reference does not cover an error model (the batch entry point scores plain leaves)");
+        if (shard_world > 1) throw std::runtime_error("objective_arith=reference runs on one GPU");
+        const int F = fam.F(), nleaves = tree.n_leaves(), R = range.root_max - range.root_min + 1;
+        if ((int)device_rows.size() != F * nleaves) {
+            device_families_current = false;   // (the option was switched on after the upload)
+            upload();
+        }
+        hip_check(cafehip_set_option(ctx, "k2", "v1ref"));
+        struct Restore {
+            cafehip_ctx* c;
+            ~Restore() { (void)cafehip_set_option(c, "k2", "auto"); }
+        } restore{ctx};
+        reset_cache_exact(nl, nm);
+        double score = 0;
+        zero = -1;
+        const int block = 16384;
+        std::vector<int32_t> lo(block, range.root_min), hi(block, range.root_max), cm(block, range.max);
+        std::vector<double> like((size_t)block * R), posterior(R);
+        for (int f0 = 0; f0 < F; f0 += block) {
+            const int nb = std::min(block, F - f0);
+            hip_check(cafehip_eval_root_likelihoods(ctx, nb, device_rows.data() + (size_t)f0 * nleaves, lo.data(), hi.data(), cm.data(), like.data()));
+            for (int i = 0; i < nb; ++i) {
+                const double* L = like.data() + (size_t)i * R;
+                double max_lik = L[0];                      // __max, libcommon/mathfunc.c
+                for (int j = 1; j < R; ++j)
+                    if (L[j] > max_lik) max_lik = L[j];
+                for (int j = 0; j < R; ++j) posterior[j] = std::exp(std::log(L[j]) + std::log(pr[j]));   // cafe/lambda.cpp:681
+                const double max_post = *std::max_element(posterior.begin(), posterior.end());
+                if (max_lik == 0) {                         // :715-720 (the reference throws at the first such family)
+                    zero = f0 + i;
+                    return score;
+                }
+                score += std::log(max_post);                // :721
+            }
         }
         return score;
     }
@@ -2408,6 +2462,12 @@ int cafehost_set_option(cafehost_session* s, const char* key, const char* value)
     }
     if (k == "timing") {
         s->opt_timing = atoi(v.c_str()) != 0;
+        return 0;
+    }
+    if (k == "objective_arith") {
+        if (v != "reference" && v != "fast" && !v.empty()) return host_fail("option objective_arith: fast | reference, got '" + v + "'");
+        s->opt_objective_reference = v == "reference";
+        s->spec.clear();
         return 0;
     }
     if (k == "report_arith") {

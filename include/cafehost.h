@@ -120,7 +120,10 @@ double cafehost_poisson_lambda(cafehost_session *s);
  * reference's empirical Poisson, cafe/lambda.cpp:808-870; an extension for tables whose root distribution is known),
  * "report_arith" (fast|reference: the likelihood vectors of report / pvalue on the matrix cores, or in the reference's
  * own arithmetic -- exact-form matrices with the host libm's exp() and a separate multiply and add per term -- which
- * returns the oracle's bits, Monte-Carlo null included, at about 2.7x the report time), "prior_lookahead" (0|1: the Poisson
+ * returns the oracle's bits, Monte-Carlo null included, at about 2.7x the report time), "objective_arith" (fast|reference:
+ * the same for every objective evaluation of a search, the posterior and the sum of logs formed on the host in the reference's
+ * order with the host's libm -- the score is the oracle's double; one GPU, no error model, slow: a proof, not a mode),
+ * "prior_lookahead" (0|1: the Poisson
  * fit evaluates Nelder-Mead's candidate points several per sweep, same bits), "lhtest_deal" (0|1: a sharded job deals
  * lhtest's files to the ranks);
  * every other key is handed to cafehip_set_option on the session's device

@@ -103,3 +103,38 @@ def test_null_distribution_of_the_report_in_reference_arithmetic(tmp_path):
     assert outs["reference"][0].shape == want.shape
     assert np.array_equal(outs["reference"][0], want)
     assert outs["reference"][1] == outs["fast"][1]        # and the report text does not move
+
+
+def test_a_whole_search_in_reference_arithmetic_carries_the_oracles_score_bits():
+    # option objective_arith=reference: exact-form matrices, v1ref root vectors, then on the HOST exp(log L + log prior), the
+    # maximum and the sum of logs in family order (cafe/lambda.cpp:657-724 line by line, the host's libm).  Every objective
+    # value of `lambda -s` on the shipped example must then EQUAL the oracle's get_posterior at the same lambda -- the
+    # double, not its printed digits -- so the Nelder-Mead trajectory is the reference's by construction; and the fast
+    # search (matrix cores) must land on the same fitted lambda to the optimiser's tolerance.
+    from cafe_amd.shell import CafeShell
+    if not _host_exp_recognised():
+        pytest.skip("this host's exp() is neither restated form")
+    sp, ids, counts = O.load_family_table(os.path.join(GOLD, "example_data.tab"))
+    t = O.PyTree(NEWICK)
+    counts = O.reorder_to_tree(sp, counts, t)
+    rng = O.range_from_max(int(counts.max()))
+    res = {}
+    for arith in ("reference", "fast"):
+        sh = CafeShell(0, os.devnull)
+        sh.set_option("objective_arith", arith)
+        for line in ("seed 10", "load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"), "tree " + NEWICK, "lambda -s"):
+            sh.dispatch(line)
+        res[arith] = (list(sh.params), sh.score, sh.iterations, sh.trace().copy(), sh.poisson_lambda)
+        sh.close()
+    params, score, iters, trace, lam_p = res["reference"]
+    prior = O.prior_poisson(1000, rng.root_min, lam_p)
+    checked = 0
+    for x, s in trace:
+        if not np.isfinite(s):
+            continue
+        so = O.eval_posterior(t, counts, rng, np.full(t.n_nodes, x), np.full(t.n_nodes, -1.0), prior)[0]
+        assert s == so, (x, s, so)           # bit for bit
+        checked += 1
+    assert checked >= 25
+    assert iters == 29 and abs(params[0] - 0.01075268816939) < 1e-9        # the reference's own run
+    assert res["fast"][2] == iters and abs(res["fast"][0][0] - params[0]) < 1e-9
