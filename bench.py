@@ -282,6 +282,29 @@ class Leg:
         self.samples_in_region = len(self.kernel_ms)
         return dt, last
 
+    def run_announced(self, warmup, steps):
+        """The same steps when the NEXT step's parameter set was announced one evaluation ahead (cafehip_prefetch_matrices),
+        as an optimiser that knows its candidate points does: the matrix build leaves the evaluation's serial chain.
+        Reported beside ms_per_step, never instead of it -- ms_per_step models an optimiser whose next point is known only
+        when the previous score is back."""
+        eng, n = self.eng, len(self.rates)
+        before = eng.matrix_cache_stats()
+
+        def one(i):
+            nxt = self.rates[(i + 1) % n]
+            eng.prefetch_matrices_at(1, nxt[2], nxt[3], eng.PREFETCH_BEHIND_NEXT_EVALUATION)
+            return self.step(i)
+        for s in range(warmup + 2):
+            one(s)
+        self.barrier()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            last = one(warmup + 2 + s)
+        self.barrier()
+        dt = time.perf_counter() - t0
+        after = eng.matrix_cache_stats()
+        return dt, last, {k: after[k] - before[k] for k in ("announced", "built", "hits", "misses", "hits_that_waited", "build_launches")}
+
     def extra_kernel_samples(self, start):
         extra = 0
         while len(self.kernel_ms) < MIN_KERNEL_SAMPLES:
@@ -609,6 +632,10 @@ def main():
             dist.all_gather_object(every, dt)
             per_rank_dt = [float(x) for x in every]
         dt = max(per_rank_dt)
+    # the same steps with every parameter set announced one evaluation ahead (all ranks: the steps contain the exchange)
+    dt_ann, last_ann, ann_stats = leg.run_announced(args.warmup, args.steps)
+    eng.set_option("matrix_cache", "")      # (drops the store: the next evaluation builds its matrices itself)
+    ann_same = leg.step(args.warmup + 2 + args.steps - 1) == last_ann
     if rank == 0 and not multi:
         leg.extra_kernel_samples(args.warmup + args.steps)
 
@@ -645,6 +672,14 @@ def main():
             "last_score": last,
         },
     }
+    out["speculated_hit_ms_per_step"] = 1000.0 * dt_ann / args.steps
+    out["speculated"] = {"what": "the same K steps with step i+1's parameter set announced before step i starts "
+                                 "(cafehip_prefetch_matrices, issued behind step i's launches): its matrices are built on a second "
+                                 "stream beside step i's pruning and step i+1 launches no K1.  What a search gains where the optimiser's "
+                                 "next points can be foreseen (Nelder-Mead's are functions of the simplex); ms_per_step above is the "
+                                 "serial figure and the headline",
+                         "value": wl.F_total * args.steps / dt_ann, "unit": "family-evals/s", "this_rank": ann_stats,
+                         "last_score_equals_an_evaluation_that_builds_its_matrices": bool(ann_same)}
     if rank == 0:
         setup = dict(leg.setup)
         setup["priming_evaluations"] = priming
@@ -904,7 +939,7 @@ def lambda_search_wallclock(wl):
     tree, cfg, rng, counts, newick = wl.tree, wl.cfg, wl.rng, wl.counts, wl.newick
     has_mu = cfg["mu"] >= 0
 
-    def run(rows, label, generator_prior=False):
+    def run(rows, label, generator_prior=False, lookahead=None):
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "families.tab")
             with open(path, "w") as f:
@@ -912,6 +947,8 @@ def lambda_search_wallclock(wl):
                 for i, row in enumerate(rows):
                     f.write("NA\tF%06d\t" % i + "\t".join(str(int(x)) for x in row) + "\n")
             sh = CafeShell(0, os.path.join(d, "log.txt"))
+            if lookahead is not None:
+                sh.set_option("lookahead", lookahead)
             if generator_prior:
                 pf = os.path.join(d, "root_prior.txt")
                 np.savetxt(pf, synth.root_size_distribution(cfg["m"]), fmt="%.17g")   # root_min = 1 (init_family_size)
@@ -936,10 +973,17 @@ def lambda_search_wallclock(wl):
                    "search_s": sh.search_seconds, "prior_fit_and_setup_s": wall - sh.search_seconds,
                    "iterations": sh.iterations, "evaluations": sh.evaluations,
                    "fitted": [float(x) for x in sh.params], "score": sh.score, "poisson_lambda": sh.poisson_lambda,
-                   "simulated_rates": [cfg["lam"]] + ([cfg["mu"]] if has_mu else [])}
+                   "simulated_rates": [cfg["lam"]] + ([cfg["mu"]] if has_mu else []),
+                   "matrices_ahead_of_time": sh.lookahead_stats()}
             sh.close()
         return res
     res = run(counts, "reference-faithful: the table as generated (one forced count == m row pins the ranges)")
+    # the same search with the matrices of the optimiser's possible next points NOT built ahead of time (round 4's loop):
+    # identical trajectory, every evaluation pays its own matrix build
+    plain = run(counts, "the same, host option lookahead=0", lookahead=0)
+    res["search_s_without_lookahead"] = plain["search_s"]
+    res["same_result_without_lookahead"] = (plain["fitted"] == res["fitted"] and plain["score"] == res["score"] and
+                                            plain["evaluations"] == res["evaluations"])
     mle = float((counts[counts > 0] - 1).mean())
     if abs(res["poisson_lambda"] - mle) > 0.05 * mle:
         # The prior fit stalled: poisspdf(count - 1, lambda_p) underflows for counts above ~170 at any start in (0, 1), so the

@@ -34,6 +34,8 @@ SIGNATURES = {
     "cafehip_num_chunks": (C.c_int, [C.c_void_p]),
     "cafehip_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int)]),
     "cafehip_matrix_size": (C.c_int, [C.c_void_p]),
+    "cafehip_prefetch_matrices": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_int]),
+    "cafehip_matrix_cache_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "cafehip_reset_birthdeath_cache": (C.c_int, [C.c_void_p, _dp, _dp]),
     "cafehip_set_exact_matrices": (C.c_int, [C.c_void_p, C.c_int]),
     "cafehip_eval_root_likelihoods": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip, _dp]),
@@ -77,6 +79,7 @@ HOST_SIGNATURES = {
     "cafehost_comm_cleanup": (C.c_int, [C.c_void_p]),
     "cafehost_init_comm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cafehost_speculation_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "cafehost_lookahead_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "cafehost_exchange_stats": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_long)]),
     "cafehost_set_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cafehost_fetch_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_ulong, C.POINTER(C.c_void_p)]),

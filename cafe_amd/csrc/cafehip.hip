@@ -42,19 +42,73 @@ int grant_lds(cafehip_ctx* c, const void* fn, size_t lds, size_t default_limit)
     return 0;
 }
 
+// ---- matrices of sets that may be evaluated next: bookkeeping (context.hpp, MatrixCache) ------------------------------
+void mc_invalidate(cafehip_ctx* c)
+{
+    // (whatever the entries were built for -- tree, ranges, error model, arithmetic form -- has changed, or their slots moved)
+    for (auto& e : c->mc.e) e.valid = false;
+    if (c->mc.bound >= 0) c->have_matrices = false;   // the bound matrices were an entry's
+    c->mc.bound = -1;
+    c->mc.pending_sets = 0;
+    c->cur_node_key = c->d_node_key;
+}
+
+// both streams idle (before storage the speculative builds write is released or moved)
+int sync_streams(cafehip_ctx* c)
+{
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->mc.stream) HIP_TRY(hipStreamSynchronize(c->mc.stream));
+    return 0;
+}
+
+size_t mc_slots(const cafehip_ctx* c) { return c->mc.e.size() * (size_t)c->mc.kpe; }
+
+// d_PT = [demand region: pt_keys_cap slots][cache entries: mc_slots(c) slots], one matrix [KP][LD] per slot
 int ensure_matrix_storage(cafehip_ctx* c, size_t min_keys = 0)
 {
     const size_t need_keys = std::max((size_t)std::max(c->n_nodes, 1), min_keys);
-    if (c->d_PT && c->pt_keys_cap >= need_keys) return 0;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_PT && c->pt_keys_cap >= need_keys && c->mc.slots_allocated == mc_slots(c)) return 0;
+    if (sync_streams(c)) return -1;
+    mc_invalidate(c);
     hipFree(c->d_PT);
     c->d_PT = nullptr;
-    const size_t bytes = need_keys * (size_t)c->KP * c->LD * sizeof(double);
+    const size_t keep = std::max(need_keys, c->pt_keys_cap);
+    const size_t bytes = (keep + mc_slots(c)) * (size_t)c->KP * c->LD * sizeof(double);
     HIP_TRY(hipMalloc(&c->d_PT, bytes));
     // padding rows/cols stay zero forever; ordered on the context's (non-blocking) stream, where K1 will run
     HIP_TRY(hipMemsetAsync(c->d_PT, 0, bytes, c->stream));
-    c->pt_keys_cap = need_keys;
+    if (!c->mc.e.empty()) HIP_TRY(hipStreamSynchronize(c->stream));   // (the speculation stream is not ordered behind that fill)
+    c->pt_keys_cap = keep;
+    c->mc.first_slot = keep;
+    c->mc.slots_allocated = mc_slots(c);
     return 0;
+}
+
+// the error-folded twins live at the same slots of d_PTfold
+int ensure_fold_storage(cafehip_ctx* c)
+{
+    const size_t need = (c->pt_keys_cap + c->mc.slots_allocated) * (size_t)c->KP * c->LD * sizeof(double);
+    if (c->d_PTfold && c->ptfold_cap == need) return 0;
+    if (sync_streams(c)) return -1;
+    for (auto& e : c->mc.e) e.folded = false;
+    hipFree(c->d_PTfold);
+    c->d_PTfold = nullptr;
+    c->ptfold_cap = 0;
+    c->fold_current = false;
+    HIP_TRY(hipMalloc(&c->d_PTfold, need));
+    HIP_TRY(hipMemsetAsync(c->d_PTfold, 0, need, c->stream));  // rows beyond C stay zero
+    if (!c->mc.e.empty()) HIP_TRY(hipStreamSynchronize(c->stream));
+    c->ptfold_cap = need;
+    return 0;
+}
+
+// k1e_fold_error over `nkeys` matrices from slot `first` on: PTfold[slot] = error model folded into PT[slot]
+int launch_fold_slots(cafehip_ctx* c, hipStream_t stream, size_t first, int nkeys)
+{
+    const size_t off = first * (size_t)c->KP * c->LD;
+    dim3 grid((c->LD + 255) / 256, c->C, nkeys);
+    FoldArgs fa{c->d_PT + off, c->d_PTfold + off, c->d_err, c->err_mfs + 1, c->err_banded, c->err_dlo, c->err_dhi, c->C, c->KP, c->LD};
+    return launch_kernel(k1e_fold_kernel(), grid, dim3(256), 0, stream, fa);
 }
 
 // Posterior mode with an error model: fold it into this evaluation's matrices (k1e_fold_error), so that every
@@ -64,20 +118,30 @@ int launch_error_fold(cafehip_ctx* c)
     c->fold_current = false;
     if (!c->d_err || c->nkeys == 0) return 0;
     if (!c->opt.errfold) return 0;
-    const size_t need = c->pt_keys_cap * (size_t)c->KP * c->LD * sizeof(double);
-    if (!c->d_PTfold || c->ptfold_cap < need) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        hipFree(c->d_PTfold);
-        c->d_PTfold = nullptr;
-        c->ptfold_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_PTfold, need));
-        HIP_TRY(hipMemsetAsync(c->d_PTfold, 0, need, c->stream));  // rows beyond C stay zero (same stream as the fold)
-        c->ptfold_cap = need;
-    }
-    dim3 grid((c->LD + 255) / 256, c->C, c->nkeys);
-    FoldArgs fa{c->d_PT, c->d_PTfold, c->d_err, c->err_mfs + 1, c->err_banded, c->err_dlo, c->err_dhi, c->C, c->KP, c->LD};
-    if (launch_kernel(k1e_fold_kernel(), grid, dim3(256), 0, c->stream, fa)) return -1;
+    if (ensure_fold_storage(c)) return -1;
+    if (launch_fold_slots(c, c->stream, 0, c->nkeys)) return -1;
     c->fold_current = true;
+    return 0;
+}
+
+// node -> matrix maps on the device: rows [0, kMaxSets) for the sets of an evaluation built on demand, row kMaxSets + e for
+// cache entry e (written by the K1 launch that builds the entry)
+int ensure_node_key_store(cafehip_ctx* c)
+{
+    const int rows = kMaxSets + (int)c->mc.e.size();
+    if (c->d_node_key && c->node_key_rows == rows) return 0;
+    if (sync_streams(c)) return -1;
+    mc_invalidate(c);
+    hipFree(c->d_node_key);
+    c->d_node_key = nullptr;
+    const size_t bytes = (size_t)rows * c->n_nodes * sizeof(int32_t);
+    HIP_TRY(hipMalloc(&c->d_node_key, bytes));
+    // (ordered on the context's stream, where K1 will write the map: a null-stream memset is not ordered with a
+    // non-blocking stream and could land AFTER the first evaluation's K1)
+    HIP_TRY(hipMemsetAsync(c->d_node_key, 0, bytes, c->stream));
+    if (!c->mc.e.empty()) HIP_TRY(hipStreamSynchronize(c->stream));
+    c->node_key_rows = rows;
+    c->cur_node_key = c->d_node_key;
     return 0;
 }
 
@@ -87,22 +151,39 @@ int ensure_param_ring(cafehip_ctx* c)
     const int key_cap = kMaxSets * std::max(c->n_nodes - 1, 1);
     const size_t bytes = eval_block_bytes(key_cap, c->n_nodes);
     if (c->h_params[0] && bytes <= c->ring_bytes && key_cap == c->key_cap) return 0;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (sync_streams(c)) return -1;
     for (int i = 0; i < kParamRing; ++i) {
         if (c->h_params[i]) hipHostFree(c->h_params[i]);
         c->h_params[i] = nullptr;
         HIP_TRY(hipHostMalloc((void**)&c->h_params[i], bytes, hipHostMallocMapped | hipHostMallocCoherent));
         memset(c->h_params[i], 0, bytes);
     }
-    hipFree(c->d_node_key);
-    c->d_node_key = nullptr;
-    HIP_TRY(hipMalloc(&c->d_node_key, (size_t)kMaxSets * c->n_nodes * sizeof(int32_t)));
-    // (ordered on the context's stream, where K1 will write the map: a null-stream memset is not ordered with a
-    // non-blocking stream and could land AFTER the first evaluation's K1)
-    HIP_TRY(hipMemsetAsync(c->d_node_key, 0, (size_t)kMaxSets * c->n_nodes * sizeof(int32_t), c->stream));
     c->key_cap = key_cap;
     c->ring_bytes = bytes;
-    return 0;
+    hipFree(c->d_node_key);
+    c->d_node_key = nullptr;
+    c->node_key_rows = 0;
+    return ensure_node_key_store(c);
+}
+
+// one (int branch length, lambda, mu) key reduced to the scalars K1 needs; `slot`: where its matrix goes in d_PT
+void fill_key(const cafehip_ctx* c, KeyParam& key, int bl, double lambda, double mu, int slot)
+{
+    const cafehip::KeyScalars ks = cafehip::key_scalars(bl, lambda, mu);
+    key.log_alpha = ks.log_alpha;
+    key.log_beta = ks.log_beta;
+    key.log_coeff = ks.log_coeff;
+    key.coeff = ks.coeff;
+    key.mode = ks.mode;
+    key.bl = bl;
+    key.l2a = ks.l2a;
+    key.l2b = ks.l2b;
+    key.rho_m = ks.rho_m;
+    key.rho_e = ks.rho_e;
+    // 2: the register-blocked kernel may run rho^j in plain doubles over 8-term chunks without leaving
+    // the double range (binomial products * rho^8 stay below 2^1000); 1: per-term mantissa/exponent form
+    key.fast_ok = !ks.fast_ok ? 0 : ((8.0 * std::abs(ks.rho_e) + c->lnc.log2_max_prod + 8.0 < 1000.0) ? 2 : 1);
+    key.slot = slot;
 }
 
 // host part of reset_birthdeath_cache: unique keys over non-root nodes
@@ -145,20 +226,7 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
                 kb.push_back(bl);
                 kl.push_back(nl[i]);
                 km.push_back(nm[i]);
-                const cafehip::KeyScalars ks = cafehip::key_scalars(bl, nl[i], nm[i]);
-                keys[k].log_alpha = ks.log_alpha;
-                keys[k].log_beta = ks.log_beta;
-                keys[k].log_coeff = ks.log_coeff;
-                keys[k].coeff = ks.coeff;
-                keys[k].mode = ks.mode;
-                keys[k].bl = bl;
-                keys[k].l2a = ks.l2a;
-                keys[k].l2b = ks.l2b;
-                keys[k].rho_m = ks.rho_m;
-                keys[k].rho_e = ks.rho_e;
-                // 2: the register-blocked kernel may run rho^j in plain doubles over 8-term chunks without leaving
-                // the double range (binomial products * rho^8 stay below 2^1000); 1: per-term mantissa/exponent form
-                keys[k].fast_ok = !ks.fast_ok ? 0 : ((8.0 * std::abs(ks.rho_e) + c->lnc.log2_max_prod + 8.0 < 1000.0) ? 2 : 1);
+                fill_key(c, keys[k], bl, nl[i], nm[i], k);
                 ++nk;
             }
             if (set == 0) c->node_key[i] = k;
@@ -194,6 +262,8 @@ int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_m
     c->cur_params = h;
     c->cur_slot = slot;
     c->cur_sets = n_sets;
+    c->mc.bound = -1;                   // the pruning launches read the demand region again
+    c->cur_node_key = c->d_node_key;
     return 0;
 }
 
@@ -226,40 +296,54 @@ int host_exp_variant_once()
     return variant;
 }
 
-int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr, bool defer_ring_event = false)
+// One K1 launch: the matrices of the staged block `ep` (nkeys keys, each stored at its own slot of d_PT) on `stream`; block
+// (0,0,0) mirrors the node -> matrix map of set s into row set_row[s] of the device store, resets `first_zero` (or NULL) and
+// mirrors the prior when n_prior > 0.  `all_fast`: every key qualifies for the product forms.
+struct K1Launch {
+    hipStream_t stream;
+    const EvalHeader* ep;
+    int nkeys, n_sets;
+    int set_row[kMaxSets];
+    int32_t* first_zero;
+    int n_prior;
+    bool all_fast;
+};
+
+// the arithmetic form K1 runs for a block of keys (the same for a set built on demand and one built ahead of time)
+bool k1_product_form(const cafehip_ctx* c, bool all_fast) { return c->lnc.product_form_ok && all_fast && !c->force_exact && c->opt.k1 != 1; }
+
+int launch_k1_block(cafehip_ctx* c, const K1Launch& L)
 {
-    if (c->nkeys == 0) return 0;
+    if (L.nkeys == 0) return 0;
     // table rows are staged once per workgroup and reused for keys_per_block keys; keep >= ~3 workgroups
     // per CU in flight.  Measured: more keys per block only lengthens the heavy tiles (tools/sweep_k1.py)
     const int kpb = std::max(1, c->opt.k1_kpb);
     K1Args a;
     memset(&a, 0, sizeof a);
-    a.ep = c->cur_params;   // pinned host block staged by stage_params
+    a.ep = L.ep;   // pinned host block
     a.ld_lnc = c->lnc.ld;
     a.PT = c->d_PT;
     a.M = c->M;
     a.LD = c->LD;
     a.KP = c->KP;
-    a.first_zero = d_first_zero;
+    a.first_zero = L.first_zero;
     a.keys_per_block = kpb;
     a.node_key_dev = c->d_node_key;
+    for (int q = 0; q < kMaxSets; ++q) a.set_row[q] = L.set_row[q];
     a.n_nodes = c->n_nodes;
-    a.n_sets = c->cur_sets;
-    a.nkeys = c->nkeys;
+    a.n_sets = L.n_sets;
+    a.nkeys = L.nkeys;
     a.key_cap = c->key_cap;
-    a.n_prior = c->cur_prior_n;
+    a.n_prior = L.n_prior;
     a.prior_offset = eval_prior_offset(c->key_cap, c->n_nodes);
     a.prior_dev = c->d_prior;
     a.logprior_dev = c->d_logprior;
     a.exp_variant = c->opt.exp_like_host ? host_exp_variant_once() : 0;
-    if (c->cur_prior_n > 0) c->prior_on_device = true;
-    c->cur_prior_n = 0;   // (this launch mirrors it)
-    dim3 grid((c->S + 15) / 16, (c->S + 15) / 16, (c->nkeys + kpb - 1) / kpb);
+    dim3 grid((c->S + 15) / 16, (c->S + 15) / 16, (L.nkeys + kpb - 1) / kpb);
     size_t lds = 2 * 16 * (size_t)c->lnc.ld * sizeof(double);
     const bool use_lds = lds <= 150 * 1024;  // bigger tables are read through L1/L2 instead
     if (!use_lds) lds = 0;
-    const bool product = c->lnc.product_form_ok && c->all_keys_fast && !c->force_exact && c->opt.k1 != 1;
-    c->k1_product_form = product;
+    const bool product = k1_product_form(c, L.all_fast);
     const bool blocked = product && c->opt.k1 != 2;
     const int K1Q = k1_rb_columns();
     const size_t lds_rb = 16 * (size_t)((c->lnc.ld + 8) + (c->lnc.ld + k1_rb_bpad() + 8)) * sizeof(double);
@@ -268,20 +352,314 @@ int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr, bool defer_ring_e
         if (grant_lds(c, fn, lds_rb, 48 * 1024)) return -1;
         a.tabA = c->d_expA;
         a.tabB = c->d_expB;
-        dim3 grid_rb((c->S + 16 * K1Q - 1) / (16 * K1Q), (c->S + 15) / 16, (c->nkeys + kpb - 1) / kpb);
-        if (launch_kernel(fn, grid_rb, dim3(256), lds_rb, c->stream, a)) return -1;
+        dim3 grid_rb((c->S + 16 * K1Q - 1) / (16 * K1Q), (c->S + 15) / 16, (L.nkeys + kpb - 1) / kpb);
+        if (launch_kernel(fn, grid_rb, dim3(256), lds_rb, L.stream, a)) return -1;
     } else {
-        // product form: every key of this evaluation qualifies and the staged tables are exp(ln C); else the exact form
+        // product form: every key of this block qualifies and the staged tables are exp(ln C); else the exact form
         const void* fn = k1_kernel(use_lds, product);
         if (grant_lds(c, fn, lds, 48 * 1024)) return -1;
         a.tabA = product ? c->d_expA : c->d_lncA;
         a.tabB = product ? c->d_expB : c->d_lncB;
-        if (launch_kernel(fn, grid, dim3(256), lds, c->stream, a)) return -1;
+        if (launch_kernel(fn, grid, dim3(256), lds, L.stream, a)) return -1;
     }
+    return 0;
+}
+
+// K1 of the evaluation staged by stage_params, on the context's stream, into the demand region
+int launch_k1(cafehip_ctx* c, int32_t* d_first_zero = nullptr, bool defer_ring_event = false)
+{
+    if (c->nkeys == 0) return 0;
+    K1Launch L;
+    L.stream = c->stream;
+    L.ep = c->cur_params;
+    L.nkeys = c->nkeys;
+    L.n_sets = c->cur_sets;
+    for (int q = 0; q < kMaxSets; ++q) L.set_row[q] = q;
+    L.first_zero = d_first_zero;
+    L.n_prior = c->cur_prior_n;
+    L.all_fast = c->all_keys_fast;
+    if (c->cur_prior_n > 0) c->prior_on_device = true;
+    c->cur_prior_n = 0;   // (this launch mirrors it)
+    c->k1_product_form = k1_product_form(c, L.all_fast);
+    if (launch_k1_block(c, L)) return -1;
     if (!defer_ring_event) HIP_TRY(hipEventRecord(c->h_params_ev[c->cur_slot], c->stream));
     c->have_matrices = true;
     c->fold_current = false;  // the folded copy (if any) belongs to the previous matrices
     return 0;
+}
+
+// ---- matrices ahead of time (context.hpp, MatrixCache) ----------------------------------------------------------------
+// the low-priority stream of the builds ahead of time (creating a stream takes ~12 ms on this runtime: done with the
+// context, not inside the first search)
+int mc_stream(cafehip_ctx* c)
+{
+    if (c->mc.stream) return 0;
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = the numerically LARGEST value = the lowest priority
+    HIP_TRY(hipStreamCreateWithPriority(&c->mc.stream, hipStreamNonBlocking, lo));
+    return 0;
+}
+
+// lay the entries out: when the tree, the table's ranges or the error model are set (so that the first search finds the
+// store ready), or by the first prefetch after an option changed it.  Returns 1 when the store is off or does not fit.
+int mc_prepare(cafehip_ctx* c)
+{
+    if (c->n_nodes <= 0 || c->M < 0) return 1;
+    auto& mc = c->mc;
+    if (!mc.e.empty()) return 0;
+    if (mc.broken || mc.want_entries <= 0) return 1;
+    mc.kpe = std::max(c->n_nodes - 1, 1);
+    const size_t per_entry = (size_t)mc.kpe * c->KP * c->LD * sizeof(double) * (c->d_err ? 2 : 1);
+    int n = mc.want_entries;
+    while (n > 0 && (size_t)n * per_entry > mc.max_bytes) --n;
+    if (n < 3) {   // (the bound entry + two candidates: fewer is not worth the bookkeeping)
+        mc.broken = true;
+        return 1;
+    }
+    if (mc_stream(c)) return -1;
+    mc.e.assign(n, cafehip_ctx::MatrixCache::Entry());
+    for (auto& e : mc.e) HIP_TRY(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming));
+    mc.bound = -1;
+    if (ensure_matrix_storage(c) || ensure_node_key_store(c)) {
+        for (auto& e : mc.e) hipEventDestroy(e.ready);
+        mc.e.clear();
+        mc.broken = true;
+        if (ensure_matrix_storage(c) || ensure_node_key_store(c)) return -1;
+        return 1;
+    }
+    return 0;
+}
+
+// the entries are dropped (tree or matrix side changed): laid out again by the next prefetch
+int mc_drop(cafehip_ctx* c)
+{
+    auto& mc = c->mc;
+    if (mc.e.empty()) {
+        mc.pending_sets = 0;
+        mc.broken = false;
+        return 0;
+    }
+    if (sync_streams(c)) return -1;
+    mc_invalidate(c);
+    for (auto& e : mc.e) hipEventDestroy(e.ready);
+    mc.e.clear();
+    mc.broken = false;
+    return 0;
+}
+
+bool mc_same_set(const cafehip_ctx* c, const cafehip_ctx::MatrixCache::Entry& e, const double* nl, const double* nm)
+{
+    // the reference's key test on every non-root node: exact-double equality of lambda and mu (cafe/cafe_tree.c:380-382; the
+    // branch lengths are the tree's).  memcmp would tell -0.0 from 0.0 and NaN from itself differently from ==: a NaN rate
+    // simply never hits.
+    for (int i = 0; i < c->n_nodes; ++i) {
+        if (i == c->root) continue;
+        if (!(e.nl[i] == nl[i]) || !(e.nm[i] == nm[i])) return false;
+    }
+    return true;
+}
+
+int mc_find(const cafehip_ctx* c, const double* nl, const double* nm)
+{
+    for (size_t i = 0; i < c->mc.e.size(); ++i)
+        if (c->mc.e[i].valid && mc_same_set(c, c->mc.e[i], nl, nm)) return (int)i;
+    return -1;
+}
+
+// Build the matrices of up to kMaxSets parameter sets into cache entries: ONE K1 launch on the speculation stream (each
+// set's keys deduplicated as an evaluation would, stored at the slots of its entry; the launch's first block writes each
+// set's node -> slot map into the entry's row of the device store), then the error fold of each entry.  Sets that are
+// already there are only touched; a set whose keys do not all take the product form is left to be built on demand (one
+// launch has one arithmetic form, and a set must get the form its own evaluation would use).
+int mc_build(cafehip_ctx* c, int n_sets, const double* node_lambda, const double* node_mu)
+{
+    auto& mc = c->mc;
+    if (n_sets <= 0) return 0;
+    if (c->n_nodes <= 0 || c->M < 0) return 0;
+    {
+        const int rc = mc_prepare(c);
+        if (rc != 0) return rc < 0 ? -1 : 0;
+    }
+    mc.requested += n_sets;
+    const int n = c->n_nodes;
+    std::vector<char> keep(mc.e.size(), 0);
+    if (mc.bound >= 0) keep[mc.bound] = 1;
+    std::vector<int> todo;   // request indices to build
+    for (int q = 0; q < n_sets && q < kMaxSets; ++q) {
+        const double* nl = node_lambda + (size_t)q * n;
+        const double* nm = node_mu + (size_t)q * n;
+        bool usable = true;
+        for (int i = 0; i < n && usable; ++i)
+            if (i != c->root && !(c->bl[i] > 0)) usable = false;   // (an evaluation of this tree fails anyway)
+        if (!usable) continue;
+        const int at = mc_find(c, nl, nm);
+        if (at >= 0) {
+            keep[at] = 1;
+            mc.e[at].tick = ++mc.tick;
+            continue;
+        }
+        bool dup = false;
+        for (int t : todo) {
+            cafehip_ctx::MatrixCache::Entry probe;
+            probe.nl.assign(node_lambda + (size_t)t * n, node_lambda + (size_t)(t + 1) * n);
+            probe.nm.assign(node_mu + (size_t)t * n, node_mu + (size_t)(t + 1) * n);
+            if (mc_same_set(c, probe, nl, nm)) dup = true;
+        }
+        if (!dup) todo.push_back(q);
+    }
+    if (todo.empty()) return 0;
+    // victims: invalid entries first, then the least recently used ones -- never the bound entry or one this request names
+    std::vector<int> victims;
+    for (size_t t = 0; t < todo.size(); ++t) {
+        int best = -1;
+        for (size_t i = 0; i < mc.e.size(); ++i) {
+            if (keep[i]) continue;
+            if (best < 0 || (!mc.e[i].valid && mc.e[best].valid) || (mc.e[i].valid == mc.e[best].valid && mc.e[i].tick < mc.e[best].tick)) best = (int)i;
+        }
+        if (best < 0) break;
+        keep[best] = 1;
+        victims.push_back(best);
+    }
+    todo.resize(victims.size());
+    if (todo.empty()) return 0;
+    const bool fold = c->d_err && c->opt.errfold;
+    if (fold && ensure_fold_storage(c)) return -1;
+
+    const int slot = c->ring_pos;
+    c->ring_pos = (c->ring_pos + 1) % kParamRing;
+    HIP_TRY(hipEventSynchronize(c->h_params_ev[slot]));
+    EvalHeader* h = c->h_params[slot];
+    KeyParam* keys = eval_keys(h);
+    int32_t* node_key = eval_node_key(h, c->key_cap);
+    K1Launch L;
+    L.stream = mc.stream;
+    L.ep = h;
+    L.first_zero = nullptr;
+    L.n_prior = 0;
+    L.all_fast = true;
+    for (int q = 0; q < kMaxSets; ++q) L.set_row[q] = 0;
+    int nk = 0, sets = 0;
+    std::vector<int> built_entries, built_nkeys;
+    for (size_t t = 0; t < todo.size(); ++t) {
+        const double* nl = node_lambda + (size_t)todo[t] * n;
+        const double* nm = node_mu + (size_t)todo[t] * n;
+        auto& e = mc.e[victims[t]];
+        if (e.valid) ++mc.evicted;
+        e.valid = false;
+        const int base = (int)(mc.first_slot + (size_t)victims[t] * mc.kpe);
+        const int nk0 = nk;
+        e.node_key.assign(n, -1);
+        bool all_fast = true;
+        auto& kl = c->stage_l;   // this set's distinct (lambda, mu) by key, the branch length in the key itself
+        auto& km = c->stage_m;
+        kl.clear();
+        km.clear();
+        for (int i = 0; i < n; ++i) {
+            node_key[(size_t)sets * n + i] = 0;
+            if (i == c->root) continue;
+            const int bl = c->bl_int[i];
+            int k = nk0;
+            for (; k < nk; ++k)
+                if (keys[k].bl == bl && kl[k - nk0] == nl[i] && km[k - nk0] == nm[i]) break;
+            if (k == nk) {
+                fill_key(c, keys[k], bl, nl[i], nm[i], base + (k - nk0));
+                kl.push_back(nl[i]);
+                km.push_back(nm[i]);
+                if (keys[k].mode >= 2 && !keys[k].fast_ok) all_fast = false;
+                ++nk;
+            }
+            e.node_key[i] = base + (k - nk0);
+            node_key[(size_t)sets * n + i] = base + (k - nk0);
+        }
+        if (k1_product_form(c, all_fast) != k1_product_form(c, true)) {
+            nk = nk0;   // this set's own evaluation would run another arithmetic form than the launch: built on demand
+            continue;
+        }
+        e.nl.assign(nl, nl + n);
+        e.nm.assign(nm, nm + n);
+        e.nkeys = nk - nk0;
+        e.folded = false;
+        e.ready_known = false;
+        L.set_row[sets] = kMaxSets + victims[t];
+        built_entries.push_back(victims[t]);
+        built_nkeys.push_back(nk - nk0);
+        ++sets;
+    }
+    h->nkeys = nk;
+    h->n_sets = sets;
+    h->n_nodes = n;
+    h->key_cap = c->key_cap;
+    if (sets == 0) return 0;
+    L.nkeys = nk;
+    L.n_sets = sets;
+    if (launch_k1_block(c, L)) return -1;
+    HIP_TRY(hipEventRecord(c->h_params_ev[slot], mc.stream));
+    ++mc.launches;
+    for (size_t t = 0; t < built_entries.size(); ++t) {
+        auto& e = mc.e[built_entries[t]];
+        if (fold) {
+            if (launch_fold_slots(c, mc.stream, mc.first_slot + (size_t)built_entries[t] * mc.kpe, built_nkeys[t])) return -1;
+            e.folded = true;
+        }
+        HIP_TRY(hipEventRecord(e.ready, mc.stream));
+        e.valid = true;
+        e.tick = ++mc.tick;
+        ++mc.built;
+    }
+    return 0;
+}
+
+// a request parked by cafehip_prefetch_matrices(..., CAFEHIP_PREFETCH_BEHIND_NEXT_EVALUATION): issued once the evaluation's
+// own launches are in the queue, so that they are not delayed by the host work of staging the candidates
+int mc_issue_pending(cafehip_ctx* c)
+{
+    auto& mc = c->mc;
+    if (mc.pending_sets <= 0) return 0;
+    const int n = mc.pending_sets;
+    mc.pending_sets = 0;
+    return mc_build(c, n, mc.pending_l.data(), mc.pending_m.data());
+}
+
+// An evaluation of (node_lambda, node_mu) whose matrices are in the cache: bind the nodes to them instead of building.
+// Returns the entry or -1.
+int mc_bind(cafehip_ctx* c, const double* node_lambda, const double* node_mu, const double* prior)
+{
+    auto& mc = c->mc;
+    if (mc.e.empty()) return -1;
+    // what K1 would have done besides the matrices must already hold: the prior on the device is this one, the
+    // first-zero word is reset (the score kernels leave it so)
+    if (!c->fz_clean || !c->prior_on_device || !prior || (int)c->prior_seen.size() != c->R ||
+        memcmp(c->prior_seen.data(), prior, sizeof(double) * c->R) != 0) {
+        return -1;
+    }
+    const int at = mc_find(c, node_lambda, node_mu);
+    if (at < 0) {
+        ++mc.misses;
+        return -1;
+    }
+    auto& e = mc.e[at];
+    if (c->d_err && c->opt.errfold && !e.folded) return -1;
+    if (!e.ready_known) {
+        const hipError_t q = hipEventQuery(e.ready);
+        if (q == hipSuccess) {
+            e.ready_known = true;
+        } else if (q == hipErrorNotReady) {
+            if (hipStreamWaitEvent(c->stream, e.ready, 0) != hipSuccess) return -1;   // the build is still running: the pruning waits for it
+            ++mc.waited;
+        } else {
+            return -1;
+        }
+    }
+    ++mc.hits;
+    e.tick = ++mc.tick;
+    mc.bound = at;
+    c->cur_node_key = c->d_node_key + (size_t)(kMaxSets + at) * c->n_nodes;
+    c->node_key = e.node_key;
+    c->nkeys = e.nkeys;
+    c->cur_sets = 1;
+    c->have_matrices = true;
+    c->fold_current = e.folded;
+    return at;
 }
 
 constexpr size_t kV1LdsLarge = 150 * 1024;   // node-vector slots of the row-per-thread kernel (one workgroup per CU)
@@ -627,7 +1005,7 @@ int launch_compressed_levels(cafehip_ctx* c, int n_sets)
     memset(&a, 0, sizeof a);
     a.PT = c->d_PT;
     a.PTfold = (c->d_err && c->fold_current) ? c->d_PTfold : nullptr;
-    a.node_key = c->d_node_key;
+    a.node_key = c->cur_node_key;
     a.n_nodes = c->n_nodes;
     a.leaf_has_err32 = c->d_leaf_has_err32;
     a.tables = p.d_tables;
@@ -1184,7 +1562,7 @@ void fill_common_k2(cafehip_ctx* c, K2Args& a)
 {
     memset(&a, 0, sizeof a);
     a.PT = c->d_PT;
-    a.node_key = c->d_node_key;
+    a.node_key = c->cur_node_key;
     a.n_nodes = c->n_nodes;
     a.prior = c->d_prior;
     a.logprior = c->d_logprior;
@@ -1251,12 +1629,20 @@ int cafehip_impl::eval_device(cafehip_ctx* c, const double* node_lambda, const d
     if (n_sets > 1 && d_chunk_sums == nullptr) {
         d_chunk_sums = c->d_chunk_sums;   // (re)allocated above
     }
-    if (stage_params(c, node_lambda, node_mu, prior, n_sets)) return -1;
+    // the matrices of this set may already be on the device (cafehip_prefetch_matrices): then the nodes are bound to them
+    // and the chain starts at the pruning -- no staging, no K1, no fold.  Only for the calls whose score kernel leaves the
+    // first-zero word reset (the synchronous and the direct-exchange paths), one set at a time.
+    const bool may_bind = n_sets == 1 && (host_out || direct_exchange) && d_first_zero == c->d_first_zero && !c->mc.e.empty();
+    const bool bound = may_bind && mc_bind(c, node_lambda, node_mu, prior) >= 0;
+    if (!bound && stage_params(c, node_lambda, node_mu, prior, n_sets)) return -1;
     RingGuard ring(c);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    ring.arm();   // from here on the slot's event is recorded on every way out
-    if (launch_k1(c, d_first_zero, true)) return -1;
-    if (launch_error_fold(c)) return -1;
+    if (!bound) {
+        ring.arm();   // from here on the slot's event is recorded on every way out
+        if (launch_k1(c, d_first_zero, true)) return -1;
+        if (launch_error_fold(c)) return -1;
+    }
+    c->fz_clean = false;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     K2Args a;
     fill_common_k2(c, a);
@@ -1321,6 +1707,7 @@ int cafehip_impl::eval_device(cafehip_ctx* c, const double* node_lambda, const d
         if (launch_kernel(k3x_kernel(), dim3(std::max(c->n_chunks, 1)), dim3(CAFEHIP_CHUNK), 0, c->stream, x)) return -1;
         c->x_seq = x.xseq;   // the launch went out: only now is the number taken
         c->x_last = x;
+        c->fz_clean = d_first_zero == c->d_first_zero;   // (its last block reads the word with an exchange)
     } else if (c->n_chunks > 0) {
         K3Args k3{c->d_max_post, c->d_max_lik, c->F == c->Fu ? nullptr : c->d_fam2u, c->F, c->Fu, d_chunk_sums, d_first_zero, nullptr, nullptr, 0};
         if (host_out) {
@@ -1329,8 +1716,11 @@ int cafehip_impl::eval_device(cafehip_ctx* c, const double* node_lambda, const d
             k3.seq = ++c->host_seq;
         }
         if (launch_kernel(k3_kernel(host_out), dim3(c->n_chunks, n_sets), dim3(CAFEHIP_CHUNK), 0, c->stream, k3)) return -1;
+        c->fz_clean = host_out && d_first_zero == c->d_first_zero;
     }
-    if (ring.record_now()) return -1;   // (deferred from launch_k1)
+    if (!bound && ring.record_now()) return -1;   // (deferred from launch_k1)
+    // candidates announced for the NEXT evaluation: their matrices are built now, beside this evaluation's pruning
+    if (mc_issue_pending(c)) return -1;
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         c->timing_pending = true;
@@ -1365,7 +1755,8 @@ namespace {
 // environment ONCE, when the context is created (tools/ sweeps), never during an evaluation
 const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
                                     "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch",
-                                    "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "exp_like_host", "comm"};
+                                    "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "exp_like_host", "matrix_cache",
+                                    "matrix_cache_mb", "comm"};
 
 int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
 {
@@ -1415,6 +1806,15 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     else if (key == "walk_lockstep") o.walk_lockstep = iv != 0;
     else if (key == "batch_lockstep_slack") o.batch_lockstep_slack = std::min(std::max(iv, 0), 100);
     else if (key == "exp_like_host") o.exp_like_host = iv != 0;
+    else if (key == "matrix_cache" || key == "matrix_cache_mb") {
+        // entries of the matrices-ahead-of-time store (0: cafehip_prefetch_matrices is ignored) / its size limit
+        HIP_TRY(hipSetDevice(c->device));
+        if (mc_drop(c)) return -1;
+        if (key == "matrix_cache") c->mc.want_entries = val.empty() ? 12 : std::min(std::max(iv, 0), 64);
+        else c->mc.max_bytes = (size_t)std::max(iv, 0) << 20;
+        if (c->M >= 0 && c->n_nodes > 0 && (ensure_matrix_storage(c) || ensure_node_key_store(c))) return -1;
+        return 0;
+    }
     else if (key == "comm") {
         if (val == "rccl") c->comm_mode = 1;
         else if (val == "direct") c->comm_mode = 2;
@@ -1424,6 +1824,7 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     }
     else return fail("unknown option '%s'", key.c_str());
     c->tune.n_items = -1;   // the wave grid is measured again under the new switches
+    mc_invalidate(c);       // ... and matrices built ahead of time may have been built under the old ones
     if (replan && c->M >= 0 && c->n_nodes > 0) {
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1492,6 +1893,7 @@ int cafehip_create(cafehip_ctx** out, int device_id)
     HIP_TRY(hipMalloc(&c->d_logprior, kMaxPrior * sizeof(double)));
     for (int i = 0; i < kParamRing; ++i) HIP_TRY(hipEventCreateWithFlags(&c->h_params_ev[i], hipEventDisableTiming));
     options_from_environment(c);
+    if (c->mc.want_entries > 0 && mc_stream(c)) return -1;
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
     HIP_TRY(hipMalloc(&c->d_first_zero, kMaxSets * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&c->d_arrive, sizeof(int32_t)));
@@ -1505,7 +1907,9 @@ void cafehip_destroy(cafehip_ctx* c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    (void)sync_streams(c);
+    for (auto& e : c->mc.e) hipEventDestroy(e.ready);
+    if (c->mc.stream) hipStreamDestroy(c->mc.stream);
     free_family_buffers(c);
     free_compression(c);
     delete c->link;
@@ -1646,7 +2050,9 @@ int cafehip_set_tree(cafehip_ctx* c, int n_nodes, const int32_t* parent, const i
         HIP_TRY(hipMemcpy(c->d_vit_slot, vslot.data(), n_nodes * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     c->have_matrices = false;
+    if (mc_drop(c)) return -1;   // (entries are sized by the tree)
     if (ensure_param_ring(c)) return -1;
+    if (c->M >= 0 && mc_prepare(c) < 0) return -1;
     if (c->M >= 0 && ensure_matrix_storage(c)) return -1;
     if (c->M >= 0 && rebuild_compression(c)) return -1;
     return 0;
@@ -1785,6 +2191,7 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
     }
     lap("table + output buffers");
     if (new_M) {
+        if (mc_drop(c)) return -1;   // (entries are sized by the matrix side; their builds read the tables released below)
         c->lnc.build(M);
         lap("ln C tables (host)");
         hipFree(c->d_lncA);
@@ -1804,9 +2211,12 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
         hipFree(c->d_PT);
         c->d_PT = nullptr;
         c->pt_keys_cap = 0;
+        c->mc.slots_allocated = 0;
         c->have_matrices = false;
     }
+    mc_invalidate(c);   // (a new table keeps the ranges' matrices valid in principle; the host driver starts a new search anyway)
     lap("ln C upload");
+    if (c->n_nodes > 0 && mc_prepare(c) < 0) return -1;
     if (c->n_nodes > 0 && ensure_matrix_storage(c)) return -1;
     lap("matrix storage");
     c->setup_ms[2] = ms_since(t_setup1);
@@ -1832,6 +2242,7 @@ int cafehip_set_error_model(cafehip_ctx* c, int mfs, const double* errormatrix,
     c->tune.n_items = -1;  // a new problem: measure the wave grids again
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (mc_drop(c)) return -1;   // (matrices built ahead of time carry the old model's fold, or none)
     hipFree(c->d_err);
     hipFree(c->d_leaf_has_err);
     hipFree(c->d_leaf_has_err32);
@@ -1840,7 +2251,7 @@ int cafehip_set_error_model(cafehip_ctx* c, int mfs, const double* errormatrix,
     c->d_leaf_has_err32 = nullptr;
     c->err_mfs = -1;
     c->h_leaf_has_err.clear();
-    if (!errormatrix) return upload_col_has_err(c);
+    if (!errormatrix) return upload_col_has_err(c) ? -1 : (mc_prepare(c) < 0 ? -1 : 0);
     if (c->n_nodes <= 0) return fail("set the tree before the error model");
     if (mfs < 0) return fail("bad error-model size %d", mfs);
     const size_t n = (size_t)(mfs + 1) * (mfs + 1);
@@ -1872,7 +2283,8 @@ int cafehip_set_error_model(cafehip_ctx* c, int mfs, const double* errormatrix,
     }
     c->h_leaf_has_err = by_col;
     c->err_mfs = mfs;
-    return upload_col_has_err(c);
+    if (upload_col_has_err(c)) return -1;
+    return mc_prepare(c) < 0 ? -1 : 0;   // (the entries again, with room for the folded twins)
 }
 
 int cafehip_num_chunks(cafehip_ctx* c) { return c ? c->n_chunks : fail("null context"); }
@@ -1999,6 +2411,7 @@ int cafehip_eval_clustered_posterior(cafehip_ctx* c, int K, const double* node_l
     HIP_TRY(hipSetDevice(c->device));
     if (ensure_output_sets(c, std::max(K, 2))) return -1;
     if (stage_params(c, node_lambda, node_mu, prior, K)) return -1;
+    c->fz_clean = false;   // (k3_cluster_score leaves the first-zero word as it found it)
     if (launch_k1(c, c->d_first_zero)) return -1;
     if (launch_error_fold(c)) return -1;
     K2Args a;
@@ -2077,6 +2490,40 @@ int cafehip_last_issued_flops(cafehip_ctx* c, double* walk, double* tables)
     return 0;
 }
 
+int cafehip_prefetch_matrices(cafehip_ctx* c, int n_sets, const double* node_lambda, const double* node_mu, int when)
+{
+    if (check_ready(c)) return -1;
+    if (n_sets < 0 || n_sets > kMaxSets) return fail("0..%d parameter sets per prefetch, got %d", kMaxSets, n_sets);
+    if (n_sets > 0 && (!node_lambda || !node_mu)) return fail("null argument");
+    if (when != CAFEHIP_PREFETCH_NOW && when != CAFEHIP_PREFETCH_BEHIND_NEXT_EVALUATION) return fail("prefetch: unknown `when` %d", when);
+    auto& mc = c->mc;
+    if (mc.want_entries <= 0 || mc.broken) return 0;   // a hint: ignored when the store is off
+    HIP_TRY(hipSetDevice(c->device));
+    if (when == CAFEHIP_PREFETCH_BEHIND_NEXT_EVALUATION) {
+        mc.pending_sets = n_sets;   // (replaces an earlier request that no evaluation picked up)
+        mc.pending_l.assign(node_lambda, node_lambda + (size_t)n_sets * c->n_nodes);
+        mc.pending_m.assign(node_mu, node_mu + (size_t)n_sets * c->n_nodes);
+        return 0;
+    }
+    mc.pending_sets = 0;
+    return mc_build(c, n_sets, node_lambda, node_mu);
+}
+
+int cafehip_matrix_cache_stats(cafehip_ctx* c, long out[CAFEHIP_MATRIX_CACHE_STATS])
+{
+    if (!c || !out) return fail("null argument");
+    const auto& mc = c->mc;
+    out[0] = mc.requested;
+    out[1] = mc.built;
+    out[2] = mc.hits;
+    out[3] = mc.misses;
+    out[4] = mc.evicted;
+    out[5] = mc.waited;
+    out[6] = mc.launches;
+    out[7] = (long)mc.e.size();
+    return 0;
+}
+
 int cafehip_reset_birthdeath_cache(cafehip_ctx* c, const double* node_lambda, const double* node_mu)
 {
     if (check_ready(c)) return -1;
@@ -2091,6 +2538,7 @@ int cafehip_reset_birthdeath_cache(cafehip_ctx* c, const double* node_lambda, co
 int cafehip_set_exact_matrices(cafehip_ctx* c, int on)
 {
     if (!c) return fail("null context");
+    if (c->force_exact != (on != 0)) mc_invalidate(c);   // (matrices built ahead of time carry the other form)
     c->force_exact = on != 0;
     return 0;
 }
@@ -2263,7 +2711,7 @@ int cafehip_viterbi(cafehip_ctx* c, int B, const int32_t* counts, const int32_t*
     K4Args a;
     memset(&a, 0, sizeof a);
     a.PT = c->d_PT;
-    a.node_key = c->d_node_key;
+    a.node_key = c->cur_node_key;
     a.ops = c->d_ops;
     a.n_ops = (int)c->sched.ops.size();
     a.counts = d_cnt;

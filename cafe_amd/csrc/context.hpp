@@ -214,7 +214,7 @@ struct cafehip_ctx {
     double* d_PTfold = nullptr;  // error model folded into the matrices (posterior mode), same shape as d_PT
     size_t ptfold_cap = 0;
     bool fold_current = false;
-    size_t pt_keys_cap = 0;
+    size_t pt_keys_cap = 0;      // slots of the demand region [0, pt_keys_cap); the cache entries' slots follow (mc.first_slot)
 
     // per-evaluation parameters (ring of pinned staging buffers)
     EvalHeader* h_params[kParamRing] = {};   // pinned, device-mapped; sized by the tree (eval_block_bytes)
@@ -233,6 +233,43 @@ struct cafehip_ctx {
     std::vector<double> prior_seen, logprior_seen;   // the last prior staged and its logarithms
     int nkeys = 0;
     bool have_matrices = false;
+
+    // ---- matrices of parameter sets that MAY be evaluated next (round 5: cafehip_prefetch_matrices) ------------------
+    // The optimiser knows the handful of points it can ask for next before the score of the current one is back
+    // (libcommon/fminsearch.cpp:198-237 are functions of the simplex).  Their matrices are built on a second, low-priority
+    // stream while the current evaluation runs, into slots of d_PT behind the demand region, each set keyed exactly as the
+    // reference keys its cache -- (int branch length, lambda, mu) per node with the doubles compared bit for bit
+    // (libtree/birthdeath.h:26-31, cafe/cafe_tree.c:374-391) -- and an evaluation that finds its set there binds the nodes
+    // to those matrices and launches no K1: the matrix build leaves the evaluation's serial chain.  Same kernel, same
+    // per-key arithmetic as a build on demand: the matrices, and every value downstream, are bit-identical.
+    struct MatrixCache {
+        struct Entry {
+            bool valid = false;
+            std::vector<double> nl, nm;   // the set as handed over, non-root nodes compared exactly
+            std::vector<int> node_key;    // node -> ABSOLUTE matrix slot (host copy; the device copy is row kMaxSets + e of d_node_key)
+            int nkeys = 0;
+            bool folded = false;          // d_PTfold holds the error-folded twins of its matrices
+            bool ready_known = false;     // its build has been seen complete (no stream wait needed any more)
+            hipEvent_t ready = nullptr;   // recorded on the speculation stream behind its build
+            unsigned long tick = 0;       // last use (least recently used entry is replaced)
+        };
+        int want_entries = 12;            // option matrix_cache=<entries> (0: off)
+        size_t max_bytes = (size_t)1 << 30;
+        bool broken = false;              // the entries did not fit max_bytes / an allocation failed: prefetches are ignored
+        std::vector<Entry> e;             // empty until the first prefetch
+        int kpe = 0;                      // slots per entry: the matrices one set can need (n_nodes - 1)
+        size_t first_slot = 0;            // of entry 0 in d_PT / d_PTfold
+        size_t slots_allocated = 0;       // cache slots the current d_PT allocation holds
+        int bound = -1;                   // entry the pruning launches read now; -1: the demand region
+        unsigned long tick = 0;
+        hipStream_t stream = nullptr;
+        int pending_sets = 0;             // request parked until the next evaluation's launches have gone out
+        std::vector<double> pending_l, pending_m;
+        long requested = 0, built = 0, hits = 0, misses = 0, evicted = 0, waited = 0, launches = 0;
+    } mc;
+    const int32_t* cur_node_key = nullptr;   // the node -> matrix map the pruning launches read (d_node_key, or a cache entry's row of it)
+    int node_key_rows = 0;                   // rows of d_node_key: kMaxSets demand rows + one per cache entry
+    bool fz_clean = false;                   // d_first_zero was left at INT32_MAX by the last score kernel (k3_score<true> / k3_score_x)
 
     // error model
     double* d_err = nullptr;

@@ -26,6 +26,7 @@ struct KeyParam {
     int fast_ok;
     int mode;  // host_math.hpp KeyScalars
     int bl;
+    int slot;  // where K1 stores this matrix: PT[slot][KP][LD] (round 5: the device holds more than one evaluation's matrices)
 };
 
 // Per-evaluation parameter block in PINNED, device-mapped host memory (a ring of kParamRing): K1 reads its keys
@@ -63,7 +64,8 @@ struct K1Args {
     int M, LD, KP;
     int32_t* first_zero;         // reset to INT32_MAX per set (the score kernel atomicMin's into it), or NULL
     int keys_per_block;
-    int32_t* node_key_dev;       // mirror target [n_sets][n_nodes], or NULL
+    int32_t* node_key_dev;       // the device's node -> matrix store [rows][n_nodes], or NULL: set s is mirrored into row set_row[s]
+    int set_row[kMaxSets];
     int n_nodes, n_sets, nkeys, key_cap;
     // the prior changed: block (0,0,0) also mirrors prior[n_prior] and logprior[n_prior] (n_prior = 0 otherwise)
     int n_prior;

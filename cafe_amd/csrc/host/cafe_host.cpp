@@ -484,6 +484,46 @@ struct cafehost_session {
         for (int q = 0; q < n_sets; ++q) spec.push_back(SpecEntry{*use[q], scores[q], zeros[q] >= 0 ? zeros[q] + shard_lo : -1});
     }
 
+    // ---- matrices ahead of time (round 5) ------------------------------------------------------------------------------
+    // Where whole evaluations are not batched (a table that fills the chip), the points the optimiser may ask for AFTER the
+    // evaluation it is about to start (FMinSearch::lookahead) are handed to the library, which builds their transition
+    // matrices on a second stream beside that evaluation's pruning (cafehip_prefetch_matrices): the evaluation that then
+    // asks for one of them starts at the pruning.  Values, call order and log lines are those of the plain loop.
+    int opt_lookahead = -1;      // cafehost_set_option "lookahead": -1 auto, 0 off, 1 on
+    long look_calls = 0, look_points = 0;
+    bool lookahead_pays()
+    {
+        if (exchange || opt_objective_reference) return false;   // (the callback path evaluates asynchronously: it builds on demand)
+        if (opt_lookahead >= 0) return opt_lookahead != 0;
+        return true;
+    }
+    void lookahead_points(const std::vector<std::vector<double>>& pts)
+    {
+        if (pts.empty() || !lookahead_pays() || speculation_pays()) return;
+        std::vector<const std::vector<double>*> use;
+        const int ncheck = has_mu ? num_params : num_lambdas;
+        for (auto& x : pts) {
+            bool ok = true;
+            for (int i = 0; i < ncheck; ++i) ok = ok && !(x[i] < 0);   // objective() never evaluates these
+            for (auto* y : use) ok = ok && (*y != x);
+            if (ok && (int)use.size() < CAFEHIP_MAX_SETS) use.push_back(&x);
+        }
+        if (use.empty()) return;
+        const int n_sets = (int)use.size();
+        look_l.resize((size_t)n_sets * tree.n);
+        look_m.resize((size_t)n_sets * tree.n);
+        for (int q = 0; q < n_sets; ++q) {
+            node_rates(use[q]->data(), look_one_l, look_one_m);
+            std::copy(look_one_l.begin(), look_one_l.end(), look_l.begin() + (size_t)q * tree.n);
+            std::copy(look_one_m.begin(), look_one_m.end(), look_m.begin() + (size_t)q * tree.n);
+        }
+        // parked until the next evaluation's own launches are out
+        if (cafehip_prefetch_matrices(ctx, n_sets, look_l.data(), look_m.data(), CAFEHIP_PREFETCH_BEHIND_NEXT_EVALUATION) != 0) return;
+        ++look_calls;
+        look_points += n_sets;
+    }
+    std::vector<double> look_l, look_m, look_one_l, look_one_m;
+
     // reset_birthdeath_cache + get_posterior over the WHOLE table (cafe/cafe_main.c:319-326, cafe/lambda.cpp:691-724):
     // on one GPU one synchronous call; sharded, this rank's partial sums stay on the device and the exchange (native
     // RCCL or the caller's callback) produces the global score.  zero = global index of the first zero-likelihood
@@ -621,6 +661,7 @@ struct cafehost_session {
             pfm.tolf = 1e-6;
             pfm.eq = [&](const double* x) { return objective(x); };
             pfm.prefetch = [&](const std::vector<std::vector<double>>& pts) { prefetch_points(pts); };
+            pfm.lookahead = [&](const std::vector<std::vector<double>>& pts) { lookahead_points(pts); };
             std::vector<double> start = params;
             pfm.minimize(start.data());
             params = pfm.v[0];
@@ -2444,6 +2485,7 @@ int cafehost_create(cafehost_session** out, int device_id, const char* log_path)
     }
     // read once, here: nothing consults the environment during a command
     if (const char* e = getenv("CAFEHOST_SPECULATE")) s->opt_speculate = atoi(e) != 0;
+    if (const char* e = getenv("CAFEHOST_LOOKAHEAD")) s->opt_lookahead = atoi(e) != 0;
     if (getenv("CAFEHOST_TIMING")) s->opt_timing = true;
     if (const char* e = getenv("CAFEHOST_LHTEST_DEAL")) s->opt_lhtest_deal = atoi(e);
     if (const char* e = getenv("CAFEHOST_PRIOR_LOOKAHEAD")) s->opt_prior_lookahead = atoi(e);
@@ -2458,6 +2500,10 @@ int cafehost_set_option(cafehost_session* s, const char* key, const char* value)
     const std::string k = key, v = value ? value : "";
     if (k == "speculate") {
         s->opt_speculate = (v.empty() || v == "auto") ? -1 : (atoi(v.c_str()) != 0);
+        return 0;
+    }
+    if (k == "lookahead") {
+        s->opt_lookahead = (v.empty() || v == "auto") ? -1 : (atoi(v.c_str()) != 0);
         return 0;
     }
     if (k == "timing") {
@@ -2653,6 +2699,18 @@ int cafehost_speculation_stats(cafehost_session* s, long* launches, long* points
     if (launches) *launches = s->spec_launches;
     if (points) *points = s->spec_points;
     if (hits) *hits = s->spec_hits;
+    return 0;
+}
+
+int cafehost_lookahead_stats(cafehost_session* s, long out[4])
+{
+    if (!s || !out) return host_fail("null argument");
+    long mc[CAFEHIP_MATRIX_CACHE_STATS] = {};
+    if (cafehip_matrix_cache_stats(s->ctx, mc) != 0) return host_fail(std::string("cafehip: ") + cafehip_last_error());
+    out[0] = s->look_calls;
+    out[1] = s->look_points;
+    out[2] = mc[2];   // evaluations that found their matrices on the device
+    out[3] = mc[1];   // parameter sets whose matrices were built ahead of time
     return 0;
 }
 

@@ -24,6 +24,13 @@ struct FMinSearch {
     // evaluate them in one batched device pass.  eq() is still called in the reference's order with the reference's
     // accept rules; the hook only changes where the values come from.
     std::function<void(const std::vector<std::vector<double>>&)> prefetch;
+    // Optional (round 5): told, just BEFORE a call of eq(), which points the call AFTER it may ask for, whatever value the
+    // pending one returns -- the expansion / contraction point of the reflection being evaluated, the reflection of every
+    // simplex the pending decision can leave behind, the vertices of a shrink.  They are built with the statements of
+    // minimize() itself (candidates(), shrink()), so they are bit-identical to what is asked for later.  The owner can
+    // have the transition matrices of those points built while eq() runs (cafehip_prefetch_matrices): the optimiser's
+    // decisions, its call order and every value stay those of the plain loop.
+    std::function<void(const std::vector<std::vector<double>>&)> lookahead;
 
     void init(int n)
     {
@@ -109,8 +116,61 @@ struct FMinSearch {
         for (int i = 1; i < N1; ++i)
             for (int j = 0; j < N; ++j) v[i][j] = v[0][j] + sigma * (v[i][j] - v[0][j]);
         if (prefetch) prefetch(std::vector<std::vector<double>>(v.begin() + 1, v.end()));
-        for (int i = 1; i < N1; ++i) fv[i] = eq(v[i].data());
+        for (int i = 1; i < N1; ++i) {
+            if (lookahead && i == N) announce_after_last_vertex();
+            fv[i] = eq(v[i].data());
+        }
         sort();
+    }
+
+    // ---- look-ahead (see `lookahead` above) ----------------------------------------------------------------------
+    // the sorted simplex with its worst vertex dropped and p at position k (0 = new best ... N = new worst)
+    std::vector<std::vector<double>> with_vertex(const std::vector<double>& p, int k) const
+    {
+        std::vector<std::vector<double>> sv;
+        sv.reserve(N1);
+        for (int j = 0; j < N; ++j) {
+            if (j == k) sv.push_back(p);
+            sv.push_back(v[j]);
+        }
+        if (k >= N) sv.push_back(p);
+        return sv;
+    }
+    // reflections of the simplexes that accepting p can produce: p lands at position k when its value falls between the
+    // k-th and the (k+1)-th of the vertices that stay (a position between two EQUAL values needs a tie: not announced)
+    void reflections_if_accepted(const std::vector<double>& p, int k_first, std::vector<std::vector<double>>& out) const
+    {
+        for (int k = k_first; k <= N; ++k) {
+            if (k > 0 && !(fv[k - 1] < fv[k])) continue;
+            out.push_back(candidates(with_vertex(p, k))[0]);
+        }
+    }
+    void shrink_vertices(std::vector<std::vector<double>>& out) const
+    {
+        for (int i = 1; i < N1; ++i) {
+            std::vector<double> q(N);
+            for (int j = 0; j < N; ++j) q[j] = v[0][j] + sigma * (v[i][j] - v[0][j]);
+            out.push_back(q);
+        }
+    }
+    // before a contraction point is evaluated: it is accepted somewhere in the order, or the simplex shrinks
+    void announce_after_contraction(const std::vector<double>& p)
+    {
+        std::vector<std::vector<double>> pts;
+        reflections_if_accepted(p, 0, pts);
+        shrink_vertices(pts);
+        lookahead(pts);
+    }
+    // before the LAST vertex of the initial simplex or of a shrink is evaluated: what follows is the reflection of the
+    // sorted simplex, whose order depends on the value to come.  With one parameter there are two orders; with more the
+    // orders multiply and nothing is announced.
+    void announce_after_last_vertex()
+    {
+        if (N != 1) return;
+        std::vector<std::vector<double>> pts;
+        pts.push_back(candidates({v[0], v[1]})[0]);
+        pts.push_back(candidates({v[1], v[0]})[0]);
+        lookahead(pts);
     }
 
     // The four points an iteration may evaluate for the SORTED simplex `sv` (reflection, expansion, inside and outside
@@ -151,6 +211,15 @@ struct FMinSearch {
                 else
                     v[i][j] = X0[j];
             }
+            if (lookahead && i == 0) {
+                // the other vertices of the initial simplex (as they come out when no vertex evaluates to infinity)
+                std::vector<std::vector<double>> pts(N, std::vector<double>(N));
+                for (int q = 1; q < N1; ++q)
+                    for (int j = 0; j < N; ++j) pts[q - 1][j] = ((q - 1) == j) ? (X0[j] ? (1 + delta) * X0[j] : zero_delta) : X0[j];
+                lookahead(pts);
+            } else if (lookahead && i == N) {
+                announce_after_last_vertex();
+            }
             fv[i] = eq(v[i].data());
         }
         sort();
@@ -176,20 +245,40 @@ struct FMinSearch {
             // the reference's accept rules (libcommon/fminsearch.cpp:203-237), one decision per outcome of the reflection:
             // better than the best -> try the expansion; no better than the worst -> contract (inside when strictly
             // worse, outside on a tie) or shrink; anything in between -> take the reflection
+            if (lookahead) {
+                // after the reflection: the expansion (better than the best), the inside contraction (worse than the worst),
+                // or -- the reflection accepted -- the next iteration's reflection (the outside contraction needs a tie)
+                std::vector<std::vector<double>> pts(2, std::vector<double>(N));
+                for (int a = 0; a < N; ++a) {
+                    pts[0][a] = x_mean[a] + chi * (x_r[a] - x_mean[a]);
+                    pts[1][a] = x_mean[a] + psi * (x_mean[a] - v[N][a]);
+                }
+                reflections_if_accepted(x_r, 1, pts);
+                lookahead(pts);
+            }
             const double f_reflect = eq(x_r.data());
             const double f_best = fv[0], f_worst = fv[N];
             if (f_reflect < f_best) {
                 for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + chi * (x_r[a] - x_mean[a]);
+                if (lookahead) {
+                    // whichever of the two is kept becomes the new best vertex
+                    std::vector<std::vector<double>> pts;
+                    pts.push_back(candidates(with_vertex(x_tmp, 0))[0]);
+                    pts.push_back(candidates(with_vertex(x_r, 0))[0]);
+                    lookahead(pts);
+                }
                 const double f_expand = eq(x_tmp.data());
                 if (f_expand < f_reflect) set_last(x_tmp, f_expand);
                 else set_last(x_r, f_reflect);
             } else if (f_reflect > f_worst) {
                 for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + psi * (x_mean[a] - v[N][a]);
+                if (lookahead) announce_after_contraction(x_tmp);
                 const double f_inside = eq(x_tmp.data());
                 if (f_inside < f_worst) set_last(x_tmp, f_inside);
                 else shrink();
             } else if (f_reflect >= f_worst) {   // == the worst (a NaN fails both tests above and this one: next branch)
                 for (int a = 0; a < N; ++a) x_tmp[a] = x_mean[a] + psi * (x_r[a] - x_mean[a]);
+                if (lookahead) announce_after_contraction(x_tmp);
                 const double f_outside = eq(x_tmp.data());
                 if (f_outside <= f_reflect) set_last(x_tmp, f_outside);
                 else shrink();

@@ -15,7 +15,10 @@ __device__ __forceinline__ void k1_mirror_node_keys(const K1Args& a)
     if (blockIdx.x != 0 || blockIdx.y != 0 || blockIdx.z != 0) return;
     if (a.node_key_dev) {
         const int32_t* __restrict__ src = eval_node_key(a.ep, a.key_cap);
-        for (int i = threadIdx.x; i < a.n_sets * a.n_nodes; i += 256) a.node_key_dev[i] = src[i];
+        for (int i = threadIdx.x; i < a.n_sets * a.n_nodes; i += 256) {
+            const int set = i / a.n_nodes;
+            a.node_key_dev[(size_t)a.set_row[set] * a.n_nodes + (i - set * a.n_nodes)] = src[i];
+        }
     }
     if (a.first_zero && (int)threadIdx.x < a.n_sets) a.first_zero[threadIdx.x] = INT32_MAX;
     if (a.n_prior > 0) {
@@ -52,7 +55,7 @@ template <bool USE_LDS, bool PRODUCT_FORM>
 __global__ __launch_bounds__(256) void k1_build_matrices(K1Args ka)
 {
     const int exp_variant = ka.exp_variant;
-    // `ep` is this evaluation's parameter block in PINNED HOST memory (read over the fabric: one 56-byte
+    // `ep` is this evaluation's parameter block in PINNED HOST memory (read over the fabric: one 80-byte
     // KeyParam per workgroup); block (0,0,0) mirrors the node -> key map into device memory for the later
     // launches, so an evaluation needs no separate host-to-device copy.
     const EvalHeader* __restrict__ ep = ka.ep;
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void k1_build_matrices(K1Args ka)
             }
             p = fmax(fmin(p, 1.0), 0.0);  // MAX(MIN(p,1),0)
         }
-        PT[(size_t)key * KP * LD + (size_t)c * LD + s] = p;
+        PT[(size_t)kp.slot * KP * LD + (size_t)c * LD + s] = p;
     }
 }
 
@@ -191,7 +194,7 @@ constexpr int K1_BPAD = 24;  // zeros in front of every staged B row (window ind
 
 __global__ __launch_bounds__(256) void k1_build_matrices_rb(K1Args ka)
 {
-    // `ep` is this evaluation's parameter block in PINNED HOST memory (read over the fabric: one 56-byte
+    // `ep` is this evaluation's parameter block in PINNED HOST memory (read over the fabric: one 80-byte
     // KeyParam per workgroup); block (0,0,0) mirrors the node -> key map into device memory for the later
     // launches, so an evaluation needs no separate host-to-device copy.
     const EvalHeader* __restrict__ ep = ka.ep;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256) void k1_build_matrices_rb(K1Args ka)
         }
 #pragma unroll
         for (int q = 0; q < K1Q; ++q)
-            if (cb + q <= M) PT[(size_t)key * KP * LD + (size_t)(cb + q) * LD + s] = p[q];
+            if (cb + q <= M) PT[(size_t)kp.slot * KP * LD + (size_t)(cb + q) * LD + s] = p[q];
     }
 }
 #pragma clang fp contract(fast)

@@ -236,9 +236,11 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(K3Args a)
     if (s_last && threadIdx.x == 0) {
         __threadfence();
         // (every other block's chunk sum was fenced system-wide before it counted itself in)
-        const int32_t fz0 = atomicMin(first_zero, INT32_MAX);   // atomic read of the final value
+        // atomic read of the final value, which also leaves the word as the NEXT evaluation needs it (INT32_MAX): an
+        // evaluation whose matrices are already on the device (cafehip_prefetch_matrices) has no K1 launch to reset it
+        const int32_t fz0 = atomicExch(first_zero, INT32_MAX);
         if (gridDim.y > 1) {
-            for (int q = 1; q < (int)gridDim.y; ++q) host->first_zero[q] = atomicMin(first_zero + q, INT32_MAX);
+            for (int q = 1; q < (int)gridDim.y; ++q) host->first_zero[q] = atomicExch(first_zero + q, INT32_MAX);
             __threadfence_system();
         }
         *arrive = 0;
@@ -271,7 +273,7 @@ __device__ __forceinline__ unsigned long long x_load_flag(const unsigned long lo
 __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score_x(K3xArgs a)
 {
     __shared__ double red[CAFEHIP_CHUNK];
-    __shared__ int s_last, s_fail;
+    __shared__ int s_last, s_fail, s_fz;
     const int i = blockIdx.x * CAFEHIP_CHUNK + threadIdx.x;
     double v = 0.0;
     if (i < a.F) {
@@ -296,8 +298,12 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score_x(K3xArgs a)
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    if (threadIdx.x == 0) s_fail = 0;
-    const long long fz = atomicMin(a.first_zero, INT32_MAX);   // atomic read of the final value
+    if (threadIdx.x == 0) {
+        s_fail = 0;
+        s_fz = atomicExch(a.first_zero, INT32_MAX);   // atomic read of the final value; the word is left reset for the next evaluation
+    }
+    __syncthreads();
+    const long long fz = s_fz;
     if ((int)threadIdx.x < a.world) {
         a.rows[threadIdx.x][row + a.slots] = __longlong_as_double(fz);
         __threadfence_system();

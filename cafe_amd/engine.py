@@ -165,6 +165,31 @@ class Engine:
         _lib.check(fast(self._h, addr_lambda, addr_mu, addr_prior, self._score_ref, self._fz_ref, None, None, None))
         return self._score.value, self._fz.value
 
+    # ---- matrices ahead of time (cafehip_prefetch_matrices) ------------------------------------------------------
+    PREFETCH_NOW, PREFETCH_BEHIND_NEXT_EVALUATION = 0, 1
+
+    def prefetch_matrices(self, node_lambdas, node_mus, when=0):
+        """Announce parameter sets ([n_sets, n_nodes] or [n_nodes]) that may be evaluated next: their matrices are built on
+        a second stream and a later get_posterior of one of them launches no matrix build (same bits)."""
+        nl = np.atleast_2d(np.ascontiguousarray(node_lambdas, np.float64))
+        nm = np.atleast_2d(np.ascontiguousarray(node_mus, np.float64))
+        assert nl.shape == nm.shape and nl.shape[1] == self.n_nodes
+        _lib.check(self._L.cafehip_prefetch_matrices(self._h, nl.shape[0], _d(nl), _d(nm), int(when)))
+
+    def prefetch_matrices_at(self, n_sets, addr_lambda, addr_mu, when=1):
+        """The same on raw addresses (address_of), one foreign call."""
+        f = getattr(self, "_fast_pf", None)
+        if f is None:
+            vp = C.c_void_p
+            f = self._fast_pf = C.CFUNCTYPE(C.c_int, vp, C.c_int, vp, vp, C.c_int)(("cafehip_prefetch_matrices", self._L))
+        _lib.check(f(self._h, n_sets, addr_lambda, addr_mu, when))
+
+    def matrix_cache_stats(self):
+        out = (C.c_long * 8)()
+        _lib.check(self._L.cafehip_matrix_cache_stats(self._h, out))
+        keys = ("announced", "built", "hits", "misses", "replaced", "hits_that_waited", "build_launches", "entries")
+        return dict(zip(keys, [int(v) for v in out]))
+
     def _bind_fast_sharded(self):
         vp = C.c_void_p
         self._fast_sh = C.CFUNCTYPE(C.c_int, vp, vp, vp, vp, vp, vp)(("cafehip_eval_posterior_sharded", self._L))

@@ -63,6 +63,12 @@ class CafeShell:
         self._check(self._L.cafehost_speculation_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def lookahead_stats(self):
+        """dict: announcements, points announced, evaluations that found their matrices on the device, sets built ahead."""
+        out = (C.c_long * 4)()
+        self._check(self._L.cafehost_lookahead_stats(self._h, out))
+        return dict(zip(("announcements", "points", "hits", "built"), [int(x) for x in out]))
+
     def exchange_stats(self):
         sec, calls = C.c_double(), C.c_long()
         self._check(self._L.cafehost_exchange_stats(self._h, C.byref(sec), C.byref(calls)))

@@ -77,6 +77,8 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *   walk_lockstep   0|1        the same pacing for the family walk of an objective evaluation (0: measured slower)
  *   exp_like_host   0|1        exact-form matrices call exp() as THIS HOST's libm computes it, restated for the device, when
  *                              one of its two builds matches std::exp at first use (1); 0: the device library's exp
+ *   matrix_cache    n          entries of the store of matrices built ahead of time (cafehip_prefetch_matrices; 12, 0: off)
+ *   matrix_cache_mb n          ... and its size limit in MiB (1024)
  *   comm            auto|direct|rccl   exchange mode of sharded evaluations (multi-GPU section below)
  * The same names, upper-cased behind CAFEHIP_ (CAFEHIP_COMPRESS=0 ...), are read from the environment ONCE, by
  * cafehip_create; nothing reads the environment during an evaluation.  Options that change the compression plan
@@ -191,6 +193,30 @@ int cafehip_num_chunks(cafehip_ctx *ctx);
 int cafehip_get_matrix(cafehip_ctx *ctx, int node, double *out, int *S_out);
 /* Side of the matrices of this context (M+1, M = max(range_max, root_max)). */
 int cafehip_matrix_size(cafehip_ctx *ctx);
+
+/* Matrices ahead of time (round 5).  An optimiser knows the few points it may ask for next BEFORE the score of the current
+ * one is back -- the reflection, expansion and contraction points of a Nelder-Mead step are functions of the simplex
+ * (libcommon/fminsearch.cpp:198-237) -- and the matrix build of an evaluation (compute_birthdeath_rates for every key of
+ * cafe_tree_set_birthdeath, cafe/cafe_tree.c:461-483) depends on nothing else.  This call hands the library up to
+ * CAFEHIP_MAX_SETS candidate parameter sets (set s = node_lambda/node_mu + s * n_nodes, as for cafehip_eval_posterior).
+ * Their matrices are built on a second, low-priority stream into a device store keyed like the reference's cache:
+ * (int branch length, lambda, mu) per node, the doubles compared exactly (libtree/birthdeath.h:26-31,
+ * cafe/cafe_tree.c:380-382).  A later cafehip_eval_posterior / cafehip_eval_posterior_sharded of one of the sets binds the
+ * nodes to those matrices and launches no matrix build: the evaluation's serial chain starts at the pruning.  The same
+ * kernel builds them with the same per-key arithmetic, so every value of such an evaluation is bit-identical to one that
+ * builds on demand; a set that was not announced, or was replaced meanwhile (least recently used of `matrix_cache`
+ * entries, default 12, at most `matrix_cache_mb` MiB, default 1024), is simply built on demand.  A hint: never an error
+ * to announce points that are not evaluated.
+ * when = CAFEHIP_PREFETCH_NOW: launched before the call returns.
+ * when = CAFEHIP_PREFETCH_BEHIND_NEXT_EVALUATION: kept until the next evaluation's own launches are in the queue, so that
+ *        the host work of staging the candidates does not delay it; replaces an earlier request nobody picked up. */
+#define CAFEHIP_PREFETCH_NOW 0
+#define CAFEHIP_PREFETCH_BEHIND_NEXT_EVALUATION 1
+int cafehip_prefetch_matrices(cafehip_ctx *ctx, int n_sets, const double *node_lambda, const double *node_mu, int when);
+/* out: [0] sets announced, [1] sets built, [2] evaluations that found their matrices, [3] evaluations that looked and did
+ * not, [4] entries replaced, [5] hits that still had to wait for the build, [6] build launches, [7] entries of the store */
+#define CAFEHIP_MATRIX_CACHE_STATS 8
+int cafehip_matrix_cache_stats(cafehip_ctx *ctx, long out[CAFEHIP_MATRIX_CACHE_STATS]);
 
 /* Rebuild the matrices for (node_lambda, node_mu) without scoring
  * (== reset_birthdeath_cache alone, cafe/cafe_main.c:319-326). */

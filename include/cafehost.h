@@ -124,7 +124,8 @@ double cafehost_poisson_lambda(cafehost_session *s);
  * the same for every objective evaluation of a search, the posterior and the sum of logs formed on the host in the reference's
  * order with the host's libm -- the score is the oracle's double; one GPU, no error model, slow: a proof, not a mode),
  * "prior_lookahead" (0|1: the Poisson
- * fit evaluates Nelder-Mead's candidate points several per sweep, same bits), "lhtest_deal" (0|1: a sharded job deals
+ * fit evaluates Nelder-Mead's candidate points several per sweep, same bits), "lookahead" (auto|0|1: matrices of the points a
+ * search may ask for next built ahead of time, cafehost_lookahead_stats), "lhtest_deal" (0|1: a sharded job deals
  * lhtest's files to the ranks);
  * every other key is handed to cafehip_set_option on the session's device
  * context(s) (include/cafehip.h).  CAFEHOST_SPECULATE / CAFEHOST_TIMING in the environment are read once, by
@@ -137,6 +138,15 @@ int cafehost_set_option(cafehost_session *s, const char *key, const char *value)
  * cafehip_eval_posterior_multi; trajectories and log lines are those of the sequential run.
  * Option speculate=0 / 1 forces it off / on. */
 int cafehost_speculation_stats(cafehost_session *s, long *launches, long *points, long *hits);
+
+/* Matrices ahead of time (round 5): where whole evaluations are not batched, the searches announce the points Nelder-Mead
+ * may ask for AFTER the evaluation it is about to start -- the expansion / contraction point of the pending reflection,
+ * the reflection of every simplex the pending decision can leave behind, the vertices of a shrink (all functions of the
+ * simplex, libcommon/fminsearch.cpp:189-250) -- and the library builds their transition matrices beside that evaluation's
+ * pruning (cafehip_prefetch_matrices).  Call order, values, log lines: those of the plain loop.  out = {announcements,
+ * points announced, evaluations that found their matrices on the device, sets built ahead of time}.
+ * Option lookahead=0 / 1 forces it off / on (CAFEHOST_LOOKAHEAD in the environment, read once by cafehost_create). */
+int cafehost_lookahead_stats(cafehost_session *s, long out[4]);
 
 /* Trace of the last command's objective calls: row i = (params[0..num_params), score).
  * Returns the number of rows copied (<= max_rows). */
