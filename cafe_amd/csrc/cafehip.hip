@@ -307,18 +307,27 @@ struct K1Launch {
     int32_t* first_zero;
     int n_prior;
     bool all_fast;
+    int kpb = 0;   // keys per workgroup (0: option k1kpb)
 };
 
 // the arithmetic form K1 runs for a block of keys (the same for a set built on demand and one built ahead of time)
 bool k1_product_form(const cafehip_ctx* c, bool all_fast) { return c->lnc.product_form_ok && all_fast && !c->force_exact && c->opt.k1 != 1; }
 
-int launch_k1_block(cafehip_ctx* c, const K1Launch& L)
+// the kernel, grid and arguments of a K1 launch
+struct K1Plan {
+    const void* fn = nullptr;
+    dim3 grid;
+    size_t lds = 0;
+    bool register_blocked = false;
+    K1Args a;
+};
+
+int plan_k1_block(cafehip_ctx* c, const K1Launch& L, K1Plan& P)
 {
-    if (L.nkeys == 0) return 0;
     // table rows are staged once per workgroup and reused for keys_per_block keys; keep >= ~3 workgroups
     // per CU in flight.  Measured: more keys per block only lengthens the heavy tiles (tools/sweep_k1.py)
-    const int kpb = std::max(1, c->opt.k1_kpb);
-    K1Args a;
+    const int kpb = L.kpb > 0 ? L.kpb : std::max(1, c->opt.k1_kpb);
+    K1Args& a = P.a;
     memset(&a, 0, sizeof a);
     a.ep = L.ep;   // pinned host block
     a.ld_lnc = c->lnc.ld;
@@ -339,7 +348,6 @@ int launch_k1_block(cafehip_ctx* c, const K1Launch& L)
     a.prior_dev = c->d_prior;
     a.logprior_dev = c->d_logprior;
     a.exp_variant = c->opt.exp_like_host ? host_exp_variant_once() : 0;
-    dim3 grid((c->S + 15) / 16, (c->S + 15) / 16, (L.nkeys + kpb - 1) / kpb);
     size_t lds = 2 * 16 * (size_t)c->lnc.ld * sizeof(double);
     const bool use_lds = lds <= 150 * 1024;  // bigger tables are read through L1/L2 instead
     if (!use_lds) lds = 0;
@@ -348,21 +356,30 @@ int launch_k1_block(cafehip_ctx* c, const K1Launch& L)
     const int K1Q = k1_rb_columns();
     const size_t lds_rb = 16 * (size_t)((c->lnc.ld + 8) + (c->lnc.ld + k1_rb_bpad() + 8)) * sizeof(double);
     if (blocked && lds_rb <= 150 * 1024) {
-        const void* fn = k1_rb_kernel();
-        if (grant_lds(c, fn, lds_rb, 48 * 1024)) return -1;
+        P.fn = k1_rb_kernel();
+        P.register_blocked = true;
+        P.lds = lds_rb;
         a.tabA = c->d_expA;
         a.tabB = c->d_expB;
-        dim3 grid_rb((c->S + 16 * K1Q - 1) / (16 * K1Q), (c->S + 15) / 16, (L.nkeys + kpb - 1) / kpb);
-        if (launch_kernel(fn, grid_rb, dim3(256), lds_rb, L.stream, a)) return -1;
+        P.grid = dim3((c->S + 16 * K1Q - 1) / (16 * K1Q), (c->S + 15) / 16, (L.nkeys + kpb - 1) / kpb);
     } else {
         // product form: every key of this block qualifies and the staged tables are exp(ln C); else the exact form
-        const void* fn = k1_kernel(use_lds, product);
-        if (grant_lds(c, fn, lds, 48 * 1024)) return -1;
+        P.fn = k1_kernel(use_lds, product);
+        P.lds = lds;
         a.tabA = product ? c->d_expA : c->d_lncA;
         a.tabB = product ? c->d_expB : c->d_lncB;
-        if (launch_kernel(fn, grid, dim3(256), lds, L.stream, a)) return -1;
+        P.grid = dim3((c->S + 15) / 16, (c->S + 15) / 16, (L.nkeys + kpb - 1) / kpb);
     }
     return 0;
+}
+
+int launch_k1_block(cafehip_ctx* c, const K1Launch& L)
+{
+    if (L.nkeys == 0) return 0;
+    K1Plan P;
+    if (plan_k1_block(c, L, P)) return -1;
+    if (grant_lds(c, P.fn, P.lds, 48 * 1024)) return -1;
+    return launch_kernel(P.fn, P.grid, dim3(256), P.lds, L.stream, P.a);
 }
 
 // K1 of the evaluation staged by stage_params, on the context's stream, into the demand region
@@ -471,8 +488,18 @@ int mc_find(const cafehip_ctx* c, const double* nl, const double* nm)
 // set's node -> slot map into the entry's row of the device store), then the error fold of each entry.  Sets that are
 // already there are only touched; a set whose keys do not all take the product form is left to be built on demand (one
 // launch has one arithmetic form, and a set must get the form its own evaluation would use).
-int mc_build(cafehip_ctx* c, int n_sets, const double* node_lambda, const double* node_mu)
+struct McStaged {
+    bool any = false;     // something to launch
+    K1Launch L;           // (its stream is chosen by the launcher)
+    int ring_slot = 0;
+    bool fold = false;
+    std::vector<int> entries, nkeys;
+};
+
+// host part: pick the entries, stage the keys and the node -> slot maps into a pinned block
+int mc_stage(cafehip_ctx* c, int n_sets, const double* node_lambda, const double* node_mu, McStaged& st)
 {
+    st.any = false;
     auto& mc = c->mc;
     if (n_sets <= 0) return 0;
     if (c->n_nodes <= 0 || c->M < 0) return 0;
@@ -531,15 +558,18 @@ int mc_build(cafehip_ctx* c, int n_sets, const double* node_lambda, const double
     EvalHeader* h = c->h_params[slot];
     KeyParam* keys = eval_keys(h);
     int32_t* node_key = eval_node_key(h, c->key_cap);
-    K1Launch L;
-    L.stream = mc.stream;
+    K1Launch& L = st.L;
+    L.stream = nullptr;
     L.ep = h;
     L.first_zero = nullptr;
     L.n_prior = 0;
     L.all_fast = true;
     for (int q = 0; q < kMaxSets; ++q) L.set_row[q] = 0;
     int nk = 0, sets = 0;
-    std::vector<int> built_entries, built_nkeys;
+    auto& built_entries = st.entries;
+    auto& built_nkeys = st.nkeys;
+    built_entries.clear();
+    built_nkeys.clear();
     for (size_t t = 0; t < todo.size(); ++t) {
         const double* nl = node_lambda + (size_t)todo[t] * n;
         const double* nm = node_mu + (size_t)todo[t] * n;
@@ -592,21 +622,55 @@ int mc_build(cafehip_ctx* c, int n_sets, const double* node_lambda, const double
     if (sets == 0) return 0;
     L.nkeys = nk;
     L.n_sets = sets;
-    if (launch_k1_block(c, L)) return -1;
-    HIP_TRY(hipEventRecord(c->h_params_ev[slot], mc.stream));
+    st.ring_slot = slot;
+    st.fold = fold;
+    st.any = true;
+    return 0;
+}
+
+// behind the launch that builds the staged sets on `stream`: the ring slot's event, the error folds, the entries' state.
+// same_stream_as_readers: every launch that will read the entries is queued on `stream` too (no event needed).
+int mc_finish(cafehip_ctx* c, McStaged& st, hipStream_t stream, bool same_stream_as_readers)
+{
+    auto& mc = c->mc;
+    HIP_TRY(hipEventRecord(c->h_params_ev[st.ring_slot], stream));
     ++mc.launches;
-    for (size_t t = 0; t < built_entries.size(); ++t) {
-        auto& e = mc.e[built_entries[t]];
-        if (fold) {
-            if (launch_fold_slots(c, mc.stream, mc.first_slot + (size_t)built_entries[t] * mc.kpe, built_nkeys[t])) return -1;
+    for (size_t t = 0; t < st.entries.size(); ++t) {
+        auto& e = mc.e[st.entries[t]];
+        if (st.fold) {
+            if (launch_fold_slots(c, stream, mc.first_slot + (size_t)st.entries[t] * mc.kpe, st.nkeys[t])) return -1;
             e.folded = true;
         }
-        HIP_TRY(hipEventRecord(e.ready, mc.stream));
+        if (same_stream_as_readers && stream == c->stream) e.ready_known = true;
+        else HIP_TRY(hipEventRecord(e.ready, stream));
         e.valid = true;
         e.tick = ++mc.tick;
         ++mc.built;
     }
+    st.any = false;
     return 0;
+}
+
+// stage + one K1 launch + finish.  Where the build runs (option prefetch_where): 0 = on the second, low-priority stream at
+// once -- beside the pruning of the evaluation just launched; 1 = on the context's own stream, i.e. behind whatever is
+// queued there; 2 = on the second stream but not before the context's stream has drained to this point
+int mc_build(cafehip_ctx* c, int n_sets, const double* node_lambda, const double* node_mu)
+{
+    auto& mc = c->mc;
+    McStaged st;
+    if (mc_stage(c, n_sets, node_lambda, node_mu, st)) return -1;
+    if (!st.any) return 0;
+    const int where = c->opt.prefetch_where;
+    hipStream_t build_stream = (where == 1 || where == 3) ? c->stream : mc.stream;
+    if (where == 2) {
+        if (!mc.chain_end) HIP_TRY(hipEventCreateWithFlags(&mc.chain_end, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(mc.chain_end, c->stream));
+        HIP_TRY(hipStreamWaitEvent(mc.stream, mc.chain_end, 0));
+    }
+    st.L.stream = build_stream;
+    st.L.kpb = build_stream == mc.stream ? c->opt.prefetch_kpb : 0;
+    if (launch_k1_block(c, st.L)) return -1;
+    return mc_finish(c, st, build_stream, build_stream == c->stream);
 }
 
 // a request parked by cafehip_prefetch_matrices(..., CAFEHIP_PREFETCH_BEHIND_NEXT_EVALUATION): issued once the evaluation's
@@ -1715,8 +1779,40 @@ int cafehip_impl::eval_device(cafehip_ctx* c, const double* node_lambda, const d
             k3.arrive = c->d_arrive;
             k3.seq = ++c->host_seq;
         }
-        if (launch_kernel(k3_kernel(host_out), dim3(c->n_chunks, n_sets), dim3(CAFEHIP_CHUNK), 0, c->stream, k3)) return -1;
+        // Candidates announced for the NEXT evaluation (cafehip_prefetch_matrices, parked): their matrices are built by the
+        // trailing blocks of the score kernel's own launch (k3_score_then_k1_rb), i.e. while the score travels to the host
+        // and the optimiser decides -- the chip is idle then, and the next chain queues behind this launch anyway.  Staging
+        // them first costs the host a few microseconds the device spends in the walk.
+        McStaged st;
+        if (c->opt.prefetch_where == 3 && c->mc.pending_sets > 0 && host_out && n_sets == 1) {
+            const int n = c->mc.pending_sets;
+            c->mc.pending_sets = 0;
+            if (mc_stage(c, n, c->mc.pending_l.data(), c->mc.pending_m.data(), st)) return -1;
+        }
+        bool fused = false;
+        if (st.any) {
+            K1Plan P;
+            st.L.stream = c->stream;
+            if (plan_k1_block(c, st.L, P)) return -1;
+            if (P.register_blocked) {
+                K3K1Args f;
+                f.k3 = k3;
+                f.k1 = P.a;
+                f.k3_blocks = c->n_chunks;
+                f.gx = (int)P.grid.x;
+                f.gy = (int)P.grid.y;
+                const void* fn = k3_then_k1_rb_kernel();
+                if (grant_lds(c, fn, P.lds, 48 * 1024)) return -1;
+                if (launch_kernel(fn, dim3(c->n_chunks + P.grid.x * P.grid.y * P.grid.z), dim3(CAFEHIP_CHUNK), P.lds, c->stream, f)) return -1;
+                fused = true;
+            }
+        }
+        if (!fused && launch_kernel(k3_kernel(host_out), dim3(c->n_chunks, n_sets), dim3(CAFEHIP_CHUNK), 0, c->stream, k3)) return -1;
         c->fz_clean = host_out && d_first_zero == c->d_first_zero;
+        if (st.any) {
+            if (!fused && launch_k1_block(c, st.L)) return -1;   // (another arithmetic form: its own launch behind the score kernel)
+            if (mc_finish(c, st, c->stream, true)) return -1;
+        }
     }
     if (!bound && ring.record_now()) return -1;   // (deferred from launch_k1)
     // candidates announced for the NEXT evaluation: their matrices are built now, beside this evaluation's pruning
@@ -1756,7 +1852,7 @@ namespace {
 const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
                                     "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch",
                                     "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "exp_like_host", "matrix_cache",
-                                    "matrix_cache_mb", "comm"};
+                                    "matrix_cache_mb", "prefetch_where", "prefetch_kpb", "comm"};
 
 int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
 {
@@ -1806,6 +1902,8 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     else if (key == "walk_lockstep") o.walk_lockstep = iv != 0;
     else if (key == "batch_lockstep_slack") o.batch_lockstep_slack = std::min(std::max(iv, 0), 100);
     else if (key == "exp_like_host") o.exp_like_host = iv != 0;
+    else if (key == "prefetch_kpb") o.prefetch_kpb = std::max(iv, 0);
+    else if (key == "prefetch_where") o.prefetch_where = std::min(std::max(iv, 0), 3);
     else if (key == "matrix_cache" || key == "matrix_cache_mb") {
         // entries of the matrices-ahead-of-time store (0: cafehip_prefetch_matrices is ignored) / its size limit
         HIP_TRY(hipSetDevice(c->device));
@@ -1909,6 +2007,7 @@ void cafehip_destroy(cafehip_ctx* c)
     hipSetDevice(c->device);
     (void)sync_streams(c);
     for (auto& e : c->mc.e) hipEventDestroy(e.ready);
+    if (c->mc.chain_end) hipEventDestroy(c->mc.chain_end);
     if (c->mc.stream) hipStreamDestroy(c->mc.stream);
     free_family_buffers(c);
     free_compression(c);

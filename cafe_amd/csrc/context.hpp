@@ -172,6 +172,8 @@ struct cafehip_ctx {
         int walk_lockstep = 0;        // the same pacing for the family walk of an objective evaluation
         int batch_lockstep_slack = 0; // ... a generation starts when all but this percentage of the previous ones have finished
         int exp_like_host = 1;        // K1 exact form: exp() as this host's libm computes it, when recognised (exp_like_host.hpp)
+        int prefetch_kpb = 0;         // ... keys per workgroup of a build on the second stream (0: as k1kpb)
+        int prefetch_where = 3;       // matrices ahead of time, parked requests: 3 trailing blocks of the score kernel's launch, 0 second stream at once, 1 the context's stream (behind the score kernel), 2 second stream behind the score kernel
     } opt;
     bool walk_compressed = false;           // the MFMA launcher walks the reduced tree (set around one launch)
     bool last_compressed = false;           // ... and the last objective evaluation did
@@ -263,6 +265,7 @@ struct cafehip_ctx {
         int bound = -1;                   // entry the pruning launches read now; -1: the demand region
         unsigned long tick = 0;
         hipStream_t stream = nullptr;
+        hipEvent_t chain_end = nullptr;   // prefetch_where=2: recorded on the context's stream behind the score kernel
         int pending_sets = 0;             // request parked until the next evaluation's launches have gone out
         std::vector<double> pending_l, pending_m;
         long requested = 0, built = 0, hits = 0, misses = 0, evicted = 0, waited = 0, launches = 0;

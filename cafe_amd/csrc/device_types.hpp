@@ -206,6 +206,14 @@ struct K3Args {
     int32_t seq;
 };
 
+// k3_score<true> and k1_build_matrices_rb in ONE launch (k1_matrices.hip): blocks [0, k3_blocks) score, the rest build the
+// (gx, gy, gz) grid of matrix tiles of the next candidates
+struct K3K1Args {
+    K3Args k3;
+    K1Args k1;
+    int k3_blocks, gx, gy;
+};
+
 // Score kernel of a SHARDED evaluation with the direct exchange (comm.hpp): every block stores its chunk sum into
 // EVERY rank's exchange buffer (row of this rank), the last block adds the first-zero index, raises this rank's flag
 // in every buffer, waits for the other ranks' flags in its own and hands all rows to the host.

@@ -3,6 +3,7 @@
 // into those matrices (posterior path), cafe/cafe_tree.c:196-203.  gfx950 only.
 #include "exp_like_host.hpp"
 #include "kernels.hpp"
+#include "k3_device.hpp"
 
 namespace {
 using namespace cafehip;
@@ -10,9 +11,9 @@ using namespace cafehip;
 // Block (0,0,0) of the first launch of an evaluation mirrors the node -> matrix map from the pinned host block into
 // device memory (the pruning launches index their matrices through it) and resets the first-zero-family slots the
 // score kernel will atomicMin into.  n_sets / n_nodes come as arguments: ONE round trip to host memory, not a chain.
-__device__ __forceinline__ void k1_mirror_node_keys(const K1Args& a)
+__device__ __forceinline__ void k1_mirror_node_keys(const K1Args& a, const bool first_block)
 {
-    if (blockIdx.x != 0 || blockIdx.y != 0 || blockIdx.z != 0) return;
+    if (!first_block) return;
     if (a.node_key_dev) {
         const int32_t* __restrict__ src = eval_node_key(a.ep, a.key_cap);
         for (int i = threadIdx.x; i < a.n_sets * a.n_nodes; i += 256) {
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void k1_build_matrices(K1Args ka)
     // issue the (slow, host-memory) read of this block's first key before the table staging so that the
     // two latencies overlap
     const KeyParam kp_first = keys[min((int)blockIdx.z * keys_per_block, nkeys - 1)];
-    k1_mirror_node_keys(ka);
+    k1_mirror_node_keys(ka, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
     const int s0 = blockIdx.y * 16;
     const int c0 = blockIdx.x * 16;
     const int tx = threadIdx.x & 15;  // s within tile
@@ -192,7 +193,9 @@ __global__ __launch_bounds__(256) void k1_build_matrices(K1Args ka)
 constexpr int K1Q = CAFEHIP_K1Q;
 constexpr int K1_BPAD = 24;  // zeros in front of every staged B row (window indices down to -22)
 
-__global__ __launch_bounds__(256) void k1_build_matrices_rb(K1Args ka)
+// (the kernel's body as a function of the block's position, so that it can also run as the trailing blocks of the score
+// kernel's launch: k3_score_then_k1_rb below)
+__device__ __forceinline__ void k1_rb_block(const K1Args& ka, const int bx, const int by, const int bz)
 {
     // `ep` is this evaluation's parameter block in PINNED HOST memory (read over the fabric: one 80-byte
     // KeyParam per workgroup); block (0,0,0) mirrors the node -> key map into device memory for the later
@@ -204,10 +207,10 @@ __global__ __launch_bounds__(256) void k1_build_matrices_rb(K1Args ka)
     const double* __restrict__ expA = ka.tabA;
     const double* __restrict__ expB = ka.tabB;
     extern __shared__ double k1_smem[];
-    const KeyParam kp_first = keys[min((int)blockIdx.z * keys_per_block, nkeys - 1)];
-    k1_mirror_node_keys(ka);
-    const int s0 = blockIdx.y * 16;
-    const int c0 = blockIdx.x * (16 * K1Q);
+    const KeyParam kp_first = keys[min(bz * keys_per_block, nkeys - 1)];
+    k1_mirror_node_keys(ka, bx == 0 && by == 0 && bz == 0);
+    const int s0 = by * 16;
+    const int c0 = bx * (16 * K1Q);
     const int tx = threadIdx.x & 15;   // row within the tile (fast lane index: PT[c][s] stores are 128-byte runs)
     const int tq = threadIdx.x >> 4;   // column group
     const int s = s0 + tx;
@@ -252,9 +255,9 @@ __global__ __launch_bounds__(256) void k1_build_matrices_rb(K1Args ka)
     const double* a = sA + tx * ldA;
     const double* b = sB + tx * ldB + K1_BPAD;
     const int mmax = min(s, min(cb + K1Q - 1, M));
-    const int key_end = min(nkeys, (int)(blockIdx.z + 1) * keys_per_block);
-    for (int key = blockIdx.z * keys_per_block; key < key_end; ++key) {
-        const KeyParam kp = (key == (int)blockIdx.z * keys_per_block) ? kp_first : keys[key];
+    const int key_end = min(nkeys, (bz + 1) * keys_per_block);
+    for (int key = bz * keys_per_block; key < key_end; ++key) {
+        const KeyParam kp = (key == bz * keys_per_block) ? kp_first : keys[key];
         double p[K1Q];
         if (s == 0) {
 #pragma unroll
@@ -338,6 +341,26 @@ __global__ __launch_bounds__(256) void k1_build_matrices_rb(K1Args ka)
             if (cb + q <= M) PT[(size_t)kp.slot * KP * LD + (size_t)(cb + q) * LD + s] = p[q];
     }
 }
+
+__global__ __launch_bounds__(256) void k1_build_matrices_rb(K1Args ka) { k1_rb_block(ka, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// Score kernel and the matrices of the NEXT candidates in one launch (round 5).  Blocks [0, k3_blocks) are k3_score<true>'s
+// (dispatched first: the score reaches the host as early as from its own launch); the blocks behind them build the
+// matrices of the parameter sets the optimiser may ask for next, into cache entries -- in the time the chip otherwise
+// idles: the tail of the score kernel and the host's turn-around (result pick-up, the optimiser's decision, the next
+// launch: ~10-15 us).  The next evaluation's launches queue behind this one on the same stream, so no event, no second
+// queue and no contention with the walk are involved; built on a second stream beside the walk, the same work cost the
+// walk 6 us of its 55 (profiles/r05).
+__global__ __launch_bounds__(256) void k3_score_then_k1_rb(K3K1Args a)
+{
+    if ((int)blockIdx.x < a.k3_blocks) {
+        k3_score_block<true>(a.k3, blockIdx.x, a.k3_blocks, 0, 1);
+        return;
+    }
+    const int lin = (int)blockIdx.x - a.k3_blocks;
+    const int bx = lin % a.gx, t = lin / a.gx;
+    k1_rb_block(a.k1, bx, t % a.gy, t / a.gy);
+}
 #pragma clang fp contract(fast)
 
 // Error model folded into the matrices (posterior mode).  For a leaf with an error model the edge factor of a
@@ -370,6 +393,7 @@ const void* k1_kernel(bool use_lds, bool product_form)
     return product_form ? reinterpret_cast<const void*>(&k1_build_matrices<false, true>) : reinterpret_cast<const void*>(&k1_build_matrices<false, false>);
 }
 const void* k1_rb_kernel() { return reinterpret_cast<const void*>(&k1_build_matrices_rb); }
+const void* k3_then_k1_rb_kernel() { return reinterpret_cast<const void*>(&k3_score_then_k1_rb); }
 int k1_rb_columns() { return K1Q; }
 int k1_rb_bpad() { return K1_BPAD; }
 const void* k1e_fold_kernel() { return reinterpret_cast<const void*>(&k1e_fold_error); }

@@ -9,6 +9,7 @@
 #include <cmath>
 
 #include "kernels.hpp"
+#include "k3_device.hpp"
 
 namespace {
 using namespace cafehip;
@@ -193,62 +194,7 @@ __global__ __launch_bounds__(1024) void k2_prune_v1(K2Args a)
 template <bool HOST_OUT>
 __global__ __launch_bounds__(CAFEHIP_CHUNK) void k3_score(K3Args a)
 {
-    const double* __restrict__ max_post_u = a.max_post_u;
-    const double* __restrict__ max_lik_u = a.max_lik_u;
-    const int32_t* __restrict__ fam2u = a.fam2u;
-    const int F = a.F, Fu = a.Fu;
-    double* __restrict__ chunk_sums = a.chunk_sums;
-    int32_t* __restrict__ first_zero = a.first_zero;
-    HostResult* host = a.host;
-    int32_t* arrive = a.arrive;
-    const int32_t seq = a.seq;
-    // blockIdx.y = parameter set: its per-family values start at set * Fu, its chunk sums at set * gridDim.x
-    __shared__ double red[CAFEHIP_CHUNK];
-    __shared__ int s_last;
-    const int set = blockIdx.y;
-    max_post_u += (size_t)set * Fu;
-    max_lik_u += (size_t)set * Fu;
-    const int i = blockIdx.x * CAFEHIP_CHUNK + threadIdx.x;
-    double v = 0.0;
-    if (i < F) {
-        const int u = fam2u ? fam2u[i] : i;   // (NULL: no duplicate rows, family i is unique row i -- one round trip less)
-        v = log(max_post_u[u]);                                   // cafe/lambda.cpp:721
-        if (max_lik_u[u] == 0.0) atomicMin(first_zero + set, i);  // cafe/lambda.cpp:715-720
-    }
-    red[threadIdx.x] = v;
-    __syncthreads();
-#pragma unroll
-    for (int s = CAFEHIP_CHUNK / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    const size_t slot = (size_t)set * gridDim.x + blockIdx.x;
-    if (!HOST_OUT) {
-        if (threadIdx.x == 0) chunk_sums[slot] = red[0];
-        return;
-    }
-    if (threadIdx.x == 0) {
-        host->chunk_sums[slot] = red[0];
-        __threadfence_system();
-        s_last = (atomicAdd(arrive, 1) == (int)(gridDim.x * gridDim.y) - 1);
-    }
-    __syncthreads();
-    if (s_last && threadIdx.x == 0) {
-        __threadfence();
-        // (every other block's chunk sum was fenced system-wide before it counted itself in)
-        // atomic read of the final value, which also leaves the word as the NEXT evaluation needs it (INT32_MAX): an
-        // evaluation whose matrices are already on the device (cafehip_prefetch_matrices) has no K1 launch to reset it
-        const int32_t fz0 = atomicExch(first_zero, INT32_MAX);
-        if (gridDim.y > 1) {
-            for (int q = 1; q < (int)gridDim.y; ++q) host->first_zero[q] = atomicExch(first_zero + q, INT32_MAX);
-            __threadfence_system();
-        }
-        *arrive = 0;
-        // the sequence number and set 0's first-zero index share one aligned 8-byte word: a single store publishes
-        // both, no fence in between (the host reads the index after it has seen the number)
-        static_assert(offsetof(HostResult, first_zero) == 4 && offsetof(HostResult, done_seq) == 0, "one 8-byte word");
-        *reinterpret_cast<volatile unsigned long long*>(host) = ((unsigned long long)(unsigned)fz0 << 32) | (unsigned)seq;
-    }
+    k3_score_block<HOST_OUT>(a, blockIdx.x, gridDim.x, blockIdx.y, gridDim.y);
 }
 
 

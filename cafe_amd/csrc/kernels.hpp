@@ -10,6 +10,7 @@ namespace cafehip {
 // k1_matrices.hip
 const void* k1_kernel(bool use_lds, bool product_form);   // k1_build_matrices<USE_LDS, PRODUCT_FORM>(K1Args)
 const void* k1_rb_kernel();                               // k1_build_matrices_rb(K1Args)
+const void* k3_then_k1_rb_kernel();                       // k3_score_then_k1_rb(K3K1Args): score blocks, then matrix-build blocks
 int k1_rb_columns();                                      // columns per thread of the register-blocked kernel
 int k1_rb_bpad();                                         // zeros staged in front of every B row
 const void* k1e_fold_kernel();                            // k1e_fold_error(FoldArgs)

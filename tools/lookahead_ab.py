@@ -58,6 +58,7 @@ def main():
     ap.add_argument("tables", nargs="*", default=["cfg2", "test1"])
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--speculate", default=None, help="host option speculate for both runs (default: the library's choice)")
+    ap.add_argument("--option", action="append", default=[], help="key=value handed to the session (e.g. matrix_cache=0: the look-ahead's host work without the builds)")
     a = ap.parse_args()
     from cafe_amd.shell import CafeShell
     for name in a.tables:
@@ -68,6 +69,9 @@ def main():
                 sh.set_option("speculate", a.speculate)
             for l in lines:
                 sh.dispatch(l)
+            for kv in a.option:
+                k, v = kv.split("=", 1)
+                sh.set_option(k, v)
             times = {0: [], 1: []}
             results = {}
             stats = None
