@@ -846,6 +846,10 @@ int rebuild_compression(cafehip_ctx* c)
     }
     if (c->opt.compress_theta >= 0) theta = std::min(c->opt.compress_theta, 1.0);
     const size_t limit = (size_t)(theta * Fu);
+    const int max_level = c->opt.compress_max_level > 0 ? c->opt.compress_max_level : INT_MAX;
+    // a table whose walk is one round of workgroups (at most 64 rows each): an evaluation is a chain of launches and
+    // latency-bound steps, not work
+    const bool launch_bound = Fu <= 64 * std::max(c->n_cu, 1);
     std::vector<std::vector<int32_t>> sid(n), idx0(n), idx1(n);
     std::vector<int> D(n, 0), level(n, 0);
     std::vector<char> comp(n, 0);
@@ -864,7 +868,8 @@ int rebuild_compression(cafehip_ctx* c)
             // open-addressing table keyed by the pair of child states (linear probing; at most `limit` entries in a power
             // of two of at least twice that)
             size_t cap = 64;
-            while (cap < 2 * (std::min<size_t>(limit, (size_t)Fu) + 1)) cap <<= 1;
+            int cap_log2 = 6;
+            while (cap < 2 * (std::min<size_t>(limit, (size_t)Fu) + 1)) { cap <<= 1; ++cap_log2; }
             std::vector<uint64_t> keys(cap);
             std::vector<int32_t> vals(cap, -1);
             int32_t n_ids = 0;
@@ -873,7 +878,9 @@ int rebuild_compression(cafehip_ctx* c)
             const int32_t *sa = sid[a].data(), *sb = sid[b].data();
             for (int u = 0; u < Fu; ++u) {
                 const uint64_t key = ((uint64_t)(uint32_t)sa[u] << 32) | (uint32_t)sb[u];
-                size_t at = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+                // home slot from the TOP bits of the product: both children's states reach them (the left child's state sits
+                // in the key's high half and only enters the product's bits from 32 up)
+                size_t at = (size_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - cap_log2));
                 while (vals[at] >= 0 && keys[at] != key) at = (at + 1) & (cap - 1);
                 if (vals[at] < 0) {
                     if ((size_t)n_ids >= limit) { fits = false; break; }
@@ -884,18 +891,20 @@ int rebuild_compression(cafehip_ctx* c)
                 }
                 mine[u] = vals[at];
             }
-            if (fits && n_ids > 0) {
+            const int lvl = 1 + std::max(comp[a] ? level[a] : 0, comp[b] ? level[b] : 0);
+            if (fits && n_ids > 0 && lvl <= max_level) {
                 comp[v] = 1;
                 D[v] = n_ids;
-                level[v] = 1 + std::max(comp[a] ? level[a] : 0, comp[b] ? level[b] : 0);
+                level[v] = lvl;
                 sid[v].swap(mine);
             } else {
                 idx0[v].clear();
                 idx1[v].clear();
             }
         }
-        // the children's states are needed again only as columns of the walk (kept below for the maximal nodes)
-        if (comp[v]) {
+        // the children's states are needed again only as columns of the walk (kept below for the maximal nodes; a small
+        // table keeps them all: its top levels may go back to the walk, see below)
+        if (comp[v] && !launch_bound) {
             std::vector<int32_t>().swap(sid[a]);
             std::vector<int32_t>().swap(sid[b]);
         }
@@ -932,6 +941,33 @@ int rebuild_compression(cafehip_ctx* c)
     int n_comp = 0, n_levels = 0;
     for (int v = 0; v < n; ++v)
         if (comp[v]) { ++n_comp; n_levels = std::max(n_levels, level[v]); }
+    // Predicted TIME, not work, decides the top of the forest of a launch-bound table (round 5).  There a level costs its
+    // launch -- ~8 us with the gap in front of it, whatever its tile count up to a chip-full (the reference's test1 table:
+    // 6.5-7.7 us for 73-367 tiles) -- while a node left to the walk costs one more walk step: ~2.5 us of gathers and
+    // barriers + the product, 0.2 us per k-step at ten row tiles (10 us at a 151-wide matrix, 4-5 us at 71).  A top level
+    // whose nodes are cheaper as walk steps goes back to the walk; measured on test1 (profiles/r05/plan_sweep.txt): 81.9 us
+    // with all five levels, 79.0 without the fifth, 77.5 without the fourth too, 80.9 once the two nodes of the third go.
+    if (launch_bound && c->opt.compress_drop_top && c->opt.compress_max_level <= 0) {
+        const double ksteps = (c->C + 3) / 4, row_tiles = (c->C + 15) / 16;
+        const double step_us = 2.5 + 0.2 * ksteps * row_tiles / 10.0, level_us = 8.0;
+        while (n_levels >= 2) {
+            int n_top = 0;
+            for (int v = 0; v < n; ++v)
+                if (comp[v] && level[v] == n_levels) ++n_top;
+            if (n_top * step_us + 0.5 >= level_us) break;
+            for (int v = 0; v < n; ++v)
+                if (comp[v] && level[v] == n_levels) {
+                    comp[v] = 0;
+                    D[v] = 0;
+                    level[v] = 0;
+                    std::vector<int32_t>().swap(idx0[v]);
+                    std::vector<int32_t>().swap(idx1[v]);
+                    std::vector<int32_t>().swap(sid[v]);
+                    --n_comp;
+                }
+            --n_levels;
+        }
+    }
     if (n_comp == 0) return 0;
     auto& p = c->cp;
     // tables
@@ -1849,7 +1885,7 @@ namespace {
 // ---- run-time switches ---------------------------------------------------------------------------------------
 // (name, what it selects) -- cafehip_set_option; the same names upper-cased behind CAFEHIP_ are read from the
 // environment ONCE, when the context is created (tools/ sweeps), never during an evaluation
-const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
+const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "compress_max_level", "compress_drop_top", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
                                     "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch",
                                     "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "exp_like_host", "matrix_cache",
                                     "matrix_cache_mb", "prefetch_where", "prefetch_kpb", "comm"};
@@ -1862,6 +1898,8 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     if (key == "compress") { o.compress = iv != 0; replan = true; }
     else if (key == "compress_theta") { o.compress_theta = val.empty() ? -1.0 : std::min(std::max(atof(val.c_str()), 0.0), 1.0); replan = true; }
     else if (key == "compress_min") { o.compress_min = iv; replan = true; }
+    else if (key == "compress_max_level") { o.compress_max_level = iv; replan = true; }
+    else if (key == "compress_drop_top") { o.compress_drop_top = iv != 0; replan = true; }
     else if (key == "errfold") o.errfold = iv != 0;
     else if (key == "errband") {
         o.errband = iv != 0;

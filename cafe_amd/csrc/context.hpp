@@ -153,6 +153,8 @@ struct cafehip_ctx {
         int compress = 1;             // subtree-state compression of the objective path
         double compress_theta = -1;   // < 0: by table size and matrix side (rebuild_compression)
         int compress_min = 64;        // unique rows below which a table is left alone
+        int compress_drop_top = 1;    // launch-bound tables: top levels whose nodes are cheaper as walk steps go back to the walk
+        int compress_max_level = 0;   // > 0: nodes above this level of the compressed forest stay in the walk (sweeps)
         int errfold = 1;              // error model folded into the matrices (posterior mode)
         int errband = 1;              // banded error models as short sums of gathers
         int k1 = 0;                   // 0 auto, 1 exact form, 2 per-term product form

@@ -56,6 +56,9 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *   compress        0|1        subtree-state compression of the objective path (1)
  *   compress_theta  0..1       share of the unique rows a node's distinct states may reach (by table size)
  *   compress_min    n          unique rows below which a table is left alone (64)
+ *   compress_drop_top 0|1      launch-bound tables (one round of walk workgroups): top levels of the compressed forest whose
+ *                              nodes are cheaper as walk steps than the level's launch go back to the walk (1)
+ *   compress_max_level n       nodes above level n of the compressed forest stay in the walk (0: no limit; sweeps)
  *   errfold         0|1        error model folded into the matrices in an objective evaluation (1)
  *   errband         0|1        banded error models as short sums of column gathers (1)
  *   k1              auto|exact|perterm   arithmetic form of the matrix build (auto: register-blocked product form)
