@@ -130,7 +130,11 @@ def synthetic_workload(config, rank, world, scaling, families, same_table_blocks
         F_total = F_local * world
         counts = synth.simulate_families(tree, F_local, cfg["m"], cfg["lam"], cfg["mu"], cfg["seed"] + 1 + rank)
         bounds = [(r * F_local, (r + 1) * F_local) for r in range(world)]
-    prior = cprior.prior_rfsize_poisson(rng.root_min, cprior.poisson_lambda_mle(counts))
+    # strong scaling: the prior must not depend on which blocks a rank holds, or the score of the SAME table would differ
+    # with N (rounds 3-4 fitted it to the local blocks: last_score moved in the 7th digit between N = 1 and N = 8).  A fixed
+    # Poisson mean near the table's (roots are 1 + Poisson(8) with a uniform tail) makes last_score one number for every N.
+    prior_lambda = 9.0 if scaling == "strong" else cprior.poisson_lambda_mle(counts)
+    prior = cprior.prior_rfsize_poisson(rng.root_min, prior_lambda)
     rate_fn = lambda step: synth.node_rates(tree, cfg, 1.0 + 0.003 * (step % 97), 1.0 + 0.002 * (step % 89))
     return Workload(config, tree, newick, counts, bounds, F_total, rng, prior, cfg, rate_fn, cfg["desc"])
 
@@ -520,6 +524,8 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    _STATE["stdout"] = real_stdout
+    _STATE["args"] = args
 
     import torch
     import torch.distributed as dist
@@ -621,6 +627,8 @@ def main():
     leg = Leg(wl, local_rank, comm, shared_engine=eng)
     leg.prepare_rates(args.warmup + args.steps + MIN_KERNEL_SAMPLES)
     priming = leg.prime(fixed_count=(1000 if F_local <= 20000 else 60) if multi else None)
+    if os.environ.get("BENCH_FAIL_RANK") == str(rank):
+        raise RuntimeError("forced by BENCH_FAIL_RANK (test: rank 0 must still print its line, with an `error` key)")
     dt, last = leg.run(args.warmup, args.steps, rank=rank)
     per_rank_dt = [dt]
     if multi:
@@ -756,6 +764,7 @@ def main():
 
     if rank == 0:
         out["bench_wall_s"] = time.perf_counter() - t_bench0   # the whole script: table generation, all legs, CPU baseline
+        _STATE["printed"] = True
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     eng.close()
     if multi:
@@ -1117,5 +1126,45 @@ def cpu_baseline(wl, eng):
     }
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The contract is one JSON line from rank 0 WHATEVER happens: when this rank fails, or is terminated because another
+# rank failed (torch.distributed.run sends SIGTERM to the survivors), the line carries an `error` key instead of a value.
+# ---------------------------------------------------------------------------------------------------------------------
+_STATE = {"stdout": None, "args": None, "printed": False}
+
+
+def _emit_error(message):
+    if _STATE["printed"] or int(os.environ.get("RANK", "0")) != 0:
+        return
+    _STATE["printed"] = True
+    a = _STATE["args"]
+    line = {"metric": "family-likelihood evals/sec (full tree)", "value": None, "unit": "family-evals/s",
+            "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "steps": getattr(a, "steps", None), "warmup": getattr(a, "warmup", None),
+            "higher_is_better": True, "error": str(message)[:2000]}
+    fd = _STATE["stdout"] if _STATE["stdout"] is not None else 1
+    try:
+        os.write(fd, (json.dumps(line) + "\n").encode())
+    except OSError:
+        pass
+
+
+def _on_sigterm(signum, frame):
+    _emit_error("terminated by signal %d (another rank failed, or the launcher's time-out)" % signum)
+    os._exit(143)
+
+
 if __name__ == "__main__":
-    main()
+    import signal
+    import traceback
+    if "WORLD_SIZE" in os.environ or "--gpus" not in sys.argv:   # (the bare `--gpus N` parent only re-executes itself)
+        signal.signal(signal.SIGTERM, _on_sigterm)
+    try:
+        main()
+    except SystemExit as e:
+        if e.code not in (0, None) and "WORLD_SIZE" in os.environ:
+            _emit_error("exit: %s" % (e.code,))
+        raise
+    except BaseException as e:   # noqa: BLE001 -- the line must be printed whatever it was
+        traceback.print_exc()
+        _emit_error("%s: %s" % (type(e).__name__, e))
+        sys.exit(1)

@@ -89,3 +89,24 @@ def test_native_exchange_failure_falls_back_to_the_torch_path_on_every_rank(monk
     d = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
     assert d["comm"] == "torch" and "forced by BENCH_FORCE_NATIVE_FAILURE" in d["comm_fallback"]
     assert d["value"] > 1e6 and d["exchange"]["mode"].startswith("torch.distributed")
+
+
+def test_round5_keys_and_the_error_line_of_a_failing_job():
+    # the serial headline and, beside it (never folded in), the same steps with the next parameter set announced ahead
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "2", "--no-cpu-baseline",
+                          "--no-search", "--no-probes", "--no-strong", "--no-tables"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    sp = d["speculated"]
+    assert d["speculated_hit_ms_per_step"] > 0 and sp["last_score_equals_an_evaluation_that_builds_its_matrices"] is True
+    assert sp["this_rank"]["hits"] >= 16 and d["ms_per_step"] > 0
+    # a rank that fails: rank 0 still prints exactly one line, with an `error` key (two ranks sharing this box's GPU)
+    env = dict(os.environ, BENCH_FAIL_RANK="1", CAFEHIP_COMM_TIMEOUT_S="20")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--steps", "8", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-search", "--no-probes", "--no-strong", "--no-tables"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode != 0
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    e = json.loads(lines[0])
+    assert "error" in e and e["value"] is None and e["n_gpus"] == 2
