@@ -18,6 +18,7 @@ SIGNATURES = {
     "cafehip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "cafehip_destroy": (None, [C.c_void_p]),
     "cafehip_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "cafehip_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     "cafehip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cafehip_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "cafehip_set_tree": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _dp]),

@@ -2095,6 +2095,25 @@ int cafehip_set_option(cafehip_ctx* c, const char* key, const char* value)
     return set_option(c, key, value ? value : "");
 }
 
+int cafehip_get_option(cafehip_ctx* c, const char* key, char* value, size_t value_bytes)
+{
+    if (!c || !key || !value || value_bytes == 0) return fail("null argument");
+    const std::string k = key;
+    const auto& o = c->opt;
+    std::string v;
+    if (k == "k2") v = o.k2 == 1 ? "v1" : (o.k2 == 2 ? "v1ref" : "auto");
+    else if (k == "k1") v = o.k1 == 1 ? "exact" : (o.k1 == 2 ? "perterm" : "auto");
+    else if (k == "compress") v = std::to_string(o.compress);
+    else if (k == "errfold") v = std::to_string(o.errfold);
+    else if (k == "matrix_cache") v = std::to_string(c->mc.want_entries);
+    else if (k == "prefetch_where") v = std::to_string(o.prefetch_where);
+    else if (k == "comm") v = c->comm_mode == 1 ? "rccl" : (c->comm_mode == 2 ? "direct" : "auto");
+    else return fail("option '%s' cannot be read back", key);
+    if (v.size() + 1 > value_bytes) return fail("option value needs %zu bytes", v.size() + 1);
+    memcpy(value, v.c_str(), v.size() + 1);
+    return 0;
+}
+
 int cafehip_set_stream(cafehip_ctx* c, void* hip_stream)
 {
     if (!c) return fail("null context");

@@ -47,6 +47,24 @@ static int run_comm_probe(cafehip_ctx* c, CommLink& L)
     a.nonce = L.nonce;
     a.timeout_ticks = (long long)(std::min(1.0, comm_timeout_s()) * 1e8);
     a.seen = d_seen;
+    // Every rank's wait slice (<= 1 s) counts from ITS kernel's start, so the kernels must start together: the kernel's code
+    // object is loaded by a launch that does nothing (world 0: no stores, no waits), the stream drained, and the ranks meet
+    // at a host barrier immediately before the real launch -- a rank that was still allocating or loading code would
+    // otherwise make a healthy fabric fail the early rank's probe.
+    {
+        XProbeArgs warm = a;
+        warm.world = 0;
+        if (launch_kernel(kx_probe_kernel(), dim3(1), dim3(64), 0, c->stream, warm) || hipStreamSynchronize(c->stream) != hipSuccess) {
+            hipFree(d_seen);
+            return fail("communicator: the probe kernel could not be launched");
+        }
+        HIP_TRY(hipMemsetAsync(d_seen, 0, sizeof(int32_t), c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (!L.barrier()) {
+            hipFree(d_seen);
+            return fail("communicator: %s", L.error.c_str());
+        }
+    }
     const auto t0 = std::chrono::steady_clock::now();
     if (launch_kernel(kx_probe_kernel(), dim3(1), dim3(64), 0, c->stream, a)) {
         hipFree(d_seen);
@@ -86,7 +104,7 @@ int cafehip_comm_init(cafehip_ctx* c, int rank, int world, const void* unique_id
         delete L;
         return -1;
     }
-    const int mode = L->decide_mode(seen == world, [&] { return c->comm_mode != 2 && L->ensure_rccl(); });
+    const int mode = L->decide_mode(seen == world, c->comm_mode != 2, [&] { return L->ensure_rccl(); });
     if (mode <= 0) {
         const std::string msg = mode < 0 ? L->error
                                          : "no exchange mode works on every rank: direct refused (this rank mapped " + std::to_string(L->peers_mapped) +
@@ -333,7 +351,8 @@ int cafehip_comm_mode_selftest(int rank, int world, const void* unique_id, int m
     if (!unique_id || !mode) return fail("null argument");
     CommLink L;
     if (!L.init(-1, rank, world, unique_id)) return fail("communicator: %s", L.error.c_str());
-    *mode = L.decide_mode(my_probe_ok != 0, [&] { return my_rccl_ok != 0; });
+    // (my_rccl_ok: 1 joins, 0 fails to join, -1 ruled out by a local option: then NO rank may enter the collective join)
+    *mode = L.decide_mode(my_probe_ok != 0, my_rccl_ok >= 0, [&] { return my_rccl_ok > 0; });
     if (*mode < 0) return fail("communicator: %s", L.error.c_str());
     return L.barrier() ? 0 : fail("communicator: %s", L.error.c_str());
 }

@@ -384,12 +384,17 @@ public:
     // the same value on every rank, so either all carry on in one mode or all fail together.  -1: the control segment
     // itself failed (a rank died).
     template <class JoinRccl>
-    int decide_mode(bool my_probe_ok, JoinRccl join_rccl)
+    int decide_mode(bool my_probe_ok, bool my_rccl_allowed, JoinRccl join_rccl)
     {
         bool all_direct = false;
         if (!all_ranks(my_probe_ok, &all_direct)) return -1;
         direct_ok = all_direct;
         if (all_direct) return 2;
+        // RCCL is tried only if NO rank rules it out: joining it is collective (two mailbox rounds), so a rank-local switch
+        // (option comm=direct, CAFEHIP_COMM in one process's environment) must not let the ranks run different numbers of rounds
+        bool all_allow = false;
+        if (!all_ranks(my_rccl_allowed, &all_allow)) return -1;
+        if (!all_allow) return 0;
         const bool mine = join_rccl();
         bool all_rccl = false;
         if (!all_ranks(mine, &all_rccl)) return -1;

@@ -11,6 +11,13 @@
 // is first used, by comparing both forms with std::exp on 200,000 arguments; K1's exact form then calls the matching one, or the
 // device library's exp when neither matches.  The table is computed in quad precision by tools/exp_table_gen.c;
 // tests/test_exp_like_host.py checks the host build of this function against the host's exp() on 10^7 arguments, bit for bit.
+//
+// Source of the algorithm (third party, NOT the CAFE reference): `exp` of ARM's Optimized Routines (math/exp.c, Copyright (c)
+// 2018 Arm Limited, SPDX-License-Identifier: MIT -- later releases: MIT OR Apache-2.0 WITH LLVM-exception), adopted by glibc
+// 2.28 as sysdeps/ieee754/dbl-64/e_exp.c (LGPL-2.1-or-later).  The reduction constants, the polynomial coefficients, the
+// table layout (tail, scale bits) and the special-case ladder below are that algorithm's -- they have to be, bit for bit,
+// or the results would not be the host's; the code is restated for host + device and the table regenerated in quad
+// precision (tools/exp_table_gen.c), not copied from either tree.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -40,11 +47,13 @@ __host__ __device__ inline double exp_from_bits(uint64_t u)
     return d;
 }
 
-#pragma clang fp contract(off)
 // FUSED: the build of the algorithm compiled with fused multiply-add (what x86-64 glibc runs on a CPU that has it)
 template <bool FUSED>
 __host__ __device__ inline double exp_like_host(double x)
 {
+    // every fused operation below is written as fma(): the compiler must not form others (scoped to this body: the
+    // including translation units keep their own contraction setting)
+#pragma clang fp contract(off)
 #ifdef __HIP_DEVICE_COMPILE__
     const uint64_t* const T = kExpTabDev;
 #else
@@ -87,7 +96,9 @@ __host__ __device__ inline double exp_like_host(double x)
             const double scale = exp_from_bits(sbits);
             return 0x1p1009 * (FUSED ? fma(scale, tmp, scale) : scale + scale * tmp);
         }
-        sbits += 1022ull << 52;          // k < 0: care in the subnormal range (the product is used twice: never fused)
+        sbits += 1022ull << 52;          // k < 0: care in the subnormal range.  The product is used twice and is kept unfused in
+                                         // BOTH forms here; a libm build that fused one use anyway would differ in this
+                                         // range, which the detection at first use samples (x < -708): it would be rejected
         const double scale = exp_from_bits(sbits);
         const double prod = scale * tmp;
         double y = scale + prod;
@@ -103,7 +114,6 @@ __host__ __device__ inline double exp_like_host(double x)
     const double scale = exp_from_bits(sbits);
     return FUSED ? fma(scale, tmp, scale) : scale + scale * tmp;
 }
-#pragma clang fp contract(fast)
 
 // 1: this host's exp() is the fused form, 2: the plain form, 0: neither (the device library's exp is used).  Decided once.
 inline int host_exp_variant(long* mismatches_fused = nullptr, long* mismatches_plain = nullptr, long n = 200000, unsigned seed = 12345)

@@ -433,16 +433,25 @@ struct cafehost_session {
     // (a proof and a debugging aid, not a mode to search in).
     bool opt_objective_reference = false;
     std::vector<int32_t> device_rows;   // the uploaded table in tree-leaf order (kept only for that mode)
-    struct ReportArith {   // scope guard around the likelihood launches of a report-phase command
-        cafehost_session* s;
-        explicit ReportArith(cafehost_session* s_) : s(s_)
+    // the pruning kernel switched to the reference's arithmetic for a scope, and back to what the user had chosen (not to the
+    // default: CAFEHIP_K2 or a cafehost_set_option "k2" must survive a report)
+    struct K2Reference {
+        cafehip_ctx* c;
+        bool active;
+        char before[16];
+        K2Reference(cafehip_ctx* ctx, bool on) : c(ctx), active(on)
         {
-            if (s->opt_report_reference && cafehip_set_option(s->ctx, "k2", "v1ref") != 0) throw std::runtime_error(std::string("cafehip: ") + cafehip_last_error());
+            if (!active) return;
+            if (cafehip_get_option(c, "k2", before, sizeof before) != 0 || cafehip_set_option(c, "k2", "v1ref") != 0)
+                throw std::runtime_error(std::string("cafehip: ") + cafehip_last_error());
         }
-        ~ReportArith()
+        ~K2Reference()
         {
-            if (s->opt_report_reference) (void)cafehip_set_option(s->ctx, "k2", "auto");
+            if (active) (void)cafehip_set_option(c, "k2", before);
         }
+    };
+    struct ReportArith : K2Reference {   // scope guard around the likelihood launches of a report-phase command
+        explicit ReportArith(cafehost_session* s_) : K2Reference(s_->ctx, s_->opt_report_reference) {}
     };
 
     bool speculation_pays()
@@ -560,11 +569,7 @@ struct cafehost_session {
             device_families_current = false;   // (the option was switched on after the upload)
             upload();
         }
-        hip_check(cafehip_set_option(ctx, "k2", "v1ref"));
-        struct Restore {
-            cafehip_ctx* c;
-            ~Restore() { (void)cafehip_set_option(c, "k2", "auto"); }
-        } restore{ctx};
+        K2Reference restore(ctx, true);
         reset_cache_exact(nl, nm);
         double score = 0;
         zero = -1;

@@ -87,6 +87,9 @@ void cafehip_destroy(cafehip_ctx *ctx);
  * cafehip_create; nothing reads the environment during an evaluation.  Options that change the compression plan
  * rebuild it.  No reference counterpart. */
 int cafehip_set_option(cafehip_ctx *ctx, const char *key, const char *value);
+/* The current value of a switch that a caller may want to put back after changing it for one call (k2, k1, compress,
+ * errfold, matrix_cache, prefetch_where, comm), as the string cafehip_set_option takes. */
+int cafehip_get_option(cafehip_ctx *ctx, const char *key, char *value, size_t value_bytes);
 
 /* Run all subsequent work of this context on the caller's HIP stream (a hipStream_t passed as
  * void*).  NULL is the HIP legacy default stream -- the handle torch reports for its default

@@ -63,6 +63,8 @@ def _mode_ranks(tmp_path, outcomes):
     ([(1, 0), (1, 1), (0, 1)], 0),          # ... and where one rank cannot join RCCL either: every rank reports "none"
     ([(0, 1), (0, 1)], 1),
     ([(1, 0)], 2),                          # one rank: its own store must come back
+    ([(1, 1), (0, -1), (1, 1)], 0),         # rank 1 rules RCCL out locally (option comm=direct in ONE process): nobody enters the
+                                            # collective join -- the ranks still run the same rounds and agree on "none" 
 ])
 def test_every_rank_lands_in_the_same_exchange_mode(tmp_path, outcomes, expected):
     # "mapped" is not "reachable" (VERDICT r03 #1): the ranks agree on ONE mode at set-up from their probe outcomes --
