@@ -69,6 +69,7 @@ HOST_SIGNATURES = {
     "cafehost_run_script": (C.c_int, [C.c_void_p, C.c_char_p]),
     "cafehost_rng_selftest": (C.c_int, [C.c_uint, C.c_int, C.c_int, C.c_int]),
     "cafehost_poisson_fit_selftest": (C.c_int, [_ip, C.c_long, C.c_double, C.c_int, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_long)]),
+    "cafehost_format_selftest": (C.c_long, [_dp, C.c_long, _dp]),
     "cafehost_pvalue_selftest": (C.c_double, [C.c_double, _dp, C.c_int]),
     "cafehost_fminsearch_selftest": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _dp, C.c_double, C.c_double, _dp, _dp, C.POINTER(C.c_int)]),
     "cafehost_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),

@@ -327,6 +327,62 @@ struct cafehost_session {
         if (native_comm && !solo) wire_native();
     }
 
+    // The Poisson fit of the prior (collect_leaf_sizes + find_poisson_lambda, cafe/lambda.cpp:771-838) needs the table and one
+    // random number; the table's upload (row dedup, compression plan, device copies) needs neither the fit nor the random
+    // stream: a search command starts the fit on a host thread, uploads, and picks the fit up where the reference runs it
+    // (round 5: configs[1] `lambda -s` spent 6.8 of 14 ms in the two, one after the other).  The random start is drawn on
+    // the calling thread, in the reference's order; log lines are written when the result is picked up.
+    struct PriorJob {
+        bool started = false;
+        std::thread worker;
+        std::exception_ptr error;
+        PoissonFit fit;
+        size_t n_leaf_sizes = 0;
+    } prior_job;
+    void begin_prior_fit()
+    {
+        if (prior_job.started || !opt_prior_file.empty()) return;
+        prior_job.started = true;
+        prior_job.error = nullptr;
+        prior_job.fit = PoissonFit();
+        const double start = unifrnd();
+        const bool look = opt_prior_lookahead != 0;
+        prior_job.worker = std::thread([this, start, look] {
+            try {
+                std::vector<int> leaf_sizes;  // collect_leaf_sizes :789-806
+                const int ns = (int)fam.species.size();
+                for (int idx = 0; idx < fam.F(); ++idx)
+                    for (int i = 0; i < ns; ++i) {
+                        if (species_index[i] < 0) continue;
+                        const int cnt = fam.counts[(size_t)idx * ns + i];
+                        if (cnt > 0) leaf_sizes.push_back(cnt - 1);
+                    }
+                prior_job.n_leaf_sizes = leaf_sizes.size();
+                prior_job.fit.run(leaf_sizes, start, look);
+            } catch (...) {
+                prior_job.error = std::current_exception();
+            }
+        });
+    }
+    // a command that failed between starting the fit and picking it up must not leave it to the next command
+    void drop_prior_job()
+    {
+        if (prior_job.worker.joinable()) prior_job.worker.join();
+        prior_job.started = false;
+        prior_job.error = nullptr;
+    }
+    // upload() with the prior fit running beside it; the caller calls set_prior_rfsize_empirical() where the reference does
+    void upload_beside_prior_fit()
+    {
+        begin_prior_fit();
+        try {
+            upload();
+        } catch (...) {
+            drop_prior_job();
+            throw;
+        }
+    }
+
     // ---- prior: cafe_set_prior_rfsize_empirical, cafe/lambda.cpp:808-870 ----
     void set_prior_rfsize_empirical()
     {
@@ -357,20 +413,19 @@ struct cafehost_session {
             (void)unifrnd();   // the fit's random start: the stream stays where the reference's flow would leave it
             return;
         }
-        std::vector<int> leaf_sizes;  // collect_leaf_sizes :789-806
-        const int ns = (int)fam.species.size();
-        for (int idx = 0; idx < fam.F(); ++idx)
-            for (int i = 0; i < ns; ++i) {
-                if (species_index[i] < 0) continue;
-                const int cnt = fam.counts[(size_t)idx * ns + i];
-                if (cnt > 0) leaf_sizes.push_back(cnt - 1);
-            }
-        PoissonFit fit;
-        const double start = unifrnd();
-        fit.run(leaf_sizes, start, opt_prior_lookahead != 0);
+        // (the fit proper may already be running beside the table's upload: begin_prior_fit)
+        if (!prior_job.started) begin_prior_fit();
+        if (prior_job.worker.joinable()) prior_job.worker.join();
+        prior_job.started = false;
+        if (prior_job.error) {
+            std::exception_ptr e = prior_job.error;
+            prior_job.error = nullptr;
+            std::rethrow_exception(e);
+        }
+        PoissonFit& fit = prior_job.fit;
         poisson_lambda = fit.lambda;
         if (opt_timing && shard_rank == 0)
-            fprintf(stderr, "prior fit: %zu leaf sizes, %d iterations, %ld passes of %ld chains, %ld cached / %ld single evaluations\n", leaf_sizes.size(),
+            fprintf(stderr, "prior fit: %zu leaf sizes, %d iterations, %ld passes of %ld chains, %ld cached / %ld single evaluations\n", prior_job.n_leaf_sizes,
                     fit.iters, fit.passes, fit.chains, fit.hits, fit.misses);
         log("Empirical Prior Estimation Result: (%d iterations)\n", fit.iters);
         log("Poisson lambda: %f & Score: %f\n", poisson_lambda, fit.score);
@@ -1225,7 +1280,7 @@ struct cafehost_session {
             } else
                 throw std::runtime_error("lambda " + a.opt + " is outside this build's scope (supported: -s -l -v -t -r -o -e -score -checkconv -k -f -p)");
         }
-        upload();
+        upload_beside_prior_fit();
         n_evals = 0;
         trace.clear();
         if (!ranges.empty()) {
@@ -1348,7 +1403,7 @@ struct cafehost_session {
             throw std::runtime_error("ERROR(lambdamu): Cannot use option eqbg without specifying a lambda tree. \n");
         num_mus = num_lambdas;
         num_params = num_lambdas + num_mus - (eqbg ? 1 : 0);
-        upload();
+        upload_beside_prior_fit();
         n_evals = 0;
         trace.clear();
         set_prior_rfsize_empirical();
@@ -1721,28 +1776,29 @@ struct cafehost_session {
         }
         // rows are formatted by worker threads over contiguous blocks of families and written in family order
         auto format_rows = [&](int i0, int i1, std::string& out) {
-            char num[64];
+            out.reserve((size_t)(i1 - i0) * (pieces.size() * 8 + (size_t)npairs * 12 + 64));
             for (int i = i0; i < i1; ++i) {
                 const int32_t* fs = &rep_sizes[(size_t)i * n];
                 out += fam.ids[i];
                 out += '\t';
                 for (size_t h = 0; h < hole_node.size(); ++h) {
                     out += pieces[h];
-                    snprintf(num, sizeof num, "%d", fs[hole_node[h]]);
-                    out += num;
+                    append_int(out, fs[hole_node[h]]);
                 }
                 out += pieces.back();
                 out += '\t';
-                snprintf(num, sizeof num, "%g", rep_max_p[i]);
-                out += num;
+                append_g(out, rep_max_p[i]);
                 out += "\t(";
                 for (int b = 0; b < npairs / 2; ++b) {
                     const double p1 = rep_branch_p[(size_t)i * (n - 1) + 2 * b], p2 = rep_branch_p[(size_t)i * (n - 1) + 2 * b + 1];
                     if (p1 < 0) {
                         out += "(-,-)";
                     } else {
-                        snprintf(num, sizeof num, "(%g,%g)", p1, p2);
-                        out += num;
+                        out += '(';
+                        append_g(out, p1);
+                        out += ',';
+                        append_g(out, p2);
+                        out += ')';
                     }
                     if (b < npairs / 2 - 1) out += ',';
                 }
@@ -2580,6 +2636,30 @@ int cafehost_poisson_fit_selftest(const int* leaf_sizes, long n, double start, i
 
 double cafehost_pvalue_selftest(double v, const double* sorted_null, int size) { return pvalue_rank(v, sorted_null, size); }
 
+// the report's number formatting against printf: returns how many of `n` values differ (0 expected), the first in `first_bad`
+long cafehost_format_selftest(const double* values, long n, double* first_bad)
+{
+    long bad = 0;
+    std::string fast;
+    char slow[64];
+    for (long i = 0; i < n; ++i) {
+        fast.clear();
+        append_g(fast, values[i]);
+        snprintf(slow, sizeof slow, "%g", values[i]);
+        bool same = fast == slow;
+        const int iv = (int)std::max(-2147483648.0, std::min(2147483647.0, values[i] * 1e6));
+        fast.clear();
+        append_int(fast, iv);
+        snprintf(slow, sizeof slow, "%d", iv);
+        same = same && fast == slow;
+        if (!same) {
+            if (bad == 0 && first_bad) *first_bad = values[i];
+            ++bad;
+        }
+    }
+    return bad;
+}
+
 int cafehost_fminsearch_selftest(cafehost_math_fn eq, int n, void* args, const double* x0, double tolx, double tolf, double* xmin,
                                  double* fmin, int* bymax)
 {
@@ -2603,6 +2683,7 @@ int cafehost_fminsearch_selftest(cafehost_math_fn eq, int n, void* args, const d
 void cafehost_destroy(cafehost_session* s)
 {
     if (!s) return;
+    s->drop_prior_job();
     if (s->own_log && s->flog) fclose(s->flog);
     cafehip_destroy(s->ctx);
     if (s->ctx_one) cafehip_destroy(s->ctx_one);
@@ -2613,8 +2694,11 @@ int cafehost_dispatch(cafehost_session* s, const char* command_line)
 {
     if (!s || !command_line) return host_fail("null argument");
     try {
-        return s->dispatch(command_line);
+        const int rc = s->dispatch(command_line);
+        s->drop_prior_job();   // (normally picked up by the command itself)
+        return rc;
     } catch (const std::exception& e) {  // cafe/cafe_commands.cpp:531-535
+        s->drop_prior_job();
         return host_fail(e.what());
     }
 }
@@ -2623,8 +2707,11 @@ int cafehost_run_script(cafehost_session* s, const char* path)
 {
     if (!s || !path) return host_fail("null argument");
     try {
-        return s->run_script(path);
+        const int rc = s->run_script(path);
+        s->drop_prior_job();
+        return rc;
     } catch (const std::exception& e) {
+        s->drop_prior_job();
         return host_fail(e.what());
     }
 }

@@ -53,6 +53,9 @@ int cafehost_poisson_fit_selftest(const int *leaf_sizes, long n, double start, i
                                   int *iters, long *passes);
 typedef double (*cafehost_math_fn)(double *x, void *args);
 double cafehost_pvalue_selftest(double v, const double *sorted_null, int size);
+/* Test hook: the number formatting of the report's per-family lines (std::to_chars, general, precision 6 / integers)
+ * against printf("%g") / printf("%d") on the caller's values; returns the number that differ (0 expected). */
+long cafehost_format_selftest(const double *values, long n, double *first_bad);
 int cafehost_fminsearch_selftest(cafehost_math_fn eq, int n, void *args, const double *x0, double tolx, double tolf,
                                  double *xmin, double *fmin, int *bymax);
 
