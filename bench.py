@@ -280,7 +280,7 @@ class Leg:
         self.barrier()
         t0 = time.perf_counter()
         for s in range(steps):
-            last = self.step(warmup + s, timed=(rank == 0 and s % timing_every == 0))
+            last = self.step(warmup + s, timed=(rank == 0 and s % timing_every == 0 and timing_every < 10 ** 9))
         self.barrier()
         dt = time.perf_counter() - t0
         self.samples_in_region = len(self.kernel_ms)
@@ -314,6 +314,20 @@ class Leg:
         while len(self.kernel_ms) < MIN_KERNEL_SAMPLES:
             self.step(start + extra, timed=True)
             extra += 1
+
+    def sample_pass(self, warmup, steps, rank=0):
+        """The SAME K steps once more, with HIP events around every launch group of every step (rank 0 records; all ranks
+        step, the steps contain the exchange).  Events are not free -- markers between the launches and their collection
+        cost a configs[1] step ~27 us (0.120 -> 0.147 ms with events on every step, profiles/r05/event_sampling_cost.txt) --
+        so the headline pass records none and the kernel durations behind `roofline` come from this pass over the same
+        parameter sets."""
+        self.kernel_ms.clear()
+        self.barrier()
+        for s in range(steps):
+            self.step(warmup + s, timed=(rank == 0))
+        self.barrier()
+        self.samples_in_region = 0
+        self.sample_pass_steps = steps
 
 
 def roofline_of(leg, F_local):
@@ -359,8 +373,12 @@ def roofline_of(leg, F_local):
         "avg_launch_ms": walk_ms,
         "launch_samples": len(km),
         "launch_samples_in_timed_region": leg.samples_in_region,
-        "launch_samples_note": "HIP events on every 8th timed step; the rest (up to %d) on extra steps right after the region"
-                               % MIN_KERNEL_SAMPLES if leg.samples_in_region < MIN_KERNEL_SAMPLES else "all inside the timed region",
+        "launch_samples_note": ("a second pass over the same %d timed steps with HIP events on every step (+ steps right behind it up to "
+                                "%d samples): events cost a step ~27 us, so the pass that times ms_per_step records none (--timing-every N "
+                                "puts them back into it)" % (leg.sample_pass_steps, MIN_KERNEL_SAMPLES)) if getattr(leg, "sample_pass_steps", 0)
+                               else ("HIP events on every %s timed step; the rest (up to %d) on extra steps right after the region"
+                                     % (getattr(leg, "timing_every", 8), MIN_KERNEL_SAMPLES) if leg.samples_in_region < MIN_KERNEL_SAMPLES
+                                     else "all inside the timed region"),
         "min_launch_ms": float((km[:, 1] - km[:, 3]).min()),
         "max_launch_ms": float((km[:, 1] - km[:, 3]).max()),
         "median_launch_ms": float(np.median(km[:, 1] - km[:, 3])),   # (a box hiccup of tens of ms in one sample moves the mean, not this)
@@ -507,6 +525,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the lambda-search wall-clock leg")
     ap.add_argument("--no-probes", action="store_true", help="skip the measured HBM / MFMA ceilings")
+    ap.add_argument("--timing-every", type=int, default=0,
+                    help="0 (default): the pass that times ms_per_step records no kernel events; the kernel durations come from a second "
+                         "pass over the same steps with events on every step.  N > 0: events on every N-th step of the timed pass itself "
+                         "(they cost a configs[1] step ~27 us: profiles/r05/event_sampling_cost.txt)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (configs[3]'s 500k-family table)")
     ap.add_argument("--no-tables", action="store_true", help="skip the test1 / high-turnover table legs")
     ap.add_argument("--backend", default=None, help="torch.distributed backend of --comm torch (default nccl = RCCL; gloo with --same-device)")
@@ -629,7 +651,8 @@ def main():
     priming = leg.prime(fixed_count=(1000 if F_local <= 20000 else 60) if multi else None)
     if os.environ.get("BENCH_FAIL_RANK") == str(rank):
         raise RuntimeError("forced by BENCH_FAIL_RANK (test: rank 0 must still print its line, with an `error` key)")
-    dt, last = leg.run(args.warmup, args.steps, rank=rank)
+    dt, last = leg.run(args.warmup, args.steps, timing_every=args.timing_every if args.timing_every > 0 else 10 ** 9, rank=rank)
+    leg.timing_every = args.timing_every
     per_rank_dt = [dt]
     if multi:
         if args.comm == "native":
@@ -641,6 +664,8 @@ def main():
             per_rank_dt = [float(x) for x in every]
         dt = max(per_rank_dt)
     # the same steps with every parameter set announced one evaluation ahead (all ranks: the steps contain the exchange)
+    if args.timing_every <= 0:
+        leg.sample_pass(args.warmup, args.steps, rank=rank)
     dt_ann, last_ann, ann_stats = leg.run_announced(args.warmup, args.steps)
     eng.set_option("matrix_cache", "")      # (drops the store: the next evaluation builds its matrices itself)
     ann_same = leg.step(args.warmup + 2 + args.steps - 1) == last_ann
@@ -842,7 +867,7 @@ def strong_leg(args, eng, comm, rank, world, local_rank):
     steps, warm = 30, 3
     leg.prepare_rates(warm + steps)
     leg.prime(fixed_count=45 if comm else None)
-    dt, last = leg.run(warm, steps, rank=rank)
+    dt, last = leg.run(warm, steps, timing_every=10 ** 9, rank=rank)   # (no kernel events inside the timed pass)
     if comm is not None and comm["kind"] == "native":
         dt = max(float(np.frombuffer(b, np.float64)[0]) for b in eng.comm_allgather(np.float64(dt).tobytes(), 8))
     elif comm is not None:
@@ -869,7 +894,8 @@ def table_leg(w, local_rank, options=None):
     steps, warm = 100, 5
     leg.prepare_rates(warm + steps + MIN_KERNEL_SAMPLES)
     priming = leg.prime()
-    dt, last = leg.run(warm, steps)
+    dt, last = leg.run(warm, steps, timing_every=10 ** 9)
+    leg.sample_pass(warm, steps)
     leg.extra_kernel_samples(warm + steps)
     roof, credit, kms, desc = roofline_of(leg, len(w.counts))
     res = {"table": w.desc, "families": len(w.counts), "value": len(w.counts) * steps / dt, "unit": "family-evals/s",

@@ -573,7 +573,7 @@ const void* k2_v1_kernel(int nf, bool reference_arithmetic)
 {
     if (reference_arithmetic) {
         switch (nf) {
-            case 16: return reinterpret_cast<const void*>(&k2_prune_v1<16, true>);
+            // (16 families per workgroup needs scratch in this form: not instantiated, the launcher stops at 8)
             case 8: return reinterpret_cast<const void*>(&k2_prune_v1<8, true>);
             case 4: return reinterpret_cast<const void*>(&k2_prune_v1<4, true>);
             case 2: return reinterpret_cast<const void*>(&k2_prune_v1<2, true>);
