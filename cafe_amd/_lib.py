@@ -26,6 +26,7 @@ SIGNATURES = {
     "cafehip_last_setup_ms": (C.c_int, [C.c_void_p, _dp]),
     "cafehip_set_error_model": (C.c_int, [C.c_void_p, C.c_int, _dp, _u8p]),
     "cafehip_eval_posterior": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip, _dp, _ip, _dp]),
+    "cafehip_eval_posterior_sequence": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _ip, C.c_int]),
     "cafehip_eval_posterior_multi": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _ip]),
     "cafehip_eval_clustered_posterior": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp]),
     "cafehip_launch_info": (C.c_int, [C.c_void_p, _ip, _ip]),

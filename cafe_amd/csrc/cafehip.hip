@@ -2556,6 +2556,25 @@ int cafehip_eval_posterior_multi(cafehip_ctx* c, int n_sets, const double* node_
     return 0;
 }
 
+int cafehip_eval_posterior_sequence(cafehip_ctx* c, int n, const double* node_lambda, const double* node_mu, const double* prior,
+                                    double* scores, int32_t* first_zero_family, int sharded)
+{
+    if (!c) return fail("null context");
+    if (n < 0 || (n > 0 && (!node_lambda || !node_mu || !prior || !scores))) return fail("bad argument");
+    // one evaluation after the other, each complete (its score on the host) before the next is staged: exactly the calls a
+    // caller's own loop would make, without the caller's per-call overhead
+    for (int i = 0; i < n; ++i) {
+        const double* nl = node_lambda + (size_t)i * c->n_nodes;
+        const double* nm = node_mu + (size_t)i * c->n_nodes;
+        int32_t fz = -1;
+        const int rc = sharded ? cafehip_eval_posterior_sharded(c, nl, nm, prior, scores + i, &fz)
+                               : cafehip_eval_posterior(c, nl, nm, prior, scores + i, &fz, nullptr, nullptr, nullptr);
+        if (rc != 0) return -1;
+        if (first_zero_family) first_zero_family[i] = fz;
+    }
+    return 0;
+}
+
 int cafehip_eval_clustered_posterior(cafehip_ctx* c, int K, const double* node_lambda, const double* node_mu,
                                      const double* weights, const double* prior, double* score,
                                      int32_t* first_zero_family, double* membership_sums, double* family_map,

@@ -206,6 +206,18 @@ class Engine:
             self._score_ref, self._fz_ref = C.addressof(self._score), C.addressof(self._fz)
         return f
 
+    def get_posterior_sequence(self, node_lambdas, node_mus, prior, sharded=False):
+        """n evaluations one after the other inside ONE foreign call (cafehip_eval_posterior_sequence): node_lambdas /
+        node_mus are [n, n_nodes].  Returns (scores[n], first_zero[n])."""
+        nl = np.ascontiguousarray(node_lambdas, np.float64)
+        nm = np.ascontiguousarray(node_mus, np.float64)
+        pr = np.ascontiguousarray(prior, np.float64)
+        assert nl.ndim == 2 and nl.shape == nm.shape and nl.shape[1] == self.n_nodes
+        scores = np.zeros(nl.shape[0])
+        fz = np.zeros(nl.shape[0], np.int32)
+        _lib.check(self._L.cafehip_eval_posterior_sequence(self._h, nl.shape[0], _d(nl), _d(nm), _d(pr), _d(scores), _i(fz), 1 if sharded else 0))
+        return scores, fz
+
     def get_posterior_multi(self, node_lambdas, node_mus, prior):
         """Several objective evaluations in one pass: node_lambdas / node_mus are [n_sets, n_nodes].
         Returns (scores[n_sets], first_zero[n_sets])."""

@@ -161,6 +161,15 @@ int cafehip_eval_posterior(cafehip_ctx *ctx, const double *node_lambda, const do
  * is beyond the matrix-core kernels. */
 int cafehip_eval_posterior_multi(cafehip_ctx *ctx, int n_sets, const double *node_lambda, const double *node_mu,
                                  const double *prior, double *scores, int32_t *first_zero_family);
+/* n objective evaluations ONE AFTER THE OTHER (set i = node_lambda/node_mu + i * n_nodes, all under `prior`): evaluation i is
+ * complete -- its score on the host, in scores[i] -- before evaluation i + 1 is staged, i.e. exactly n calls of
+ * cafehip_eval_posterior (or, sharded != 0, of cafehip_eval_posterior_sharded on every rank), minus the caller's per-call
+ * overhead.  What it is for: loops whose points are known up front but whose evaluations must not share a pass -- the grid of
+ * `lambda -r` when a table fills the chip (cafe_lambda_distribution, cafe/lambda.cpp:192-231, evaluates its points one by
+ * one), likelihood profiles.  (Measured for bench.py's timed steps in round 5: no faster than one ctypes call per step --
+ * 0.1178 against 0.1154 ms at configs[1] -- so the bench keeps its loop; the entry point saves a caller the loop, not time.) */
+int cafehip_eval_posterior_sequence(cafehip_ctx *ctx, int n, const double *node_lambda, const double *node_mu,
+                                    const double *prior, double *scores, int32_t *first_zero_family, int sharded);
 /* One evaluation of the k-cluster objective (`lambda -k`): cafe_get_clustered_posterior (cafe/cafe_main.c:165-253) over
  * cafe_tree_clustered_likelihood (cafe/cafe_tree.c:704-850).  Cluster k prunes every family with its own rates
  * (node_lambda/node_mu + k * n_nodes; K <= CAFEHIP_MAX_SETS) in the same pass as the other clusters; per family

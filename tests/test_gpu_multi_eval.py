@@ -116,3 +116,20 @@ def test_evaluation_on_addresses_equals_the_array_wrapper():
             eng.address_of(np.arange(10.0)[::2])
     finally:
         eng.close()
+
+
+def test_a_sequence_of_evaluations_in_one_call_equals_the_single_calls():
+    # cafehip_eval_posterior_sequence: n evaluations one after the other inside the library (a `lambda -r` grid on a table
+    # that fills the chip, a likelihood profile): the same calls, the same bits
+    eng, t, rng = _example_engine()
+    try:
+        prior = np.ascontiguousarray(O.prior_poisson(1000, rng.root_min, 9.442907))
+        lams = [0.0017, 0.0031, 0.2, 0.0005, 0.0017]
+        nl = np.array([np.full(t.n_nodes, x) for x in lams])
+        nm = np.full_like(nl, -1.0)
+        singles = [eng.get_posterior(nl[i], nm[i], prior) for i in range(len(lams))]
+        scores, fz = eng.get_posterior_sequence(nl, nm, prior)
+        for i, (s1, z1) in enumerate(singles):
+            assert (scores[i] == s1 or (np.isinf(scores[i]) and np.isinf(s1))) and fz[i] == z1, i
+    finally:
+        eng.close()
