@@ -47,7 +47,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured float4 copy)
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak: 256 CUs x 4 SIMDs x 32 flop/cycle x 2.4 GHz
 MIN_KERNEL_SAMPLES = 16
-TRAFFIC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")]
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")]
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "cafehip_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int)]),
     "cafehip_matrix_size": (C.c_int, [C.c_void_p]),
     "cafehip_prefetch_matrices": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_int]),
+    "cafehip_prearm_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "cafehip_matrix_cache_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "cafehip_reset_birthdeath_cache": (C.c_int, [C.c_void_p, _dp, _dp]),
     "cafehip_set_exact_matrices": (C.c_int, [C.c_void_p, C.c_int]),

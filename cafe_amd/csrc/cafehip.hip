@@ -189,14 +189,18 @@ void fill_key(const cafehip_ctx* c, KeyParam& key, int bl, double lambda, double
 // host part of reset_birthdeath_cache: unique keys over non-root nodes
 // (cafe/cafe_tree.c:374-391, 461-483) -> staged parameter block
 int stage_params(cafehip_ctx* c, const double* node_lambda, const double* node_mu,
-                 const double* prior, int n_sets = 1)
+                 const double* prior, int n_sets = 1, int forced_slot = -1)
 {
     if (c->n_nodes <= 0) return fail("no tree set");
     if (c->M < 0) return fail("no families/ranges set");
     if (n_sets < 1 || n_sets > kMaxSets) return fail("1..%d parameter sets per evaluation, got %d", kMaxSets, n_sets);
-    const int slot = c->ring_pos;
-    c->ring_pos = (c->ring_pos + 1) % kParamRing;
-    HIP_TRY(hipEventSynchronize(c->h_params_ev[slot]));
+    // forced_slot: the block a pre-armed chain will read (arm_next reserved it; its event sits BEHIND that chain and must
+    // not be waited for here -- the chain waits for us)
+    const int slot = forced_slot >= 0 ? forced_slot : c->ring_pos;
+    if (forced_slot < 0) {
+        c->ring_pos = (c->ring_pos + 1) % kParamRing;
+        HIP_TRY(hipEventSynchronize(c->h_params_ev[slot]));
+    }
     EvalHeader* h = c->h_params[slot];
     KeyParam* keys = eval_keys(h);
     int32_t* node_key = eval_node_key(h, c->key_cap);
@@ -1722,21 +1726,22 @@ int ensure_output_sets(cafehip_ctx* c, int n_sets)
 }  // namespace
 
 // (declared in context.hpp: the multi-GPU entry points of cafehip_comm.hip run the same evaluation)
-int cafehip_impl::eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu, const double* prior, double* d_chunk_sums,
-                              int32_t* d_first_zero, bool host_out, int n_sets, bool direct_exchange)
+namespace {
+
+// whether the pruning launch of an objective evaluation has stopped trying wave grids (a pre-armed chain repeats the launch
+// as it is)
+bool k2_settled(const cafehip_ctx* c)
 {
-    if (check_ready(c)) return -1;
-    HIP_TRY(hipSetDevice(c->device));
-    if (n_sets > 1 && ensure_output_sets(c, n_sets)) return -1;
-    if (n_sets > 1 && d_chunk_sums == nullptr) {
-        d_chunk_sums = c->d_chunk_sums;   // (re)allocated above
-    }
-    // the matrices of this set may already be on the device (cafehip_prefetch_matrices): then the nodes are bound to them
-    // and the chain starts at the pruning -- no staging, no K1, no fold.  Only for the calls whose score kernel leaves the
-    // first-zero word reset (the synchronous and the direct-exchange paths), one set at a time.
-    const bool may_bind = n_sets == 1 && (host_out || direct_exchange) && d_first_zero == c->d_first_zero && !c->mc.e.empty();
-    const bool bound = may_bind && mc_bind(c, node_lambda, node_mu, prior) >= 0;
-    if (!bound && stage_params(c, node_lambda, node_mu, prior, n_sets)) return -1;
+    if (c->opt.k2 != 0) return true;
+    if (!c->opt.k2tune || c->opt.mfma != 0 || c->opt.have_cfg16 || c->opt.have_cfg4) return true;
+    return c->tune.n_items == c->Fu && c->tune.locked >= 0 && !c->tune.pending;
+}
+
+// K1 (unless the nodes are bound to matrices built ahead) -> error fold -> table levels -> walk -> score kernel of the
+// evaluation staged in c->cur_params, on the context's stream.  *seq_out: the sequence number its score kernel publishes.
+int launch_chain(cafehip_ctx* c, double* d_chunk_sums, int32_t* d_first_zero, bool host_out, int n_sets, bool direct_exchange, bool bound,
+                 int32_t* seq_out)
+{
     RingGuard ring(c);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (!bound) {
@@ -1792,6 +1797,7 @@ int cafehip_impl::eval_device(cafehip_ctx* c, const double* node_lambda, const d
         x.host = c->h_result;
         x.arrive = c->d_arrive;
         x.seq = ++c->host_seq;
+        if (seq_out) *seq_out = x.seq;
         x.rank = L.rank;
         x.world = L.world;
         x.slots = c->x_slots;
@@ -1816,6 +1822,7 @@ int cafehip_impl::eval_device(cafehip_ctx* c, const double* node_lambda, const d
             k3.host = c->h_result;
             k3.arrive = c->d_arrive;
             k3.seq = ++c->host_seq;
+            if (seq_out) *seq_out = k3.seq;
         }
         // Candidates announced for the NEXT evaluation (cafehip_prefetch_matrices, parked): their matrices are built by the
         // trailing blocks of the score kernel's own launch (k3_score_then_k1_rb), i.e. while the score travels to the host
@@ -1862,6 +1869,121 @@ int cafehip_impl::eval_device(cafehip_ctx* c, const double* node_lambda, const d
     return 0;
 }
 
+// Queue the NEXT evaluation's launches behind a gate (context.hpp, Armed).  The block its K1 will read is reserved now and
+// filled with a copy of the current evaluation's parameters, so that the chain is a valid evaluation whatever happens.
+int arm_next(cafehip_ctx* c, double* d_chunk_sums, int32_t* d_first_zero)
+{
+    if (!c->opt.prearm || c->timing || c->stream != c->own_stream || c->n_chunks <= 0 || c->nkeys <= 0 || !k2_settled(c)) return 0;
+    if (c->mc.pending_sets > 0 || c->mc.requested != c->mc_requested_seen) return 0;   // somebody announces sets: the store serves them
+    if (!c->h_gate) {
+        HIP_TRY(hipHostMalloc((void**)&c->h_gate, 32 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(c->h_gate, 0, 32 * sizeof(unsigned long long));
+    }
+    const int slot = c->ring_pos;
+    c->ring_pos = (c->ring_pos + 1) % kParamRing;
+    HIP_TRY(hipEventSynchronize(c->h_params_ev[slot]));
+    memcpy(c->h_params[slot], c->cur_params, eval_prior_offset(c->key_cap, c->n_nodes));   // header, keys, node -> matrix maps
+    GateArgs g;
+    g.flag = c->h_gate;
+    g.outcome = c->h_gate + 16;
+    g.want = ++c->gate_seq;
+    g.timeout_ticks = 2000000;   // 20 ms of the 100 MHz clock
+    if (launch_kernel(gate_kernel(), dim3(1), dim3(64), 0, c->stream, g)) return -1;
+    c->cur_params = c->h_params[slot];
+    c->cur_slot = slot;
+    c->cur_prior_n = 0;
+    int32_t seq = 0;
+    if (launch_chain(c, d_chunk_sums, d_first_zero, true, 1, false, false, &seq)) {
+        // (the gate is in the queue: let it go, whatever made it behind it runs on the copied block)
+        __atomic_store_n(&c->h_gate[0], g.want, __ATOMIC_RELEASE);
+        return -1;
+    }
+    c->armed.on = true;
+    c->armed.slot = slot;
+    c->armed.nkeys = c->nkeys;
+    c->armed.all_fast = c->all_keys_fast;
+    c->armed.seq = seq;
+    c->armed.gate = g.want;
+    return 0;
+}
+
+}  // namespace
+
+int cafehip_impl::eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu, const double* prior, double* d_chunk_sums,
+                              int32_t* d_first_zero, bool host_out, int n_sets, bool direct_exchange)
+{
+    if (check_ready(c)) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    if (n_sets > 1 && ensure_output_sets(c, n_sets)) return -1;
+    if (n_sets > 1 && d_chunk_sums == nullptr) {
+        d_chunk_sums = c->d_chunk_sums;   // (re)allocated above
+    }
+    // the matrices of this set may already be on the device (cafehip_prefetch_matrices): then the nodes are bound to them
+    // and the chain starts at the pruning -- no staging, no K1, no fold.  Only for the calls whose score kernel leaves the
+    // first-zero word reset (the synchronous and the direct-exchange paths), one set at a time.
+    bool staged = false;
+    if (c->armed.on) {
+        // A chain for exactly this call is waiting behind its gate: stage the parameters into the block it reads and let it
+        // go with one store.  It fits if the evaluation has the shape it was armed with (as many distinct matrices in the same
+        // arithmetic form, the prior already on the device) and the gate has not given up meanwhile.
+        const bool gate_alive = __atomic_load_n(&c->h_gate[16], __ATOMIC_ACQUIRE) != ((c->armed.gate << 2) | 2ull);
+        if (n_sets == 1 && host_out && !direct_exchange && d_first_zero == c->d_first_zero && !c->timing && gate_alive &&
+            c->mc.pending_sets == 0 && c->mc.requested == c->mc_requested_seen) {
+            if (stage_params(c, node_lambda, node_mu, prior, 1, c->armed.slot)) {
+                disarm(c);
+                return -1;
+            }
+            staged = true;
+            if (c->nkeys == c->armed.nkeys && c->all_keys_fast == c->armed.all_fast && c->cur_prior_n == 0) {
+                std::atomic_thread_fence(std::memory_order_release);
+                __atomic_store_n(&c->h_gate[0], c->armed.gate, __ATOMIC_RELEASE);
+                c->armed.on = false;
+                ++c->prearm_used;
+                c->eval_seq = c->armed.seq;
+                c->released_gate = c->armed.gate;
+                c->have_matrices = true;
+                c->mc.bound = -1;
+                if (arm_next(c, d_chunk_sums, d_first_zero)) return -1;
+                return 0;
+            }
+            // another shape: the armed chain runs on what the block holds now (every slot and count in it stays in range) and
+            // its result is ignored; this evaluation is launched the ordinary way behind it, from the same block
+        }
+        disarm(c);
+    }
+    const bool may_bind = !staged && n_sets == 1 && (host_out || direct_exchange) && d_first_zero == c->d_first_zero && !c->mc.e.empty();
+    const bool bound = may_bind && mc_bind(c, node_lambda, node_mu, prior) >= 0;
+    if (!bound && !staged && stage_params(c, node_lambda, node_mu, prior, n_sets)) return -1;
+    int32_t seq = c->host_seq;
+    if (launch_chain(c, d_chunk_sums, d_first_zero, host_out, n_sets, direct_exchange, bound, &seq)) return -1;
+    c->eval_seq = seq;
+    c->released_gate = 0;
+    if (!bound && n_sets == 1 && host_out && !direct_exchange && d_first_zero == c->d_first_zero && arm_next(c, d_chunk_sums, d_first_zero)) return -1;
+    c->mc_requested_seen = c->mc.requested;
+    return 0;
+}
+
+void cafehip_impl::disarm(cafehip_ctx* c)
+{
+    if (!c || !c->armed.on) return;
+    // let it go: its K1 reads the block it was armed with (a copy of the previous evaluation's parameters), the chain
+    // repeats that evaluation and publishes a sequence number nobody waits for
+    std::atomic_thread_fence(std::memory_order_release);
+    __atomic_store_n(&c->h_gate[0], c->armed.gate, __ATOMIC_RELEASE);
+    c->armed.on = false;
+    ++c->prearm_wasted;
+}
+
+bool cafehip_impl::armed_chain_expired(cafehip_ctx* c)
+{
+    if (!c->released_gate) return false;
+    const unsigned long long got = __atomic_load_n(&c->h_gate[16], __ATOMIC_ACQUIRE);
+    const bool expired = got != ((c->released_gate << 2) | 1ull);
+    c->released_gate = 0;
+    if (expired) ++c->prearm_expired;
+    return expired;
+}
+
 // elapsed times of the last evaluation's three launches (blocks until its last event has completed)
 int cafehip_impl::collect_kernel_ms(cafehip_ctx* c)
 {
@@ -1890,7 +2012,7 @@ namespace {
 const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "compress_max_level", "compress_drop_top", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
                                     "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch",
                                     "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "exp_like_host", "matrix_cache",
-                                    "matrix_cache_mb", "prefetch_where", "prefetch_kpb", "comm"};
+                                    "matrix_cache_mb", "prefetch_where", "prefetch_kpb", "prearm", "comm"};
 
 int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
 {
@@ -1942,6 +2064,7 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     else if (key == "walk_lockstep") o.walk_lockstep = iv != 0;
     else if (key == "batch_lockstep_slack") o.batch_lockstep_slack = std::min(std::max(iv, 0), 100);
     else if (key == "exp_like_host") o.exp_like_host = iv != 0;
+    else if (key == "prearm") { disarm(c); o.prearm = iv != 0; return 0; }
     else if (key == "prefetch_kpb") o.prefetch_kpb = std::max(iv, 0);
     else if (key == "prefetch_where") o.prefetch_where = std::min(std::max(iv, 0), 3);
     else if (key == "matrix_cache" || key == "matrix_cache_mb") {
@@ -2045,6 +2168,7 @@ void cafehip_destroy(cafehip_ctx* c)
 {
     if (!c) return;
     hipSetDevice(c->device);
+    disarm(c);
     (void)sync_streams(c);
     for (auto& e : c->mc.e) hipEventDestroy(e.ready);
     if (c->mc.chain_end) hipEventDestroy(c->mc.chain_end);
@@ -2086,6 +2210,7 @@ void cafehip_destroy(cafehip_ctx* c)
     for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev[i]);
     if (c->ev_mid) hipEventDestroy(c->ev_mid);
     hipHostFree(c->h_result);
+    if (c->h_gate) hipHostFree(c->h_gate);
     hipFree(c->d_arrive);
     hipStreamDestroy(c->own_stream);
     delete c;
@@ -2094,6 +2219,7 @@ void cafehip_destroy(cafehip_ctx* c)
 int cafehip_set_option(cafehip_ctx* c, const char* key, const char* value)
 {
     if (!c || !key) return fail("null argument");
+    disarm(c);   // (a pre-armed chain was queued under the old switches)
     return set_option(c, key, value ? value : "");
 }
 
@@ -2119,6 +2245,7 @@ int cafehip_get_option(cafehip_ctx* c, const char* key, char* value, size_t valu
 int cafehip_set_stream(cafehip_ctx* c, void* hip_stream)
 {
     if (!c) return fail("null context");
+    disarm(c);   // (a pre-armed chain waits on this stream)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     // NULL is a real stream in HIP (the legacy default stream, which is also what
@@ -2130,6 +2257,7 @@ int cafehip_set_stream(cafehip_ctx* c, void* hip_stream)
 int cafehip_get_stream(cafehip_ctx* c, void** hip_stream)
 {
     if (!c || !hip_stream) return fail("null argument");
+    disarm(c);   // (a pre-armed chain waits on this stream)
     *hip_stream = (void*)c->stream;
     return 0;
 }
@@ -2138,6 +2266,7 @@ int cafehip_set_tree(cafehip_ctx* c, int n_nodes, const int32_t* parent, const i
                      const int32_t* right, const double* branchlength)
 {
     if (!c) return fail("null context");
+    disarm(c);   // (a pre-armed chain waits on this stream)
     c->tune.n_items = -1;  // a new problem: measure the wave grids again
     if (n_nodes < 3 || (n_nodes & 1) == 0) return fail("a binary tree has an odd number (>= 3) of nodes, got %d", n_nodes);
     if (n_nodes > kMaxNodesCap) return fail("at most %d nodes supported, got %d", kMaxNodesCap, n_nodes);
@@ -2221,6 +2350,7 @@ int cafehip_set_families(cafehip_ctx* c, int F, int n_leaves, const int32_t* cou
                          int root_max)
 {
     if (!c) return fail("null context");
+    disarm(c);   // (a pre-armed chain waits on this stream)
     c->tune.n_items = -1;  // a new problem: measure the wave grids again
     if (F < 0 || n_leaves <= 0 || n_leaves > (kMaxNodesCap + 1) / 2) return fail("bad table shape %d x %d", F, n_leaves);
     if (range_min != 0) return fail("range_min must be 0 (cafe/cafe_family.c:357-364), got %d", range_min);
@@ -2397,6 +2527,7 @@ int cafehip_set_error_model(cafehip_ctx* c, int mfs, const double* errormatrix,
                             const uint8_t* leaf_has_model)
 {
     if (!c) return fail("null context");
+    disarm(c);   // (a pre-armed chain waits on this stream)
     c->tune.n_items = -1;  // a new problem: measure the wave grids again
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2470,7 +2601,7 @@ int cafehip_eval_posterior(cafehip_ctx* c, const double* node_lambda, const doub
     if (c->n_chunks > 0) {
         // spin on the sequence number the last K3 block publishes (a few microseconds after the kernel
         // ends); fall back to a stream query now and then so that a faulted launch cannot hang us
-        const int32_t want = c->host_seq;
+        const int32_t want = c->eval_seq;
         unsigned long spins = 0;
         while (c->h_result->done_seq != want) {
             if ((++spins & 0x3FFFF) == 0) {
@@ -2489,6 +2620,15 @@ int cafehip_eval_posterior(cafehip_ctx* c, const double* node_lambda, const doub
     // the payload below was written before the sequence number (device-side system fence): order our reads after
     // the flag read
     std::atomic_thread_fence(std::memory_order_acquire);
+    if (armed_chain_expired(c)) {
+        // (the gate gave up in the instant the parameters were being staged: the chain ran on a block in flux)
+        const int keep = c->opt.prearm;
+        c->opt.prearm = 0;
+        disarm(c);
+        const int rc = cafehip_eval_posterior(c, node_lambda, node_mu, prior, score, first_zero_family, max_lik, argmax_root, max_post);
+        c->opt.prearm = keep;
+        return rc;
+    }
     if (collect_kernel_ms(c)) return -1;
     // fixed-order final sum over chunks (independent of how chunks were produced)
     double s = 0.0;
@@ -2526,7 +2666,7 @@ int cafehip_eval_posterior_multi(cafehip_ctx* c, int n_sets, const double* node_
     if (n_sets == 1) return cafehip_eval_posterior(c, node_lambda, node_mu, prior, scores, first_zero_family, nullptr, nullptr, nullptr);
     if (eval_device(c, node_lambda, node_mu, prior, nullptr, c->d_first_zero, true, n_sets)) return -1;
     if (c->n_chunks > 0) {
-        const int32_t want = c->host_seq;
+        const int32_t want = c->eval_seq;
         unsigned long spins = 0;
         while (c->h_result->done_seq != want) {
             if ((++spins & 0x3FFFF) == 0) {
@@ -2581,6 +2721,7 @@ int cafehip_eval_clustered_posterior(cafehip_ctx* c, int K, const double* node_l
                                      double* family_membership)
 {
     if (check_ready(c)) return -1;
+    disarm(c);   // (a pre-armed chain waits on this stream)
     if (!node_lambda || !node_mu || !weights || !prior || !score || !membership_sums) return fail("null argument");
     if (K < 1 || K > kMaxSets) return fail("1..%d clusters, got %d", kMaxSets, K);
     if (c->d_err && c->err_mfs < c->range_max)
@@ -2686,6 +2827,15 @@ int cafehip_prefetch_matrices(cafehip_ctx* c, int n_sets, const double* node_lam
     return mc_build(c, n_sets, node_lambda, node_mu);
 }
 
+int cafehip_prearm_stats(cafehip_ctx* c, long out[3])
+{
+    if (!c || !out) return fail("null argument");
+    out[0] = c->prearm_used;
+    out[1] = c->prearm_wasted;
+    out[2] = c->prearm_expired;
+    return 0;
+}
+
 int cafehip_matrix_cache_stats(cafehip_ctx* c, long out[CAFEHIP_MATRIX_CACHE_STATS])
 {
     if (!c || !out) return fail("null argument");
@@ -2704,6 +2854,7 @@ int cafehip_matrix_cache_stats(cafehip_ctx* c, long out[CAFEHIP_MATRIX_CACHE_STA
 int cafehip_reset_birthdeath_cache(cafehip_ctx* c, const double* node_lambda, const double* node_mu)
 {
     if (check_ready(c)) return -1;
+    disarm(c);   // (a pre-armed chain waits on this stream)
     if (!node_lambda || !node_mu) return fail("null argument");
     HIP_TRY(hipSetDevice(c->device));
     if (stage_params(c, node_lambda, node_mu, nullptr)) return -1;
@@ -2715,6 +2866,7 @@ int cafehip_reset_birthdeath_cache(cafehip_ctx* c, const double* node_lambda, co
 int cafehip_set_exact_matrices(cafehip_ctx* c, int on)
 {
     if (!c) return fail("null context");
+    disarm(c);   // (a pre-armed chain waits on this stream)
     if (c->force_exact != (on != 0)) mc_invalidate(c);   // (matrices built ahead of time carry the other form)
     c->force_exact = on != 0;
     return 0;
@@ -2723,6 +2875,7 @@ int cafehip_set_exact_matrices(cafehip_ctx* c, int on)
 int cafehip_get_matrix(cafehip_ctx* c, int node, double* out, int* S_out)
 {
     if (check_ready(c)) return -1;
+    disarm(c);   // (a pre-armed chain waits on this stream)
     if (!c->have_matrices) return fail("no matrices built yet");
     if (node < 0 || node >= c->n_nodes || c->node_key[node] < 0) return fail("node %d has no matrix", node);
     HIP_TRY(hipSetDevice(c->device));
@@ -2740,6 +2893,7 @@ int cafehip_eval_root_likelihoods(cafehip_ctx* c, int B, const int32_t* counts, 
                                   const int32_t* root_hi, const int32_t* col_max, double* out)
 {
     if (check_ready(c)) return -1;
+    disarm(c);   // (a pre-armed chain waits on this stream)
     if (!c->have_matrices) return fail("no matrices built yet (call cafehip_eval_posterior or cafehip_reset_birthdeath_cache)");
     if (B <= 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
@@ -2826,6 +2980,7 @@ int cafehip_viterbi(cafehip_ctx* c, int B, const int32_t* counts, const int32_t*
                     const int32_t* root_hi, const int32_t* col_max, int32_t* node_sizes)
 {
     if (check_ready(c)) return -1;
+    disarm(c);   // (a pre-armed chain waits on this stream)
     if (!c->have_matrices) return fail("no matrices built yet (call cafehip_eval_posterior or cafehip_reset_birthdeath_cache)");
     if (B <= 0) return 0;
     if (!counts || !root_lo || !root_hi || !col_max || !node_sizes) return fail("null argument");
@@ -2936,6 +3091,7 @@ int cafehip_viterbi(cafehip_ctx* c, int B, const int32_t* counts, const int32_t*
 int cafehip_fetch_small(cafehip_ctx* c, const void* d_src, size_t nbytes, const void** host_ptr)
 {
     if (!c) return fail("null context");
+    disarm(c);   // (a pre-armed chain waits on this stream)
     if (!d_src || !host_ptr || nbytes == 0 || (nbytes & 7) || nbytes > (1u << 20)) return fail("bad fetch of %zu bytes", nbytes);
     HIP_TRY(hipSetDevice(c->device));
     const size_t n_words = nbytes / 8;
@@ -2981,6 +3137,7 @@ int cafehip_exp_like_host_selftest(long n, unsigned seed, long* mismatches_fused
 int cafehip_enable_timing(cafehip_ctx* c, int on)
 {
     if (!c) return fail("null context");
+    disarm(c);   // (a pre-armed chain waits on this stream)
     c->timing = on != 0;
     return 0;
 }

@@ -137,6 +137,7 @@ static int comm_pick_mode(cafehip_ctx* c)
 static int comm_realign(cafehip_ctx* c)
 {
     CommLink& L = *c->link;
+    disarm(c);   // (a pre-armed chain of the single-GPU path would hold the stream for its slice)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!L.barrier()) return fail("communicator: %s", L.error.c_str());
     if (L.xbuf) {
@@ -178,6 +179,7 @@ int cafehip_comm_set_blocks(cafehip_ctx* c, const int32_t* block_lo, const int32
         memset((void*)c->h_result, 0, bytes);
         c->h_result_chunks = need;
         c->host_seq = 0;
+        c->eval_seq = 0;
     }
     // direct mode: rows of ranks with fewer chunks must read 0 in the slots they never write.  Everybody is between
     // evaluations here (collective call): clear my buffer between two barriers, sequence numbers back to 0

@@ -174,6 +174,7 @@ struct cafehip_ctx {
         int walk_lockstep = 0;        // the same pacing for the family walk of an objective evaluation
         int batch_lockstep_slack = 0; // ... a generation starts when all but this percentage of the previous ones have finished
         int exp_like_host = 1;        // K1 exact form: exp() as this host's libm computes it, when recognised (exp_like_host.hpp)
+        int prearm = 0;               // the next evaluation's launches queued behind a gate while the current one runs (see Armed)
         int prefetch_kpb = 0;         // ... keys per workgroup of a build on the second stream (0: as k1kpb)
         int prefetch_where = 3;       // matrices ahead of time, parked requests: 3 trailing blocks of the score kernel's launch, 0 second stream at once, 1 the context's stream (behind the score kernel), 2 second stream behind the score kernel
     } opt;
@@ -272,6 +273,23 @@ struct cafehip_ctx {
         std::vector<double> pending_l, pending_m;
         long requested = 0, built = 0, hits = 0, misses = 0, evicted = 0, waited = 0, launches = 0;
     } mc;
+    // ---- pre-armed chain (round 5, option prearm): the NEXT evaluation's launches queued behind a gate kernel while the
+    // current one runs; the next cafehip_eval_posterior stages its parameters into the block the chain reads and releases
+    // the gate with one store.  Only the plain synchronous single-set path, only once the wave grid is settled, only while
+    // nobody announces parameter sets (a search that does is served from the matrix store instead).
+    struct Armed {
+        bool on = false;
+        int slot = 0;                     // ring block its K1 reads
+        int nkeys = 0;
+        bool all_fast = false;
+        int32_t seq = 0;                  // sequence number its score kernel publishes
+        unsigned long long gate = 0;      // value that releases it
+    } armed;
+    unsigned long long* h_gate = nullptr;     // pinned: [0] release word, [16] outcome word (their own cache lines)
+    unsigned long long gate_seq = 0;
+    unsigned long long released_gate = 0;     // gate of the chain the current evaluation rode on (0: launched normally)
+    long mc_requested_seen = 0;               // mc.requested at the previous evaluation
+    long prearm_used = 0, prearm_wasted = 0, prearm_expired = 0;
     const int32_t* cur_node_key = nullptr;   // the node -> matrix map the pruning launches read (d_node_key, or a cache entry's row of it)
     int node_key_rows = 0;                   // rows of d_node_key: kMaxSets demand rows + one per cache entry
     bool fz_clean = false;                   // d_first_zero was left at INT32_MAX by the last score kernel (k3_score<true> / k3_score_x)
@@ -290,7 +308,8 @@ struct cafehip_ctx {
     size_t h_fetch_words = 0;
     int32_t fetch_seq = 0;
     int32_t* d_arrive = nullptr;
-    int32_t host_seq = 0;
+    int32_t host_seq = 0;          // last sequence number handed to a score kernel
+    int32_t eval_seq = 0;          // ... the one the CURRENT evaluation's score kernel publishes (a pre-armed chain behind it holds a later one)
 
     // timing
     bool timing = false, timing_pending = false;
@@ -350,4 +369,8 @@ int eval_device(cafehip_ctx* c, const double* node_lambda, const double* node_mu
                 int32_t* d_first_zero, bool host_out = false, int n_sets = 1, bool direct_exchange = false);
 // elapsed times of the last evaluation's launches (blocks until its last event has completed)
 int collect_kernel_ms(cafehip_ctx* c);
+// a pre-armed chain is let go (it repeats the previous evaluation; its result is ignored): before anything else uses the stream
+void disarm(cafehip_ctx* c);
+// the current evaluation rode on a pre-armed chain whose gate had expired under the host's hands: its result is void
+bool armed_chain_expired(cafehip_ctx* c);
 }  // namespace cafehip_impl

@@ -234,6 +234,15 @@ struct K3xArgs {
     long long timeout_ticks;    // wall_clock64() ticks to wait for the peers before giving up (host sees -seq)
 };
 
+// Gate of a pre-armed launch chain (k_gate, one wave): waits until the host's word equals `want`, at most `timeout_ticks` of
+// the 100 MHz clock, then writes what happened to the host's outcome word: (want << 2) | 1 released, | 2 expired.
+struct GateArgs {
+    const volatile unsigned long long* flag;   // pinned host memory, written by the host
+    volatile unsigned long long* outcome;      // pinned host memory, written by the gate
+    unsigned long long want;
+    long long timeout_ticks;
+};
+
 struct XProbeArgs {   // k_x_probe
     unsigned long long* probe[kXMaxWorld];   // rank r's probe words: [kXMaxWorld]
     int rank, world, mute;

@@ -559,7 +559,14 @@ struct cafehost_session {
     {
         if (exchange || opt_objective_reference) return false;   // (the callback path evaluates asynchronously: it builds on demand)
         if (opt_lookahead >= 0) return opt_lookahead != 0;
-        return true;
+        // Worth it where an evaluation is a chain of launches, not work: the walk is at most two rounds of workgroups.  There
+        // the matrix build is 10-15 % of the chain (configs[1] search -2.4 %, the reference's test1 table -7.9 %); on a table
+        // that fills the chip it is 2-3 %, two or three candidate sets are built per evaluation and the builds behind the
+        // score kernel outlast the host's turn-around: configs[2] / [3] searches measured 3.3 % SLOWER
+        // (profiles/r05_lookahead_ab.txt).
+        int wg = 0, cu = 0;
+        if (cafehip_launch_info(ctx, &wg, &cu) != 0) return false;
+        return wg > 0 && wg <= 2 * cu;
     }
     void lookahead_points(const std::vector<std::vector<double>>& pts)
     {

@@ -311,6 +311,30 @@ __global__ __launch_bounds__(CAFEHIP_CHUNK) void k_x_collect(K3xArgs a)
 }
 
 // ------------------------------------------------------------------------------------
+// Gate of a pre-armed launch chain (round 5).  The launches of the NEXT evaluation are queued behind this one-wave kernel
+// while the current evaluation still runs; the host then starts them with ONE store to pinned memory instead of a launch
+// (tools/gate_probe.hip: 3.9 us from the store to a word written by the released kernel, against 6.4 us for a launch).
+// The wait is bounded: a host that never comes back (the loop ended, another entry point was called without disarming)
+// costs one slice, not a hang -- the chain then runs on the parameter block it was armed with (a copy of the previous
+// evaluation's: a valid, harmless repetition) and the outcome word tells the host that it did.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_gate(GateArgs a)
+{
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    unsigned long long how = 2;
+    for (;;) {
+        if (__hip_atomic_load(a.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == a.want) {
+            how = 1;
+            break;
+        }
+        if (wall_clock64() - t0 > a.timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(a.outcome, (a.want << 2) | how, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ------------------------------------------------------------------------------------
 // Functional probe of the direct exchange, run once per communicator by cafehip_comm_init: lane t stores (nonce | my
 // rank) into word [my rank] of rank t's probe area THROUGH THE PEER MAPPING and waits (bounded) until (nonce | t)
 // stands in word [t] of my own area -- i.e. until rank t's store has really arrived in my memory and is visible to
@@ -593,6 +617,7 @@ const void* k2_v1_kernel(int nf, bool reference_arithmetic)
 const void* k3_kernel(bool host_out) { return host_out ? reinterpret_cast<const void*>(&k3_score<true>) : reinterpret_cast<const void*>(&k3_score<false>); }
 const void* k3x_kernel() { return reinterpret_cast<const void*>(&k3_score_x); }
 const void* kx_collect_kernel() { return reinterpret_cast<const void*>(&k_x_collect); }
+const void* gate_kernel() { return reinterpret_cast<const void*>(&k_gate); }
 const void* kx_probe_kernel() { return reinterpret_cast<const void*>(&k_x_probe); }
 const void* k3_cluster_kernel() { return reinterpret_cast<const void*>(&k3_cluster_score); }
 const void* fetch_small_kernel() { return reinterpret_cast<const void*>(&k_fetch_small); }

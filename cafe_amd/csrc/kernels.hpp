@@ -32,6 +32,7 @@ const void* k2_v1_kernel(int nf, bool reference_arithmetic = false);   // k2_pru
 const void* k3_kernel(bool host_out);      // k3_score<HOST_OUT>(K3Args)
 const void* k3x_kernel();                  // k3_score_x(K3xArgs): score + direct multi-GPU exchange
 const void* kx_collect_kernel();           // k_x_collect(K3xArgs): the exchange's wait alone (host-paced re-poll)
+const void* gate_kernel();                 // k_gate(GateArgs): bounded wait for the host's release word (pre-armed chain)
 const void* kx_probe_kernel();             // k_x_probe(XProbeArgs): functional probe of the peer mappings
 const void* k3_cluster_kernel();           // k3_cluster_score(K3cArgs)
 const void* fetch_small_kernel();          // k_fetch_small(FetchArgs)

@@ -184,6 +184,11 @@ class Engine:
             f = self._fast_pf = C.CFUNCTYPE(C.c_int, vp, C.c_int, vp, vp, C.c_int)(("cafehip_prefetch_matrices", self._L))
         _lib.check(f(self._h, n_sets, addr_lambda, addr_mu, when))
 
+    def prearm_stats(self):
+        out = (C.c_long * 3)()
+        _lib.check(self._L.cafehip_prearm_stats(self._h, out))
+        return {"used": int(out[0]), "let_go": int(out[1]), "expired": int(out[2])}
+
     def matrix_cache_stats(self):
         out = (C.c_long * 8)()
         _lib.check(self._L.cafehip_matrix_cache_stats(self._h, out))

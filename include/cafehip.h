@@ -80,6 +80,8 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *   walk_lockstep   0|1        the same pacing for the family walk of an objective evaluation (0: measured slower)
  *   exp_like_host   0|1        exact-form matrices call exp() as THIS HOST's libm computes it, restated for the device, when
  *                              one of its two builds matches std::exp at first use (1); 0: the device library's exp
+ *   prearm          0|1        the next evaluation's launches queued behind a gate while the current one runs
+ *                              (cafehip_prearm_stats; 0)
  *   matrix_cache    n          entries of the store of matrices built ahead of time (cafehip_prefetch_matrices; 12, 0: off)
  *   matrix_cache_mb n          ... and its size limit in MiB (1024)
  *   comm            auto|direct|rccl   exchange mode of sharded evaluations (multi-GPU section below)
@@ -232,6 +234,15 @@ int cafehip_prefetch_matrices(cafehip_ctx *ctx, int n_sets, const double *node_l
  * not, [4] entries replaced, [5] hits that still had to wait for the build, [6] build launches, [7] entries of the store */
 #define CAFEHIP_MATRIX_CACHE_STATS 8
 int cafehip_matrix_cache_stats(cafehip_ctx *ctx, long out[CAFEHIP_MATRIX_CACHE_STATS]);
+
+/* Pre-armed chain (round 5, option prearm=1; off by default).  While a synchronous single-set evaluation runs, the launches of
+ * the NEXT one -- matrix build, table levels, walk, score kernel -- are queued behind a one-wave gate kernel; the next
+ * cafehip_eval_posterior stages its parameters into the block that chain reads and starts it with one store to pinned memory
+ * instead of a launch.  Same kernels on the same inputs: identical values.  The gate waits at most 20 ms (then the chain
+ * repeats the previous evaluation and its result is ignored), every other entry point lets a waiting chain go first, and a
+ * chain is armed only once the wave grid of the table is settled and while nobody announces parameter sets.
+ * out = {evaluations that rode on a pre-armed chain, chains let go unused, chains whose gate expired under a release}. */
+int cafehip_prearm_stats(cafehip_ctx *ctx, long out[3]);
 
 /* Rebuild the matrices for (node_lambda, node_mu) without scoring
  * (== reset_birthdeath_cache alone, cafe/cafe_main.c:319-326). */

@@ -4,7 +4,7 @@ two rocprofv3 passes per workload (FETCH_SIZE and WRITE_SIZE cannot share a pass
 --kernel-trace only (the PMC guidance of /opt/skills/guides/MI355X_MICROARCH.md).  On gfx950 FETCH_SIZE tallies
 128-byte requests at 64 bytes: it is doubled; WRITE_SIZE is taken as reported -- both factors measured on known-bytes
 kernels with this walk's access patterns (profiles/r03_fetch_size_calibration.txt: x2.000 / x1.000).  Writes
-<out>/<ROUND_TAG, default r04>_pmc_traffic.json (keys "<config>:<families per launch>:<k2|mcnull>") and a text summary.
+<out>/<ROUND_TAG, default r05>_pmc_traffic.json (keys "<config>:<families per launch>:<k2|mcnull>") and a text summary.
 
     python tools/collect_pmc.py [out_dir]          (on the GPU box; needs rocprofv3)"""
 import glob
@@ -79,7 +79,7 @@ def main():
                      % ("%s:%d:%s" % (cfg, F, kind), kname[:60], n, fetch_kib, 2 * fetch_kib, write_kib, traffic / 1e6,
                         t_fetch, t_write, tables / 1e6))
         print(lines[-1], flush=True)
-    tag = os.environ.get("ROUND_TAG", "r04")
+    tag = os.environ.get("ROUND_TAG", "r05")
     json.dump(res, open(os.path.join(out_dir, tag + "_pmc_traffic.json"), "w"), indent=1)
     open(os.path.join(out_dir, tag + "_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
 

@@ -15,10 +15,13 @@ done
 (timeout 900 python bench.py --gpus 2 --same-device --no-cpu-baseline --no-search --no-probes > $O/bench_cfg2_2rank_same_device.json 2> $O/bench_2rank.err; echo "rc=$?" >> $O/bench_2rank.err)
 cd /tmp && rm -rf /tmp/kt && (timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -o r -- python $R/bench.py --no-cpu-baseline --no-search --no-probes --no-strong --no-tables > $O/kernel_stats_cfg2_bench_line.json 2>$O/kt.err); cd $R
 DB=$(find /tmp/kt -name "*.db" | head -1)
-python tools/rocpd_stats.py $DB > $O/kernel_stats_cfg2.txt 2>&1; python tools/step_timeline.py $DB 150 > $O/timeline_cfg2.txt 2>&1; cat $O/timeline_cfg2.txt
+python tools/rocpd_stats.py $DB > $O/kernel_stats_cfg2.txt 2>&1; python tools/chain_timeline.py $DB 2000 > $O/timeline_cfg2.txt 2>&1; cat $O/timeline_cfg2.txt
 for c in cfg3 cfg4; do
 cd /tmp && rm -rf /tmp/kt2 && (timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o r -- python $R/bench.py --config $c --steps 60 --no-cpu-baseline --no-search --no-probes > $O/kt_bench_line_$c.json 2>$O/kt_$c.err); cd $R
-python tools/rocpd_stats.py $(find /tmp/kt2 -name "*.db" | head -1) > $O/kernel_stats_$c.txt 2>&1; python tools/step_timeline.py $(find /tmp/kt2 -name "*.db" | head -1) 40 > $O/timeline_$c.txt 2>&1
+python tools/rocpd_stats.py $(find /tmp/kt2 -name "*.db" | head -1) > $O/kernel_stats_$c.txt 2>&1; python tools/chain_timeline.py $(find /tmp/kt2 -name "*.db" | head -1) 400 > $O/timeline_$c.txt 2>&1
 done
 (CAFEHOST_TIMING=1 timeout 600 python tools/cfg5_pipeline_time.py 100000 > $O/cfg5_pipeline.txt 2>&1)
 (timeout 2400 python tools/collect_pmc.py $O/pmc > $O/pmc.log 2>&1; echo "rc=$?" >> $O/pmc.log); tail -7 $O/pmc.log | cut -c1-300
+# round 5: searches with / without the matrices of the optimiser's next points built ahead of time; the N = 8 dry run
+(timeout 900 python tools/lookahead_ab.py cfg2 test1 cfg3 cfg4 example --reps 4 2>&1 | grep -v WARNING > $O/lookahead_ab.txt); cat $O/lookahead_ab.txt
+(timeout 1500 tools/first_node.sh --same-device > $O/first_node_dry_run.txt 2>&1); tail -12 $O/first_node_dry_run.txt
