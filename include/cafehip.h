@@ -81,7 +81,7 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *   exp_like_host   0|1        exact-form matrices call exp() as THIS HOST's libm computes it, restated for the device, when
  *                              one of its two builds matches std::exp at first use (1); 0: the device library's exp
  *   prearm          0|1        the next evaluation's launches queued behind a gate while the current one runs
- *                              (cafehip_prearm_stats; 0)
+ *                              (cafehip_prearm_stats; 1)
  *   matrix_cache    n          entries of the store of matrices built ahead of time (cafehip_prefetch_matrices; 12, 0: off)
  *   matrix_cache_mb n          ... and its size limit in MiB (1024)
  *   comm            auto|direct|rccl   exchange mode of sharded evaluations (multi-GPU section below)
@@ -235,7 +235,7 @@ int cafehip_prefetch_matrices(cafehip_ctx *ctx, int n_sets, const double *node_l
 #define CAFEHIP_MATRIX_CACHE_STATS 8
 int cafehip_matrix_cache_stats(cafehip_ctx *ctx, long out[CAFEHIP_MATRIX_CACHE_STATS]);
 
-/* Pre-armed chain (round 5, option prearm=1; off by default).  While a synchronous single-set evaluation runs, the launches of
+/* Pre-armed chain (round 5, option prearm, on by default for tables whose walk is at most two rounds of workgroups).  While a synchronous single-set evaluation runs, the launches of
  * the NEXT one -- matrix build, table levels, walk, score kernel -- are queued behind a one-wave gate kernel; the next
  * cafehip_eval_posterior stages its parameters into the block that chain reads and starts it with one store to pinned memory
  * instead of a launch.  Same kernels on the same inputs: identical values.  The gate waits at most 20 ms (then the chain
