@@ -14,7 +14,7 @@ LIB = os.path.join(LIBDIR, "libcafehip.so")
 # translation units of libcafehip.so: compiled in parallel into cafe_amd/lib/obj/, relinked when any object changes
 SOURCES = ["cafehip.hip", "cafehip_comm.hip", "k1_matrices.hip", "k2_walk16.hip", "k2_walk4.hip", "k2c_tables.hip", "k_misc.hip",
            os.path.join("host", "cafe_host.cpp")]
-HEADERS = ["context.hpp", "exp_like_host.hpp", "exp_like_host_table.inc", "device_types.hpp", "kernels.hpp", "comm.hpp", "k2_mfma.hpp", "host_math.hpp", "schedule.hpp",
+HEADERS = ["context.hpp", "matrix_store.hpp", "compression_plan.hpp", "k2_launch.hpp", "k3_device.hpp", "exp_like_host.hpp", "exp_like_host_table.inc", "device_types.hpp", "kernels.hpp", "comm.hpp", "k2_mfma.hpp", "host_math.hpp", "schedule.hpp",
            os.path.join("host", "tree_table.hpp"), os.path.join("host", "nelder_mead.hpp"), os.path.join("host", "glibc_rand.hpp"),
            os.path.join("host", "poisson_prior.hpp"), os.path.join("host", "host_util.hpp"),
            os.path.join("..", "..", "include", "cafehip.h"), os.path.join("..", "..", "include", "cafehost.h")]
