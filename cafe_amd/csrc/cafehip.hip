@@ -464,6 +464,7 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     else if (key == "batch_lockstep_slack") o.batch_lockstep_slack = std::min(std::max(iv, 0), 100);
     else if (key == "exp_like_host") o.exp_like_host = iv != 0;
     else if (key == "prearm") { disarm(c); o.prearm = iv != 0; return 0; }
+    else if (key == "test_stall_ms") { o.test_stall_ms = std::max(iv, 0); return 0; }   // test hook: the host sleeps before it looks for the score
     else if (key == "prefetch_kpb") o.prefetch_kpb = std::max(iv, 0);
     else if (key == "prefetch_where") o.prefetch_where = std::min(std::max(iv, 0), 3);
     else if (key == "matrix_cache" || key == "matrix_cache_mb") {
@@ -1000,18 +1001,37 @@ int cafehip_eval_posterior(cafehip_ctx* c, const double* node_lambda, const doub
     if (c->n_chunks > 0) {
         // spin on the sequence number the last K3 block publishes (a few microseconds after the kernel
         // ends); fall back to a stream query now and then so that a faulted launch cannot hang us
+        if (c->opt.test_stall_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(c->opt.test_stall_ms));   // (tests: a host kept off its core)
         const int32_t want = c->eval_seq;
+        // A chain armed behind this evaluation repeats it (its block is a copy of this one's) and publishes the NEXT number:
+        // if this thread was kept off its core for longer than the gate waits (20 ms: a loaded host), the repetition has run
+        // and its number stands where ours was -- same chunk sums, same first-zero index, same per-family values.  Accept it
+        // (found by the round-5 soak run: "score kernel finished without publishing its result").
+        bool repetition_ran = false;
+        auto published = [&]() {
+            const int32_t d = c->h_result->done_seq;
+            if (d == want) return true;
+            if (c->armed.on && d == c->armed.seq) {
+                repetition_ran = true;
+                return true;
+            }
+            return false;
+        };
         unsigned long spins = 0;
-        while (c->h_result->done_seq != want) {
+        while (!published()) {
             if ((++spins & 0x3FFFF) == 0) {
                 hipError_t q = hipStreamQuery(c->stream);
                 if (q == hipSuccess) {
-                    if (c->h_result->done_seq != want) HIP_TRY(hipStreamSynchronize(c->stream));
-                    if (c->h_result->done_seq != want) return fail("score kernel finished without publishing its result");
+                    if (!published()) HIP_TRY(hipStreamSynchronize(c->stream));
+                    if (!published()) return fail("score kernel finished without publishing its result");
                     break;
                 }
                 if (q != hipErrorNotReady) return fail("stream error while waiting: %s", hipGetErrorString(q));
             }
+        }
+        if (repetition_ran) {
+            c->armed.on = false;   // (it is spent)
+            ++c->prearm_wasted;
         }
     } else {
         HIP_TRY(hipStreamSynchronize(c->stream));

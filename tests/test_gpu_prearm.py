@@ -73,3 +73,21 @@ def test_other_calls_between_evaluations_and_an_expired_gate():
     assert st["used"] >= 2 and st["let_go"] >= 3, st
     eng.close()
     ref.close()
+
+
+def test_a_host_kept_off_its_core_longer_than_the_gate_waits():
+    # found by the round-5 soak run: the thread that waits for the score is descheduled for more than the gate's 20 ms, the
+    # chain armed behind the evaluation expires, runs as a repetition of it and publishes the NEXT sequence number where
+    # the evaluation's own stood.  The repetition carries the same values: the call must return them, not fail.
+    eng, tree, rng, prior = _table(F=1200)
+    ref, _, _, _ = _table(F=1200, prearm=0)
+    nl, nm = _rates(tree, 6, seed=9)
+    eng.set_option("test_stall_ms", 45)
+    for i in range(6):
+        a = eng.get_posterior(nl[i], nm[i], prior, per_family=True)
+        b = ref.get_posterior(nl[i], nm[i], prior, per_family=True)
+        assert a[0] == b[0] and a[1] == b[1] and all(np.array_equal(x, y) for x, y in zip(a[2:], b[2:])), i
+    st = eng.prearm_stats()
+    assert st["let_go"] >= 4 and st["used"] == 0, st      # every armed chain expired behind its evaluation
+    eng.close()
+    ref.close()
