@@ -74,6 +74,7 @@ HOST_SIGNATURES = {
     "cafehost_format_selftest": (C.c_long, [_dp, C.c_long, _dp]),
     "cafehost_pvalue_selftest": (C.c_double, [C.c_double, _dp, C.c_int]),
     "cafehost_fminsearch_selftest": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _dp, C.c_double, C.c_double, _dp, _dp, C.POINTER(C.c_int)]),
+    "cafehost_lookahead_selftest": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _dp, C.c_double, C.c_double, _dp, _dp, C.POINTER(C.c_long)]),
     "cafehost_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "cafehost_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "cafehost_shard_bounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

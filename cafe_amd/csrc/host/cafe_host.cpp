@@ -2687,6 +2687,53 @@ int cafehost_fminsearch_selftest(cafehost_math_fn eq, int n, void* args, const d
     return pfm.iters;
 }
 
+// Test hook (host only): the same minimisation with the look-ahead hook installed.  out = {evaluations, evaluations whose
+// point was among the twelve most recently announced before the PREVIOUS evaluations (bit for bit), announcements, points}.
+int cafehost_lookahead_selftest(cafehost_math_fn eq, int n, void* args, const double* x0, double tolx, double tolf, double* xmin,
+                                double* fmin, long out[4])
+{
+    if (!eq || !x0 || !xmin || !fmin || !out || n < 1) return host_fail("bad argument");
+    FMinSearch pfm;
+    pfm.init(n);
+    pfm.tolx = tolx;
+    pfm.tolf = tolf;
+    std::vector<double> x(n);
+    // what the device store would hold: the points of the announcements made before earlier evaluations, the twelve most
+    // recent ones (an announcement made before THIS evaluation is built beside it and serves the next)
+    std::vector<std::vector<double>> pending, store;
+    long evals = 0, covered = 0, calls = 0, points = 0;
+    pfm.lookahead = [&](const std::vector<std::vector<double>>& pts) {
+        pending = pts;
+        ++calls;
+        points += (long)pts.size();
+    };
+    pfm.eq = [&](const double* p) {
+        std::copy(p, p + n, x.begin());
+        for (const auto& q : store)
+            if (std::equal(q.begin(), q.end(), p)) {
+                ++covered;
+                break;
+            }
+        ++evals;
+        for (const auto& q : pending) {
+            bool have = false;
+            for (const auto& r : store) have = have || r == q;
+            if (!have) store.push_back(q);
+        }
+        pending.clear();
+        while (store.size() > 12) store.erase(store.begin());
+        return eq(x.data(), args);
+    };
+    pfm.minimize(x0);
+    std::copy(pfm.v[0].begin(), pfm.v[0].end(), xmin);
+    *fmin = pfm.fv[0];
+    out[0] = evals;
+    out[1] = covered;
+    out[2] = calls;
+    out[3] = points;
+    return pfm.iters;
+}
+
 void cafehost_destroy(cafehost_session* s)
 {
     if (!s) return;

@@ -58,6 +58,11 @@ double cafehost_pvalue_selftest(double v, const double *sorted_null, int size);
 long cafehost_format_selftest(const double *values, long n, double *first_bad);
 int cafehost_fminsearch_selftest(cafehost_math_fn eq, int n, void *args, const double *x0, double tolx, double tolf,
                                  double *xmin, double *fmin, int *bymax);
+/* Test hook: the same minimisation with the look-ahead hook installed (FMinSearch::lookahead, the points announced before
+ * each evaluation for the one after it).  out = {evaluations, evaluations whose point had been announced -- compared bit for
+ * bit --, announcements, points announced}; the trajectory must be the plain one's. */
+int cafehost_lookahead_selftest(cafehost_math_fn eq, int n, void *args, const double *x0, double tolx, double tolf,
+                                double *xmin, double *fmin, long out[4]);
 
 /* ---- multi-GPU (one process per GPU) ------------------------------------------------------------
  * Every rank runs the same script (same seed => same Nelder-Mead decisions); a rank scores only its
