@@ -82,6 +82,11 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *                              one of its two builds matches std::exp at first use (1); 0: the device library's exp
  *   prearm          0|1        the next evaluation's launches queued behind a gate while the current one runs
  *                              (cafehip_prearm_stats; 1)
+ *   prefetch_where  0..3       where the builds of announced parameter sets run: 3 trailing blocks of the score kernel's
+ *                              launch (default), 0 second stream at once, 1 the context's stream behind the score kernel,
+ *                              2 second stream behind an event (A/B runs: profiles/r05/matrices_ahead_of_time_ab.txt)
+ *   prefetch_kpb    n          matrices per workgroup of a build on the second stream (0: as k1kpb)
+ *   test_stall_ms   n          test hook: cafehip_eval_posterior sleeps n ms before it looks for the score (0)
  *   matrix_cache    n          entries of the store of matrices built ahead of time (cafehip_prefetch_matrices; 12, 0: off)
  *   matrix_cache_mb n          ... and its size limit in MiB (1024)
  *   comm            auto|direct|rccl   exchange mode of sharded evaluations (multi-GPU section below)
