@@ -270,8 +270,10 @@ int launch_chain(cafehip_ctx* c, double* d_chunk_sums, int32_t* d_first_zero, bo
 int arm_next(cafehip_ctx* c, double* d_chunk_sums, int32_t* d_first_zero)
 {
     if (!c->opt.prearm || c->timing || c->stream != c->own_stream || c->n_chunks <= 0 || c->nkeys <= 0 || !k2_settled(c)) return 0;
-    // worth a microsecond per evaluation (115.3 -> 114.3 us at configs[1], profiles/r05/prearm_ab.txt): only where an evaluation
-    // is short -- a chain let go unused repeats a whole evaluation, which a table that fills the chip should not pay
+    // worth a microsecond per evaluation inside a steady loop (115.3 -> 114.3 us at configs[1], profiles/r05/prearm_ab.txt) and
+    // only where an evaluation is short -- a chain let go unused repeats a whole evaluation.  Off by default: the END of a loop
+    // pays (the next synchronisation of the stream waits out the gate's slice: bench.py's 100-step table legs measured
+    // +0.2 ms per step = one 20 ms slice behind their closing barrier)
     if (c->k2_grid <= 0 || c->k2_grid > 2 * std::max(c->n_cu, 1)) return 0;
     if (c->mc.pending_sets > 0 || c->mc.requested != c->mc_requested_seen) return 0;   // somebody announces sets: the store serves them
     if (!c->h_gate) {

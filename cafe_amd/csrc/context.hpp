@@ -176,7 +176,7 @@ struct cafehip_ctx {
         int batch_lockstep_slack = 0; // ... a generation starts when all but this percentage of the previous ones have finished
         int exp_like_host = 1;        // K1 exact form: exp() as this host's libm computes it, when recognised (exp_like_host.hpp)
         int test_stall_ms = 0;        // test hook: cafehip_eval_posterior sleeps this long before it looks for the score
-        int prearm = 1;               // the next evaluation's launches queued behind a gate while the current one runs (see Armed)
+        int prearm = 0;               // the next evaluation's launches queued behind a gate while the current one runs (see Armed)
         int prefetch_kpb = 0;         // ... keys per workgroup of a build on the second stream (0: as k1kpb)
         int prefetch_where = 3;       // matrices ahead of time, parked requests: 3 trailing blocks of the score kernel's launch, 0 second stream at once, 1 the context's stream (behind the score kernel), 2 second stream behind the score kernel
     } opt;

@@ -81,7 +81,7 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *   exp_like_host   0|1        exact-form matrices call exp() as THIS HOST's libm computes it, restated for the device, when
  *                              one of its two builds matches std::exp at first use (1); 0: the device library's exp
  *   prearm          0|1        the next evaluation's launches queued behind a gate while the current one runs
- *                              (cafehip_prearm_stats; 1)
+ *                              (cafehip_prearm_stats; 0)
  *   prefetch_where  0..3       where the builds of announced parameter sets run: 3 trailing blocks of the score kernel's
  *                              launch (default), 0 second stream at once, 1 the context's stream behind the score kernel,
  *                              2 second stream behind an event (A/B runs: profiles/r05/matrices_ahead_of_time_ab.txt)
@@ -240,7 +240,8 @@ int cafehip_prefetch_matrices(cafehip_ctx *ctx, int n_sets, const double *node_l
 #define CAFEHIP_MATRIX_CACHE_STATS 8
 int cafehip_matrix_cache_stats(cafehip_ctx *ctx, long out[CAFEHIP_MATRIX_CACHE_STATS]);
 
-/* Pre-armed chain (round 5, option prearm, on by default for tables whose walk is at most two rounds of workgroups).  While a synchronous single-set evaluation runs, the launches of
+/* Pre-armed chain (round 5, option prearm=1; OFF by default -- worth 1 us per evaluation inside a steady loop, but the loop's end
+ * pays for it: whoever synchronises the stream next waits out the gate's 20 ms or a repeated evaluation).  While a synchronous single-set evaluation runs, the launches of
  * the NEXT one -- matrix build, table levels, walk, score kernel -- are queued behind a one-wave gate kernel; the next
  * cafehip_eval_posterior stages its parameters into the block that chain reads and starts it with one store to pinned memory
  * instead of a launch.  Same kernels on the same inputs: identical values.  The gate waits at most 20 ms (then the chain
