@@ -411,7 +411,7 @@ namespace {
 // (name, what it selects) -- cafehip_set_option; the same names upper-cased behind CAFEHIP_ are read from the
 // environment ONCE, when the context is created (tools/ sweeps), never during an evaluation
 const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "compress_max_level", "compress_drop_top", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
-                                    "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch",
+                                    "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch", "k2c_pair", "k2c_pair_min",
                                     "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "exp_like_host", "matrix_cache",
                                     "matrix_cache_mb", "prefetch_where", "prefetch_kpb", "prearm", "comm"};
 
@@ -460,6 +460,8 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     else if (key == "ldspark") o.ldspark = val.empty() ? -1 : iv;
     else if (key == "vitlds") o.vitlds = iv != 0;
     else if (key == "k2c_batch") o.k2c_batch = iv != 0;
+    else if (key == "k2c_pair") o.k2c_pair = val.empty() ? -1 : iv;
+    else if (key == "k2c_pair_min") o.k2c_pair_min = std::max(iv, 0);
     else if (key == "batch_trim") o.batch_trim = iv != 0;
     else if (key == "batch_lockstep") o.batch_lockstep = iv != 0;
     else if (key == "walk_lockstep") o.walk_lockstep = iv != 0;

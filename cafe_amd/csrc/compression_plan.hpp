@@ -30,11 +30,29 @@ int upload_col_has_err(cafehip_ctx* c)
     return 0;
 }
 
-// wave rows / row tiles per wave of k2c_nodes for this matrix side: one wave per row tile up to 16 waves
-// (0: matrix too large, no compression)
-int k2c_wave_rows(const cafehip_ctx* c, int* nrt_w)
+// Paired row tiles for a level of `n_tiles` workgroups (k2c_nodes<.., PAIR>): two row tiles per wave, read as ONE 16-byte load
+// per lane and k-step (the even and the odd rows of 32) -- half the vector-memory instructions of the product and half the
+// waves per tile, so that four tiles instead of two are resident per CU and one tile's set-up hides behind the others'
+// products.  Worth 8-11 % of the table launches where a level is many rounds of tiles (configs[2..4]); a level of a small
+// table is ONE round and lasts as long as its slowest wave, which then carries two tiles instead of one (configs[1]: +17 %).
+// Option k2c_pair: -1 = by level size (default: at least `k2c_pair_min` tiles per CU), 0 = never, 1 = always.
+bool k2c_pairs(const cafehip_ctx* c, long long n_tiles)
 {
     const int RT = (c->C + 15) / 16;
+    if (RT < 2 || RT > 32 || (c->LD & 1) || c->opt.k2c_pair == 0) return false;
+    if (c->opt.k2c_pair > 0) return true;
+    return n_tiles >= (long long)c->opt.k2c_pair_min * std::max(c->n_cu, 1);
+}
+
+// wave rows / row tiles per wave of k2c_nodes for this matrix side: one wave per row tile up to 16 waves, or one wave per
+// PAIR of row tiles (0: matrix too large, no compression)
+int k2c_wave_rows(const cafehip_ctx* c, int* nrt_w, bool pair = false)
+{
+    const int RT = (c->C + 15) / 16;
+    if (pair) {
+        *nrt_w = 2;
+        return (RT + 1) / 2;
+    }
     const int wr = std::min(RT, 16);
     *nrt_w = (RT + wr - 1) / wr;
     return *nrt_w <= 2 ? wr : 0;   // (matrix sides up to 512; beyond, the plain walk)

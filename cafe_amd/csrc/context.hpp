@@ -170,6 +170,8 @@ struct cafehip_ctx {
         int ldspark = -1;             // park buffers kept in LDS (< 0: by residency)
         int vitlds = 0;               // Viterbi argmax tables in LDS
         int k2c_batch = 1;            // k2c_nodes: the child columns of a state gathered in one batch (round 3)
+        int k2c_pair = -1;            // k2c_nodes: two row tiles per wave read with one 16-byte load per k-step: -1 by level size, 0 never, 1 always (round 5)
+        int k2c_pair_min = 2;         // ... by level size: at least this many tiles per CU (crossover between 427 and 586 tiles on 256 CUs)
         int batch_trim = 1;           // batch mode: a tile's products stop at its largest column limit (round 3)
         int batch_lockstep = 1;       // batch mode: workgroups start generation by generation (L2 reuse of the edge matrices)
         int walk_lockstep = 0;        // the same pacing for the family walk of an objective evaluation

@@ -51,8 +51,6 @@ int launch_compressed_levels(cafehip_ctx* c, int n_sets)
         HIP_TRY(hipMemsetAsync(p.d_tables, 0, need * sizeof(double), c->stream));   // row padding beyond the tiles stays zero
         p.tables_cap = need;
     }
-    int nrt_w = 0;
-    const int wr = k2c_wave_rows(c, &nrt_w);
     K2cArgs a;
     memset(&a, 0, sizeof a);
     a.PT = c->d_PT;
@@ -74,7 +72,10 @@ int launch_compressed_levels(cafehip_ctx* c, int n_sets)
         a.tiles = p.d_tiles + first;
         const int nft = p.level_nft[l];
         slots += (double)n_tiles * nft;
-        if (launch_k2c_inst(c, k2c_kernel(nft, nrt_w, c->opt.k2c_batch != 0), nft, a, n_tiles, n_sets, 64 * wr)) return -1;
+        const bool pair = k2c_pairs(c, (long long)n_tiles * n_sets);
+        int nrt_w = 0;
+        const int wr = k2c_wave_rows(c, &nrt_w, pair);
+        if (launch_k2c_inst(c, k2c_kernel(nft, nrt_w, c->opt.k2c_batch != 0, pair), nft, a, n_tiles, n_sets, 64 * wr)) return -1;
     }
     const double kpad = 4.0 * ((c->C + 3) / 4), rows = 16.0 * ((c->C + 15) / 16);
     c->issued_tables = 2.0 * kpad * rows * 16.0 * slots * n_sets;

@@ -117,6 +117,9 @@ __device__ __forceinline__ void k2_region_pattern()
 typedef const double __attribute__((address_space(1))) * k2_gptr;
 typedef const char __attribute__((address_space(1))) * k2_gbytes;
 typedef const double __attribute__((address_space(3))) * k2_lptr;
+// two adjacent matrix rows in one 16-byte load (PAIR products: a wave's two row tiles are the even and the odd rows of 32)
+typedef double cafe_d2 __attribute__((ext_vector_type(2)));
+typedef const cafe_d2 __attribute__((address_space(1))) * k2_gptr2;
 
 // keeps the 32-bit lane offset a 32-bit value at the load (hoisted out of the loop and widened there, it would
 // cost a 64-bit vector add per load instead of the scalar-base addressing mode)
@@ -174,7 +177,15 @@ __device__ __forceinline__ k2_gbytes k2_uniform(const double* p)
 
 #define CAFE_K2_LOAD(slot, koff)                                                                               \
     {                                                                                                          \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[slot][j] = *(k2_gptr)(bk + vo[j]);                   \
+        if constexpr (PAIR_) {                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < NT / 2; ++j) {                                               \
+                const cafe_d2 v2 = *(k2_gptr2)(bk + vo[j]);                                                    \
+                bq[slot][2 * j] = v2.x;                                                                        \
+                bq[slot][2 * j + 1] = v2.y;                                                                    \
+            }                                                                                                  \
+        } else {                                                                                               \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) bq[slot][j] = *(k2_gptr)(bk + vo[j]);               \
+        }                                                                                                      \
         bk += kstride_bytes;                                                                                   \
         _Pragma("unroll") for (int i = 0; i < NA_; ++i) aq[slot][i] = pa[i][(koff) * 4];                       \
     }
@@ -182,7 +193,7 @@ __device__ __forceinline__ k2_gbytes k2_uniform(const double* p)
     {                                                                                                          \
         CAFE_K2_LOAD(((u) + D - 1) % D, (u) + D - 1)                                                           \
         CAFE_K2_MFMA((u) % D)                                                                                  \
-        k2_region_pattern<NT, NA_, NA_ * NT, DS_FIRST_>();                                                                \
+        k2_region_pattern<(PAIR_ ? NT / 2 : NT), NA_, NA_ * NT, DS_FIRST_>();                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
 #define CAFE_K2_REGION_N(u)                                                                                    \
@@ -191,12 +202,19 @@ __device__ __forceinline__ k2_gbytes k2_uniform(const double* p)
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
 
-template <int NFT_W, int NRT_W, int NT, int D>
+// PAIR (k2c_nodes on levels of many tiles, round 5): the NT (even) row tiles of the wave are read as NT / 2 16-byte loads, lane
+// li of a pair holding rows 2 li and 2 li + 1 of the pair's 32: voff[0 .. NT/2) are the pairs' lane offsets, accumulator
+// column 2 q carries the even rows of pair q and column 2 q + 1 the odd rows.  Half the vector-memory instructions for the
+// same bytes; every accumulator still sees the same operands in the same k order.  (The family walk with the same dealing,
+// gathers and stores included, measured 6.7 % SLOWER at configs[2] and 8 % at configs[3]: profiles/r05/walk16_paired_tiles_ab.txt.)
+template <int NFT_W, int NRT_W, int NT, int D, bool PAIR = false>
 __device__ __forceinline__ void mfma_edge_p(k2_gbytes sb, const unsigned (&voff)[NRT_W], unsigned kstride_bytes,
                                             const double* ap, int astride, int ksteps, cafe_d4 (&acc)[NFT_W][NRT_W])
 {
+    static_assert(!PAIR || NT % 2 == 0, "paired loads carry two row tiles each");
     constexpr int NA_ = NFT_W;
     constexpr bool DS_FIRST_ = true;
+    constexpr bool PAIR_ = PAIR;
     k2_lptr pa[NFT_W];
 #pragma unroll
     for (int i = 0; i < NFT_W; ++i) pa[i] = (k2_lptr)ap + i * astride;
@@ -214,6 +232,7 @@ __device__ __forceinline__ void mfma4_edge_p(k2_gbytes sb, const unsigned (&voff
 {
     constexpr int NA_ = G;
     constexpr bool DS_FIRST_ = false;
+    constexpr bool PAIR_ = false;
     k2_lptr pa[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) pa[g] = (k2_lptr)ap4 + (4 * g) * LDv;
@@ -1074,7 +1093,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 #endif
 constexpr int K2C_GATHER_MAX = 6;   // vector slices per thread kept in registers (LDv <= 6 * threads per state, else a loop)
 
-template <int NFT_W, int NRT_W, bool BATCH>
+template <int NFT_W, int NRT_W, bool BATCH, bool PAIR = false>
 __global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
 {
     extern __shared__ double Lbuf[];   // [16 * NFT_W][LDv]
@@ -1188,7 +1207,15 @@ __global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
             unsigned voff[NRT_W];
 #pragma unroll
             for (int j = 0; j < NRT_W; ++j) voff[j] = (unsigned)(lk * a.LD + li + ((j < ntile) ? (rt0 + j) : rt0) * 16) * 8u;
-            if constexpr (NRT_W > 1) {
+            if constexpr (PAIR) {
+                static_assert(!PAIR || NRT_W == 2, "pairs: two row tiles per wave");
+                if (ntile == 2) {
+                    voff[0] = (unsigned)(lk * a.LD + 2 * li + rt0 * 16) * 8u;   // rows rt0 * 16 + 2 li, + 1: one 16-byte load
+                    mfma_edge_p<NFT_W, NRT_W, 2, CAFE_K2C_DEPTH, true>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+                } else {   // (the last wave of an odd number of row tiles)
+                    mfma_edge_p<NFT_W, NRT_W, 1, CAFE_K2C_DEPTH>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
+                }
+            } else if constexpr (NRT_W > 1) {
                 if (ntile == NRT_W - 1)
                     mfma_edge_p<NFT_W, NRT_W, NRT_W - 1, CAFE_K2C_DEPTH>(sb, voff, kstride_bytes, ap, 16 * a.LDv, a.ksteps, fac);
                 else
@@ -1209,7 +1236,7 @@ __global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
 #pragma unroll
             for (int j = 0; j < NRT_W; ++j) {
                 if (j < ntile) {
-                    const int row = (rt0 + j) * 16 + li;
+                    const int row = (PAIR && ntile == 2) ? rt0 * 16 + 2 * li + j : (rt0 + j) * 16 + li;
                     out[(size_t)f * a.LD + row] = (row < a.C) ? fac[i][j][r] : 0.0;
                 }
             }

@@ -4,8 +4,12 @@
 
 namespace cafehip {
 
-const void* k2c_kernel(int nft_w, int nrt_w, bool batch_gathers)
+const void* k2c_kernel(int nft_w, int nrt_w, bool batch_gathers, bool pair)
 {
+    if (pair) {
+        if (nft_w == 1 && nrt_w == 2) return batch_gathers ? reinterpret_cast<const void*>(&k2c_nodes<1, 2, true, true>) : reinterpret_cast<const void*>(&k2c_nodes<1, 2, false, true>);
+        return nullptr;
+    }
     if (nft_w == 1 && nrt_w == 1) return batch_gathers ? reinterpret_cast<const void*>(&k2c_nodes<1, 1, true>) : reinterpret_cast<const void*>(&k2c_nodes<1, 1, false>);
     if (nft_w == 1 && nrt_w == 2) return batch_gathers ? reinterpret_cast<const void*>(&k2c_nodes<1, 2, true>) : reinterpret_cast<const void*>(&k2c_nodes<1, 2, false>);
     return nullptr;

@@ -25,7 +25,7 @@ const void* k2_mfma16_kernel(int nft_w, int nrt_w);
 const void* k2_mfma4_kernel(int G, int nrt_w);
 
 // k2c_tables.hip: factor tables of compressed subtrees, K2cArgs (batch_gathers: the child columns of a state in one batch)
-const void* k2c_kernel(int nft_w, int nrt_w, bool batch_gathers);
+const void* k2c_kernel(int nft_w, int nrt_w, bool batch_gathers, bool pair);
 
 // k_misc.hip
 const void* k2_v1_kernel(int nf, bool reference_arithmetic = false);   // k2_prune_v1<NF, REF>(K2Args), NF in {1, 2, 4, 8, 16}

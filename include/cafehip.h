@@ -73,6 +73,10 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *   ldspark         n          park buffers kept in LDS (empty: by residency)
  *   vitlds          0|1        Viterbi argmax tables in LDS (0: global scratch)
  *   k2c_batch       0|1        factor-table kernel gathers the child columns of a state in one batch (1)
+ *   k2c_pair        -1|0|1     factor-table kernel deals a wave TWO row tiles and reads both with one 16-byte load per k-step
+ *                              (half the vector-memory instructions, four tiles resident per CU instead of two): -1 = on levels
+ *                              of at least k2c_pair_min tiles per CU (default), 0 = never, 1 = always.  Bit-identical either way
+ *   k2c_pair_min    n          ... tiles per CU from which a level uses pairs (2)
  *   batch_trim      0|1        batch mode: a tile's products stop at its largest column limit (1)
  *   batch_lockstep  0|1        batch mode: workgroups start generation by generation, a generation = as many as the
  *                              chip holds at once, so that co-resident tiles stream the same edge matrix through L2 (1)

@@ -173,3 +173,42 @@ def test_plan_follows_tables_trees_and_error_models_through_one_context():
         assert ra[0] == rb[0] and ra[1] == rb[1]
         for x, y in zip(ra[2:], rb[2:]):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("max_size", [40, 70, 100])   # matrix sides 41 / 71 / 101 -> 3 / 5 / 7 row tiles (odd: a lone last tile)
+@pytest.mark.parametrize("with_error", [False, True])
+def test_paired_row_tiles_of_the_table_kernel_change_no_bit(max_size, with_error):
+    """Round 5: on levels of many tiles k2c_nodes deals a wave two row tiles and reads both with one 16-byte load per
+    k-step (option k2c_pair: -1 by level size, 0 never, 1 always).  Same operands in the same order per accumulator:
+    forced on and forced off must agree bit for bit, for even and odd numbers of row tiles, with and without an error model,
+    for one parameter set and for several."""
+    import cafe_amd
+    t = O.PyTree(NEWICK)
+    counts = _table(5000, t.n_leaves, 5, top=min(max_size - 1, 25))
+    rng_tuple = (0, max_size, 1, max_size - 10)
+    prior = O.prior_poisson(1000, 1, 2.0)
+    lam = np.full(t.n_nodes, 0.015)
+    mu = np.full(t.n_nodes, 0.011)
+    sets = (np.stack([lam, 1.3 * lam, 0.6 * lam]), np.stack([mu, mu, 1.2 * mu]))
+    outs = {}
+    for pair in (0, 1):
+        eng = cafe_amd.Engine(0)
+        try:
+            eng.set_option("k2c_pair", pair)
+            eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+            eng.set_families(counts, cafe_amd.FamilySizeRange(*rng_tuple))
+            if with_error:
+                from cafe_amd import synth
+                eng.set_error_model(synth.banded_error_matrix(max_size), None)
+            one = eng.get_posterior(lam, mu, prior, per_family=True)
+            many = eng.get_posterior_multi(sets[0], sets[1], prior)
+            assert "compressed(" in eng.describe()
+            outs[pair] = (one, many)
+        finally:
+            eng.close()
+    (s0, fz0, ml0, am0, mp0), m0 = outs[0]
+    (s1, fz1, ml1, am1, mp1), m1 = outs[1]
+    assert s0 == s1 and fz0 == fz1
+    assert np.array_equal(ml0, ml1) and np.array_equal(am0, am1) and np.array_equal(mp0, mp1)
+    for x, y in zip(m0, m1):
+        assert np.array_equal(np.asarray(x), np.asarray(y))

@@ -57,6 +57,16 @@ def main():
         cols = [(st[:, :, k].max(axis=1) - t0).mean() for k in range(1, 7)]
         # (s_memtime counters of different XCDs are not synchronised: only differences inside a tile mean anything)
         print("%5d %6d %6d | %s | %9.0f" % (level, grid, waves, " ".join("%9.0f" % c for c in cols), cols[-1]))
+        if os.environ.get("K2C_STAMPS_DETAIL"):
+            # per wave, from the wave's OWN start: how long each stage takes once the wave runs, and how far apart the waves of a
+            # tile start
+            own = [(st[:, :, k] - st[:, :, 0]) for k in range(1, 7)]
+            skew = (st[:, :, 0].max(axis=1) - t0)
+            print("      launch skew inside a tile: mean %.0f  p50 %.0f  p90 %.0f  max %.0f" % (skew.mean(), np.percentile(skew, 50), np.percentile(skew, 90), skew.max()))
+            print("      per wave from its own start (mean / p10 / p90): " + "  ".join(
+                "%s %.0f/%.0f/%.0f" % (names[k], own[k].mean(), np.percentile(own[k], 10), np.percentile(own[k], 90)) for k in range(6)))
+            seg = [own[0]] + [own[k] - own[k - 1] for k in range(1, 6)]
+            print("      per wave, stage by stage (mean): " + "  ".join("%s %.0f" % (names[k], seg[k].mean()) for k in range(6)))
         level += 1
 
 
