@@ -384,7 +384,7 @@ def roofline_of(leg, F_local):
         "median_launch_ms": float(np.median(km[:, 1] - km[:, 3])),   # (a box hiccup of tens of ms in one sample moves the mean, not this)
         "families_per_launch": F_local,
         "factor_tables": None if not compressed else {
-            "kernel": "k2c_nodes (v_mfma_f64_16x16x4): one launch per compression level, 16 states per workgroup",
+            "kernel": "k2c_nodes (v_mfma_f64_16x16x4): one launch per compression level, 16 states per workgroup; levels of at least 2 tiles per CU deal a wave two row tiles read with one 16-byte load (option k2c_pair)",
             "launches_per_evaluation": int(re.search(r"levels=(\d+)", desc).group(1)),
             "states": int(re.search(r"states=(\d+)", desc).group(1)),
             "ms_per_evaluation": tables_ms,
