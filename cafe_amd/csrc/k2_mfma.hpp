@@ -1233,10 +1233,21 @@ __global__ __launch_bounds__(1024) void k2c_nodes(K2cArgs a)
         for (int r = 0; r < 4; ++r) {
             const int f = i * 16 + lk + 4 * r;
             if (f >= n_live) continue;
+            if constexpr (PAIR) {
+                if (ntile == 2) {
+                    // the two rows of a pair side by side: one 16-byte store per lane (LD, the tables' offsets and the row are even)
+                    const int row = rt0 * 16 + 2 * li;
+                    cafe_d2 v2;
+                    v2.x = (row < a.C) ? fac[i][0][r] : 0.0;
+                    v2.y = (row + 1 < a.C) ? fac[i][1][r] : 0.0;
+                    *reinterpret_cast<cafe_d2*>(out + (size_t)f * a.LD + row) = v2;
+                    continue;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NRT_W; ++j) {
                 if (j < ntile) {
-                    const int row = (PAIR && ntile == 2) ? rt0 * 16 + 2 * li + j : (rt0 + j) * 16 + li;
+                    const int row = (rt0 + j) * 16 + li;
                     out[(size_t)f * a.LD + row] = (row < a.C) ? fac[i][j][r] : 0.0;
                 }
             }
