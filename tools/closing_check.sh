@@ -1,11 +1,16 @@
-mkdir -p gpurun_out/final3
-export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q > gpurun_out/final3/pytest_gpu.txt 2>&1; tail -3 gpurun_out/final3/pytest_gpu.txt
-python bench.py --steps 20 --warmup 5 > gpurun_out/final3/bench_cfg2.json 2> gpurun_out/final3/bench_cfg2.err; tail -c 300 gpurun_out/final3/bench_cfg2.err
-for c in cfg3 cfg4 cfg5; do python bench.py --config $c --steps 60 --warmup 5 --no-search --no-tables --no-strong > gpurun_out/final3/bench_$c.json 2>/dev/null; done
-python - <<'PY'
-import json
-for c in ("cfg2","cfg3","cfg4","cfg5"):
-    d=json.load(open("gpurun_out/final3/bench_%s.json"%c)); r=d["roofline"]; ft=r.get("factor_tables") or {}
-    print(c, "step %.4f ms value %.2f M/s walk %.4f frac %.3f tables %.4f frac %.3f whole %.3f" % (d["ms_per_step"], d["value"]/1e6, r["avg_launch_ms"], r["frac"], ft.get("ms_per_evaluation",0), ft.get("frac",0), r["whole_evaluation"]["frac"]), d.get("mc_null",{}).get("launch_ms"))
-PY
+#!/bin/bash
+# After a change that touches only the table kernel of the large tables: the GPU suite, smoke, the bench lines of every
+# configuration, rocprofv3 kernel stats + timelines of cfg3 / cfg4 and the PMC traffic passes again (a subset of tools/final_pass.sh;
+# everything lands under gpurun_out/final/).
+mkdir -p gpurun_out/final; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/final; R=$GRAFT_REPO_ROOT
+(timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log); tail -2 $O/smoke.log
+(timeout 2700 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log); tail -4 $O/pytest_gpu.log | cut -c1-200
+(timeout 900 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err; echo "rc=$?" >> $O/bench_cfg2.err); head -c 200 $O/bench_cfg2.json; echo
+for c in cfg3 cfg4 cfg5; do
+  (timeout 900 python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; echo "rc=$?" >> $O/bench_$c.err); head -c 200 $O/bench_$c.json; echo
+done
+for c in cfg3 cfg4; do
+cd /tmp && rm -rf /tmp/kt2 && (timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o r -- python $R/bench.py --config $c --steps 60 --no-cpu-baseline --no-search --no-probes > $O/kt_bench_line_$c.json 2>$O/kt_$c.err); cd $R
+python tools/rocpd_stats.py $(find /tmp/kt2 -name "*.db" | head -1) > $O/kernel_stats_$c.txt 2>&1; python tools/chain_timeline.py $(find /tmp/kt2 -name "*.db" | head -1) 400 > $O/timeline_$c.txt 2>&1
+done
+(timeout 2400 python tools/collect_pmc.py $O/pmc > $O/pmc.log 2>&1; echo "rc=$?" >> $O/pmc.log); tail -7 $O/pmc.log | cut -c1-300
