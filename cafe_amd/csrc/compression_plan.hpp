@@ -108,6 +108,10 @@ int rebuild_compression(cafehip_ctx* c)
         const bool bushy = 2 * (height[c->root] - 1) <= n_internal - 1;
         if (bushy && Fu < 10 * std::max(c->n_cu, 1)) theta = 1.0;
         else if (bushy && Fu < 32 * std::max(c->n_cu, 1)) theta = 0.8;
+        // round 5, with the paired table kernel: a LARGE table on a narrow matrix is served as well by 0.7 as a wide one
+        // (151-wide, 160 k rows: 0.663 -> 0.644 ms; 62.5 k rows on 64 taxa: 1.444 -> 1.438; 40 k rows: the same plan either
+        // way; profiles/r05/theta_sweep2_paired_tables.txt)
+        else if (c->C < 200 && Fu >= 160 * std::max(c->n_cu, 1)) theta = 0.7;
     }
     if (c->opt.compress_theta >= 0) theta = std::min(c->opt.compress_theta, 1.0);
     const size_t limit = (size_t)(theta * Fu);
