@@ -235,7 +235,8 @@ int launch_chain(cafehip_ctx* c, double* d_chunk_sums, int32_t* d_first_zero, bo
             K1Plan P;
             st.L.stream = c->stream;
             if (plan_k1_block(c, st.L, P)) return -1;
-            if (P.register_blocked) {
+            // (the score blocks inherit K1's LDS and launch bounds: only where they are one round of the chip -- ADVICE r05)
+            if (P.register_blocked && c->n_chunks <= std::max(c->n_cu, 1)) {
                 K3K1Args f;
                 f.k3 = k3;
                 f.k1 = P.a;

@@ -35,6 +35,14 @@
 #include <string>
 #include <vector>
 
+// (see "RCCL, resolved on demand" below: the real header, where the toolchain has one, checks the hand-declared ABI)
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define CAFEHIP_HAVE_RCCL_HEADER 1
+#endif
+#endif
+
 namespace cafehip {
 
 constexpr int kCommMaxWorld = 16;          // ranks of one node (xGMI: 8 GPUs)
@@ -52,10 +60,20 @@ inline double comm_timeout_s()
 }
 
 // ---- RCCL, resolved on demand -----------------------------------------------------------------------------------
+// The library is dlopen'ed (a build box or a one-GPU box need not have it), so the few types and constants of its ABI that
+// cross the function pointers below are declared by hand -- and, wherever the toolchain ships <rccl/rccl.h> (this image does),
+// the header itself is compiled in instead and the hand-written values are checked against it.
+#ifdef CAFEHIP_HAVE_RCCL_HEADER
+static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes in the hand-declared ABI (kCommIdBytes)");
+static_assert((int)ncclSuccess == 0 && (int)ncclChar == 0 && (int)ncclDouble == 8, "hand-declared RCCL constants");
+static_assert(sizeof(ncclDataType_t) == sizeof(int) && sizeof(ncclResult_t) == sizeof(int), "enums travel as int through the function pointers");
+#else
 typedef struct ncclComm* ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 enum { ncclSuccess = 0 };
 enum { ncclChar = 0, ncclDouble = 8 };
+#endif
+static_assert(sizeof(ncclUniqueId) == 128, "the id travels in kCommIdBytes = 128 bytes");
 
 struct RcclApi {
     void* lib = nullptr;

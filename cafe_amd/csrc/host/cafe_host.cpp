@@ -342,12 +342,11 @@ struct cafehost_session {
     void begin_prior_fit()
     {
         if (prior_job.started || !opt_prior_file.empty()) return;
-        prior_job.started = true;
         prior_job.error = nullptr;
         prior_job.fit = PoissonFit();
         const double start = unifrnd();
         const bool look = opt_prior_lookahead != 0;
-        prior_job.worker = std::thread([this, start, look] {
+        auto body = [this, start, look] {
             try {
                 std::vector<int> leaf_sizes;  // collect_leaf_sizes :789-806
                 const int ns = (int)fam.species.size();
@@ -362,7 +361,14 @@ struct cafehost_session {
             } catch (...) {
                 prior_job.error = std::current_exception();
             }
-        });
+        };
+        // (started only once there is a worker -- or a finished fit: a thread that cannot be created runs the fit inline)
+        try {
+            prior_job.worker = std::thread(body);
+        } catch (const std::system_error&) {
+            body();
+        }
+        prior_job.started = true;
     }
     // a command that failed between starting the fit and picking it up must not leave it to the next command
     void drop_prior_job()

@@ -31,6 +31,10 @@ int ensure_matrix_storage(cafehip_ctx* c, size_t min_keys = 0)
     if (c->d_PT && c->pt_keys_cap >= need_keys && c->mc.slots_allocated == mc_slots(c)) return 0;
     if (sync_streams(c)) return -1;
     mc_invalidate(c);
+    // the buffer moves and is zero-filled: whatever was built on demand is gone too (a later cafehip_get_matrix, root-likelihood
+    // or Viterbi call must rebuild instead of reading zeros -- ADVICE r05)
+    c->have_matrices = false;
+    c->fold_current = false;
     hipFree(c->d_PT);
     c->d_PT = nullptr;
     const size_t keep = std::max(need_keys, c->pt_keys_cap);

@@ -243,3 +243,23 @@ def test_a_search_on_a_table_that_fills_the_chip_with_an_error_model():
             sh.close()
     assert out[0][0] == out[1][0]
     assert out[1][1]["hits"] >= 0.9 * (out[1][0][3] - 1), out[1][1]
+
+
+def test_moving_the_matrix_storage_forgets_the_matrices_built_on_demand():
+    """resizing the store of sets built ahead (option matrix_cache) reallocates and zero-fills the matrix buffer; the
+    matrices an ordinary evaluation left there are gone, so cafehip_get_matrix must refuse (or rebuild), never hand out zeros."""
+    eng, tree, rng, prior = _table(options=(("matrix_cache", 0),))
+    nl, nm = _sets(tree, 1)
+    eng.get_posterior(nl[0], nm[0], prior)
+    before = eng.get_matrix(2)
+    assert before.sum() > 0
+    eng.set_option("matrix_cache", 4)
+    try:
+        after = eng.get_matrix(2)
+    except RuntimeError:
+        after = None
+    assert after is None or np.array_equal(after, before)
+    # and the next evaluation rebuilds: same matrix again
+    eng.get_posterior(nl[0], nm[0], prior)
+    assert np.array_equal(eng.get_matrix(2), before)
+    eng.close()

@@ -39,6 +39,15 @@ fi
 echo "== 1. rank-per-device parity test (skips on one GPU)"
 timeout 900 python -m pytest tests/test_gpu_comm.py -q -x -k "distinct_devices or one_device" 2>&1 | tail -3
 
+echo "== 1b. RCCL first (the mode north_star names, and the one the default direct exchange leaves least exercised): N=2 with --comm-mode rccl"
+if [ -z "$SAME" ] && [ "$N_MAX" -ge 2 ]; then
+  timeout 900 python bench.py --gpus 2 --comm-mode rccl --steps 20 --warmup 5 --no-cpu-baseline --no-tables --no-search --no-probes --no-strong \
+      > $OUT/bench_2_rccl.json 2> $OUT/bench_2_rccl.err
+  echo "   rc=$?: $(python -c "import json,sys; d=json.load(open('$OUT/bench_2_rccl.json')); x=d.get('exchange') or {}; print(d.get('error') or ('%.4f ms/step, mode %s, rccl_ranks %s' % (d['ms_per_step'], x.get('mode'), d.get('rccl_ranks'))))" 2>&1 | tail -1)"
+else
+  echo "   skipped (RCCL refuses two ranks on one device)"
+fi
+
 echo "== 2. bench.py --gpus N"
 for n in 1 2 4 8; do
   [ "$n" -gt "$N_MAX" ] && continue
