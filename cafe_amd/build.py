@@ -12,9 +12,12 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcafehip.so")
 
 # translation units of libcafehip.so: compiled in parallel into cafe_amd/lib/obj/, relinked when any object changes
-SOURCES = ["cafehip.hip", "cafehip_comm.hip", "k1_matrices.hip", "k2_walk16.hip", "k2_walk4.hip", "k2c_tables.hip", "k_misc.hip",
+SOURCES = ["cafehip.hip", "cafehip_comm.hip", "k1_matrices.hip", "k2_walk16.hip", "k2_walk4.hip", "k2c_tables.hip", "k2c_gemm.hip", "k_misc.hip",
            os.path.join("host", "cafe_host.cpp")]
-HEADERS = ["context.hpp", "matrix_store.hpp", "compression_plan.hpp", "k2_launch.hpp", "k3_device.hpp", "exp_like_host.hpp", "exp_like_host_table.inc", "device_types.hpp", "kernels.hpp", "comm.hpp", "k2_mfma.hpp", "host_math.hpp", "schedule.hpp",
+# per-unit flags: k2c_gemm keeps its accumulators in VGPRs (with 256 registers per lane the compiler otherwise shuttles them
+# between AGPRs inside the chunk loop and VGPRs across its back edge: 128 moves per chunk)
+UNIT_FLAGS = {"k2c_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+HEADERS = ["k2c_gemm.hpp", "context.hpp", "matrix_store.hpp", "compression_plan.hpp", "k2_launch.hpp", "k3_device.hpp", "exp_like_host.hpp", "exp_like_host_table.inc", "device_types.hpp", "kernels.hpp", "comm.hpp", "k2_mfma.hpp", "host_math.hpp", "schedule.hpp",
            os.path.join("host", "tree_table.hpp"), os.path.join("host", "nelder_mead.hpp"), os.path.join("host", "glibc_rand.hpp"),
            os.path.join("host", "poisson_prior.hpp"), os.path.join("host", "host_util.hpp"),
            os.path.join("..", "..", "include", "cafehip.h"), os.path.join("..", "..", "include", "cafehost.h")]
@@ -58,7 +61,7 @@ def build(force=False, verbose=False):
         path = os.path.join(CSRC, src)
         obj = os.path.join(OBJDIR, os.path.basename(src).rsplit(".", 1)[0] + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header):
-            jobs.append([hipcc()] + CFLAGS + os.environ.get("CAFEHIP_EXTRA_CFLAGS", "").split() + ["-c", "-o", obj, path])
+            jobs.append([hipcc()] + CFLAGS + UNIT_FLAGS.get(src, []) + os.environ.get("CAFEHIP_EXTRA_CFLAGS", "").split() + ["-c", "-o", obj, path])
     if verbose:
         for j in jobs:
             print(" ".join(j))

@@ -412,7 +412,7 @@ namespace {
 // (name, what it selects) -- cafehip_set_option; the same names upper-cased behind CAFEHIP_ are read from the
 // environment ONCE, when the context is created (tools/ sweeps), never during an evaluation
 const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "compress_max_level", "compress_drop_top", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
-                                    "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch", "k2c_pair", "k2c_pair_min",
+                                    "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch", "k2c_pair", "k2c_pair_min", "k2c_gemm", "k2c_nst", "k2c_xcd",
                                     "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "exp_like_host", "matrix_cache",
                                     "matrix_cache_mb", "prefetch_where", "prefetch_kpb", "prearm", "comm"};
 
@@ -463,6 +463,13 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
     else if (key == "k2c_batch") o.k2c_batch = iv != 0;
     else if (key == "k2c_pair") o.k2c_pair = val.empty() ? -1 : iv;
     else if (key == "k2c_pair_min") o.k2c_pair_min = std::max(iv, 0);
+    else if (key == "k2c_gemm") { o.k2c_gemm = val.empty() ? -1 : iv; replan = true; }
+    else if (key == "k2c_nst") {
+        if (!(iv == 0 || iv == 1 || iv == 2 || iv == 4)) return fail("option k2c_nst: 0 (by level size) | 1 | 2 | 4, got '%s'", val.c_str());
+        o.k2c_nst = iv;
+        replan = true;
+    }
+    else if (key == "k2c_xcd") o.k2c_xcd = iv != 0;
     else if (key == "batch_trim") o.batch_trim = iv != 0;
     else if (key == "batch_lockstep") o.batch_lockstep = iv != 0;
     else if (key == "walk_lockstep") o.walk_lockstep = iv != 0;

@@ -254,10 +254,33 @@ int rebuild_compression(cafehip_ctx* c)
     // tiles, level by level (children's tables are complete before a level starts)
     p.level_first.assign(1, 0);
     p.level_nft.clear();
+    p.level_nrt.clear();
     for (int l = 1; l <= n_levels; ++l) {
-            // 16 states per tile: 32- and 64-state tiles (a half / a quarter of the workgroups and of the matrix re-reads)
-        // measured 2-30 % slower at every bench shape -- fewer, longer workgroups fill the chip worse
-        const int nft = 1;
+        // k2c_nodes: 16 states per tile (32- and 64-state tiles of THAT kernel -- a half / a quarter of the workgroups and of
+        // the matrix re-reads, but the whole node vectors gathered up front -- measured 2-30 % slower at every bench shape).
+        // k2c_gemm (round 6): 16 * nft states per tile with the node vectors formed chunk by chunk; large tiles only where the
+        // level still gives every CU a couple of them.
+        int nft = 1, nrt = 0;
+        {
+            long long states = 0, tiles16 = 0;
+            for (int v = 0; v < n; ++v)
+                if (comp[v] && level[v] == l) { states += D[v]; tiles16 += (D[v] + 15) / 16; }
+            const int RT = (c->C + 15) / 16, n_cu = std::max(c->n_cu, 1);
+            const bool gemm = c->opt.k2c_gemm > 0 || c->opt.k2c_gemm < 0;
+            if (gemm && RT <= 32 && !(c->LD & 1)) {
+                const bool pair = RT >= 2 && (RT > 16 || c->opt.k2c_pair > 0 || (c->opt.k2c_pair < 0 && tiles16 >= (long long)c->opt.k2c_pair_min * n_cu));
+                nrt = pair ? 2 : 1;
+                const int waves = (RT + nrt - 1) / nrt;
+                // Measured (profiles/r06/k2c_gemm_ab.txt): what pays is a tile whose gathers are ONE 16-byte slot per thread
+                // (256 * nft slots over 64 * waves threads) -- 32-state tiles on a 251-wide matrix (8 waves: -10 % against
+                // k2c_nodes), 16-state tiles on a 151-wide one (5 waves: -9 %).  A second slot per thread costs the registers
+                // of a resident wave per SIMD, and 64-state tiles measured 4-30 % SLOWER than 16-state ones everywhere: a
+                // level is bound by the tiles in flight per CU, not by the matrix operand's bytes.
+                nft = c->opt.k2c_nst > 0 ? c->opt.k2c_nst : ((states >= 64LL * n_cu && waves >= 8) ? 2 : 1);
+                while (nft > waves) nft >>= 1;   // (at most 4 gather slots per thread)
+                nft = std::max(nft, 1);
+            }
+        }
         const int ts = 16 * nft;
         for (int v = 0; v < n; ++v) {
             if (!comp[v] || level[v] != l) continue;
@@ -282,6 +305,7 @@ int rebuild_compression(cafehip_ctx* c)
         }
         p.level_first.push_back((int)p.tiles.size());
         p.level_nft.push_back(nft);
+        p.level_nrt.push_back(nrt);
     }
     // the reduced tree's leaves and the walk's index table
     std::vector<char> under(n, 0);   // strictly below a compressed node

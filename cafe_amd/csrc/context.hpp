@@ -142,6 +142,7 @@ struct cafehip_ctx {
         std::vector<cafehip::CTile> tiles;
         std::vector<int> level_first;       // tiles of level l: [level_first[l], level_first[l + 1])
         std::vector<int> level_nft;         // ... of 16 * level_nft[l] states each
+        std::vector<int> level_nrt;         // ... built by k2c_gemm with this many row tiles per wave (1 | 2), 0: by k2c_nodes
         cafehip::CTile* d_tiles = nullptr;
         int32_t* d_table_off = nullptr;     // [n_nodes]
         size_t table_elems = 0;             // per parameter set
@@ -171,6 +172,9 @@ struct cafehip_ctx {
         int vitlds = 0;               // Viterbi argmax tables in LDS
         int k2c_batch = 1;            // k2c_nodes: the child columns of a state gathered in one batch (round 3)
         int k2c_pair = -1;            // k2c_nodes: two row tiles per wave read with one 16-byte load per k-step: -1 by level size, 0 never, 1 always (round 5)
+        int k2c_gemm = -1;            // factor tables by k2c_gemm (round 6): -1 by level size, 0 never (k2c_nodes), 1 always
+        int k2c_nst = 0;              // ... state tiles of 16 per workgroup: 0 by level size, else 1 | 2 | 4
+        int k2c_xcd = 1;              // ... XCD x takes a contiguous eighth of a level's tiles
         int k2c_pair_min = 2;         // ... by level size: at least this many tiles per CU (crossover between 427 and 586 tiles on 256 CUs)
         int batch_trim = 1;           // batch mode: a tile's products stop at its largest column limit (round 3)
         int batch_lockstep = 1;       // batch mode: workgroups start generation by generation (L2 reuse of the edge matrices)

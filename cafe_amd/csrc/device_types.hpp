@@ -179,6 +179,7 @@ struct K2cArgs {
     size_t table_set_stride;
     int C, LD, KP, LDv, ksteps;
     int block_threads;                // = blockDim.x (read from here: the implicit argument would be one more dependent load)
+    int xcd_remap;                    // k2c_gemm: XCD x takes a contiguous eighth of the level's tiles
     // debug builds (-DCAFE_K2_STAMPS): s_memtime stamps [tile][wave (16)][8], else NULL and unused
     unsigned long long* stamps;
 };

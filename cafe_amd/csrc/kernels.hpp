@@ -27,6 +27,10 @@ const void* k2_mfma4_kernel(int G, int nrt_w);
 // k2c_tables.hip: factor tables of compressed subtrees, K2cArgs (batch_gathers: the child columns of a state in one batch)
 const void* k2c_kernel(int nft_w, int nrt_w, bool batch_gathers, bool pair);
 
+// k2c_gemm.hip: the same tables as a tiled GEMM (k2c_gemm.hpp): nst state tiles per workgroup, nrt_w row tiles per wave, gs gather
+// slots per thread (1, 2, 4)
+const void* k2c_gemm_kernel(int nst, int nrt_w, int gs, int max_threads);   // max_threads: 512 or 1024
+
 // k_misc.hip
 const void* k2_v1_kernel(int nf, bool reference_arithmetic = false);   // k2_prune_v1<NF, REF>(K2Args), NF in {1, 2, 4, 8, 16}
 const void* k3_kernel(bool host_out);      // k3_score<HOST_OUT>(K3Args)

@@ -38,7 +38,8 @@ int ensure_matrix_storage(cafehip_ctx* c, size_t min_keys = 0)
     hipFree(c->d_PT);
     c->d_PT = nullptr;
     const size_t keep = std::max(need_keys, c->pt_keys_cap);
-    const size_t bytes = (keep + mc_slots(c)) * (size_t)c->KP * c->LD * sizeof(double);
+    // (+ 16 rows behind the last slot: k2c_gemm's operand ring requests up to three k-steps past a matrix's last and never uses them)
+    const size_t bytes = ((keep + mc_slots(c)) * (size_t)c->KP + 16) * c->LD * sizeof(double);
     HIP_TRY(hipMalloc(&c->d_PT, bytes));
     // padding rows/cols stay zero forever; ordered on the context's (non-blocking) stream, where K1 will run
     HIP_TRY(hipMemsetAsync(c->d_PT, 0, bytes, c->stream));
