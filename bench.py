@@ -98,6 +98,28 @@ class Workload:
         self.C = rng.max - rng.min + 1
 
 
+def cached_families(tree, newick, F, cfg, seed):
+    """synth.simulate_families through a disk cache (a 100k-row table takes seconds to simulate; the generator is pinned by
+    hashes in tests/test_synth_tables.py, and the cache key carries every argument)."""
+    from cafe_amd import synth
+    key = hashlib.sha1(repr((newick, tree.n_nodes, F, cfg["m"], cfg["lam"], cfg["mu"], seed, "v1")).encode()).hexdigest()[:16]
+    d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "cafe_amd_bench_tables")
+    path = os.path.join(d, "%s.npy" % key)
+    try:
+        return np.load(path)
+    except Exception:
+        pass
+    counts = synth.simulate_families(tree, F, cfg["m"], cfg["lam"], cfg["mu"], seed)
+    try:
+        os.makedirs(d, exist_ok=True)
+        tmp = path + ".%d.tmp.npy" % os.getpid()
+        np.save(tmp, counts)
+        os.replace(tmp, path)
+    except OSError:
+        pass
+    return counts
+
+
 def synthetic_workload(config, rank, world, scaling, families, same_table_blocks=0):
     """BASELINE configs[1..4] (cafe_amd/synth.py).  weak: every rank simulates its own table of
     F_local families (seed + rank).  strong: the global table is the concatenation of `same_table_blocks` blocks
@@ -120,7 +142,7 @@ def synthetic_workload(config, rank, world, scaling, families, same_table_blocks
         per_block = (F_total // nb // D.CHUNK) * D.CHUNK      # chunk-aligned blocks
         F_total = per_block * nb
         mine = range(rank * nb // world, (rank + 1) * nb // world)
-        counts = np.concatenate([synth.simulate_families(tree, per_block, cfg["m"], cfg["lam"], cfg["mu"], cfg["seed"] + 1 + b) for b in mine])
+        counts = np.concatenate([cached_families(tree, newick, per_block, cfg, cfg["seed"] + 1 + b) for b in mine])
         bounds = [(r * (nb // world) * per_block, (r + 1) * (nb // world) * per_block) for r in range(world)]
     else:
         per_gpu_default = 62500 if config == "cfg4" else cfg["F"]   # configs[3] is quoted on 8 GPUs
@@ -128,7 +150,7 @@ def synthetic_workload(config, rank, world, scaling, families, same_table_blocks
         if world > 1:
             F_local = (F_local // D.CHUNK) * D.CHUNK or D.CHUNK    # blocks of the global table start on chunk boundaries
         F_total = F_local * world
-        counts = synth.simulate_families(tree, F_local, cfg["m"], cfg["lam"], cfg["mu"], cfg["seed"] + 1 + rank)
+        counts = cached_families(tree, newick, F_local, cfg, cfg["seed"] + 1 + rank)
         bounds = [(r * F_local, (r + 1) * F_local) for r in range(world)]
     # strong scaling: the prior must not depend on which blocks a rank holds, or the score of the SAME table would differ
     # with N (rounds 3-4 fitted it to the local blocks: last_score moved in the 7th digit between N = 1 and N = 8).  A fixed
@@ -409,10 +431,9 @@ def roofline_of(leg, F_local):
         },
         "useful_flops_per_launch": useful * F_local,
         "useful_flops_note": "exact rows x C for every internal edge and family, i.e. what an uncompressed walk without "
-                             "tile padding executes; with compression fewer are executed, so the two rates below are "
-                             "NOT utilisations",
+                             "tile padding executes; with compression fewer are executed, so the rate below is a CREDIT, "
+                             "not a utilisation (it can exceed the peak: see algorithmic_credit)",
         "useful_TFLOP/s": useful * F_local / (k2_ms * 1e-3) / 1e12,
-        "useful_frac": useful * F_local / (k2_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
     }
     credit = {
         "what": "SURVEY.md 8(d) F_alg = 2*N_el flops and B_alg = 8*N_el bytes per family evaluation: what the "
@@ -421,6 +442,13 @@ def roofline_of(leg, F_local):
         "N_el_per_family": n_el,
         "F_alg_TFLOP/s": 2.0 * n_el * F_local / (k2_ms * 1e-3) / 1e12,
         "B_alg_effective_GB/s": 8.0 * n_el * F_local / (k2_ms * 1e-3) / 1e9,
+        # ratios to the hardware peaks, printed beside roofline.frac on purpose: both are ABOVE 1 -- the timed kernels do not do
+        # the reference's work (leaf edges are gathers, subtree-state compression removes 61-72 % of the products; same values
+        # bit for bit), so these say how much of the reference's work an evaluation is CREDITED with per second, while
+        # roofline.frac prices the matrix instructions the launches actually issue
+        "F_alg_over_fp64_peak": 2.0 * n_el * F_local / (k2_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+        "B_alg_over_hbm_peak": 8.0 * n_el * F_local / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "uncompressed_unpadded_walk_credit_ratio": useful * F_local / (k2_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
     }
     kms = {"k1_matrix_build": float(km[:, 0].mean()), "k2_prune": k2_ms, "k3_score": float(km[:, 2].mean())}
     return roof, credit, kms, desc
@@ -512,6 +540,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--blocks", type=int, default=5, help="timed regions of --steps steps taken back to back: the headline is the median block (default 5)")
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--table", choices=("synthetic", "test1", "turnover"), default="synthetic",
                     help="headline table: the config's synthetic one (default), the reference's test1 table, or the "
@@ -531,6 +560,7 @@ def main():
                          "(they cost a configs[1] step ~27 us: profiles/r05/event_sampling_cost.txt)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (configs[3]'s 500k-family table)")
     ap.add_argument("--no-tables", action="store_true", help="skip the test1 / high-turnover table legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs[2] / configs[4] legs of the default run")
     ap.add_argument("--backend", default=None, help="torch.distributed backend of --comm torch (default nccl = RCCL; gloo with --same-device)")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: take the multi-rank code path (communicator + exchange) even with 1 rank")
@@ -651,18 +681,27 @@ def main():
     priming = leg.prime(fixed_count=(1000 if F_local <= 20000 else 60) if multi else None)
     if os.environ.get("BENCH_FAIL_RANK") == str(rank):
         raise RuntimeError("forced by BENCH_FAIL_RANK (test: rank 0 must still print its line, with an `error` key)")
-    dt, last = leg.run(args.warmup, args.steps, timing_every=args.timing_every if args.timing_every > 0 else 10 ** 9, rank=rank)
+    # The timed region of the contract -- W warm-up steps, then EXACTLY K steps between barrier + synchronise, maximum over the
+    # ranks -- is taken `--blocks` times back to back (default 5) and the headline is the MEDIAN block, with the spread beside
+    # it: 20 steps of configs[1] are 2.4 ms, and one block alone moved by +-5 % between runs of an unchanged kernel.
+    def timed_block(warm):
+        dt_b, last_b = leg.run(warm, args.steps, timing_every=args.timing_every if args.timing_every > 0 else 10 ** 9, rank=rank)
+        per_rank = [dt_b]
+        if multi:
+            if args.comm == "native":
+                slots8 = eng.comm_allgather(np.float64(dt_b).tobytes(), 8)
+                per_rank = [float(np.frombuffer(b, np.float64)[0]) for b in slots8]
+            else:
+                every = [None] * world
+                dist.all_gather_object(every, dt_b)
+                per_rank = [float(x) for x in every]
+        return max(per_rank), last_b, per_rank
+    blocks = [timed_block(args.warmup if b == 0 else 0) for b in range(max(args.blocks, 1))]
     leg.timing_every = args.timing_every
-    per_rank_dt = [dt]
-    if multi:
-        if args.comm == "native":
-            slots8 = eng.comm_allgather(np.float64(dt).tobytes(), 8)
-            per_rank_dt = [float(np.frombuffer(b, np.float64)[0]) for b in slots8]
-        else:
-            every = [None] * world
-            dist.all_gather_object(every, dt)
-            per_rank_dt = [float(x) for x in every]
-        dt = max(per_rank_dt)
+    block_ms = [1e3 * b[0] / args.steps for b in blocks]
+    mid = sorted(range(len(blocks)), key=lambda i: blocks[i][0])[(len(blocks) - 1) // 2]   # (the median block, lower one of an even count)
+    dt, last, per_rank_dt = blocks[mid]
+    last = blocks[-1][1]
     # the same steps with every parameter set announced one evaluation ahead (all ranks: the steps contain the exchange)
     if args.timing_every <= 0:
         leg.sample_pass(args.warmup, args.steps, rank=rank)
@@ -682,6 +721,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt / args.steps,
+        "ms_per_step_blocks": {"what": "%d timed regions of %d steps each, back to back; value / ms_per_step are the MEDIAN region's" % (len(blocks), args.steps),
+                               "ms_per_step": block_ms, "min": min(block_ms), "max": max(block_ms), "median": 1000.0 * dt / args.steps,
+                               "spread_rel": (max(block_ms) - min(block_ms)) / (1000.0 * dt / args.steps)},
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
@@ -781,6 +823,24 @@ def main():
         # nothing would run at (every family walks the whole tree; same values bit for bit)
         out["tables"]["uncompressed"] = table_leg(wl, local_rank, options={"compress": 0})
 
+    # ---- the other single-GPU configurations of BASELINE.json, each a leg of the SAME line (the driver's run
+    # covered configs[1] only): configs[2] (100 k families, 32 taxa, lambda/mu) and configs[4] (100 k families, error model
+    # on every leaf); configs[1] is the headline itself, configs[3] (8 GPUs) is the strong leg above
+    if rank == 0 and world == 1 and not multi and not args.no_configs and args.table == "synthetic" and args.config == "cfg2":
+        out["configs"] = {"what": "every single-GPU configuration of BASELINE.json measured like the headline (median of 3 timed regions "
+                                  "of 40 steps; HIP-event kernel durations from a second pass): \"1\" = the headline above"}
+        out["configs"]["1"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "see": "the headline of this line"}
+        for key, cname in (("2", "cfg3"), ("4", "cfg5")):
+            t0 = time.perf_counter()
+            w2 = synthetic_workload(cname, 0, 1, "weak", None)
+            t_gen = time.perf_counter() - t0
+            leg2 = table_leg(w2, local_rank, steps=40, blocks=3)
+            leg2["table_generation_s"] = t_gen
+            leg2["config"] = "BASELINE.json configs[%s]: %s" % (key, w2.desc)
+            minimal = minimal_traffic_bytes(w2, leg2["engine"], len(w2.counts))
+            leg2["roofline"].update(pmc_traffic(cname, len(w2.counts), minimal=minimal))
+            out["configs"][key] = leg2
+
     if rank == 0 and world == 1 and not multi and not args.no_search and args.table == "synthetic":
         out["lambda_search"] = lambda_search_wallclock(wl)
 
@@ -868,6 +928,15 @@ def strong_leg(args, eng, comm, rank, world, local_rank):
     leg.prepare_rates(warm + steps)
     leg.prime(fixed_count=45 if comm else None)
     dt, last = leg.run(warm, steps, timing_every=10 ** 9, rank=rank)   # (no kernel events inside the timed pass)
+    leg.sample_pass(warm, 16, rank=rank)   # (all ranks step: the steps contain the exchange; rank 0 records)
+    roof = None
+    if rank == 0 and leg.kernel_ms:
+        r, credit, kms, desc = roofline_of(leg, len(w.counts))
+        roof = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "median_launch_ms", "launch_samples",
+                                  "issued_flops_per_launch", "factor_tables", "pruning_total", "whole_evaluation")}
+        roof["kernel_ms"] = kms
+        roof["engine"] = desc
+        roof["algorithmic_credit"] = {k: credit[k] for k in ("F_alg_over_fp64_peak", "B_alg_over_hbm_peak")}
     if comm is not None and comm["kind"] == "native":
         dt = max(float(np.frombuffer(b, np.float64)[0]) for b in eng.comm_allgather(np.float64(dt).tobytes(), 8))
     elif comm is not None:
@@ -880,10 +949,10 @@ def strong_leg(args, eng, comm, rank, world, local_rank):
                     "3 lambda classes, split over %d GPU(s); one objective evaluation per step" % world,
             "scaling": "strong", "families_total": w.F_total, "families_per_gpu": len(w.counts), "n_gpus": world,
             "steps": steps, "ms_per_step": 1e3 * dt / steps, "value": w.F_total * steps / dt, "unit": "family-evals/s",
-            "last_score": last, "setup_ms": leg.setup["set_families_ms"]}
+            "last_score": last, "setup_ms": leg.setup["set_families_ms"], "roofline": roof}
 
 
-def table_leg(w, local_rank, options=None):
+def table_leg(w, local_rank, options=None, steps=100, blocks=3):
     """Headline measurement on another table (or under other library options): evaluations/s, kernel times, roofline with
     work saved."""
     import cafe_amd
@@ -891,16 +960,24 @@ def table_leg(w, local_rank, options=None):
     for k, v in (options or {}).items():
         eng.set_option(k, v)
     leg = Leg(w, local_rank, None, shared_engine=eng)
-    steps, warm = 100, 5
+    warm = 5
     leg.prepare_rates(warm + steps + MIN_KERNEL_SAMPLES)
     priming = leg.prime()
-    dt, last = leg.run(warm, steps, timing_every=10 ** 9)
-    leg.sample_pass(warm, steps)
+    dts = []
+    for b in range(blocks):
+        dt_b, last = leg.run(warm if b == 0 else 0, steps, timing_every=10 ** 9)
+        dts.append(dt_b)
+    dt = sorted(dts)[(len(dts) - 1) // 2]
+    leg.sample_pass(warm, min(steps, 48))
     leg.extra_kernel_samples(warm + steps)
     roof, credit, kms, desc = roofline_of(leg, len(w.counts))
     res = {"table": w.desc, "families": len(w.counts), "value": len(w.counts) * steps / dt, "unit": "family-evals/s",
-           "ms_per_step": 1e3 * dt / steps, "steps": steps, "kernel_ms": kms,
-           "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "factor_tables", "pruning_total", "whole_evaluation")},
+           "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "ms_per_step_blocks": {"ms_per_step": [1e3 * x / steps for x in dts], "min": 1e3 * min(dts) / steps, "max": 1e3 * max(dts) / steps},
+           "kernel_ms": kms,
+           "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "median_launch_ms", "launch_samples",
+                                             "issued_flops_per_launch", "factor_tables", "pruning_total", "whole_evaluation")},
+           "algorithmic_credit": {k: credit[k] for k in ("F_alg_over_fp64_peak", "B_alg_over_hbm_peak")},
            "setup_ms": leg.setup["set_families_ms"], "engine": desc, "last_score": last}
     if options:
         res["options"] = options
@@ -974,7 +1051,7 @@ def lambda_search_wallclock(wl):
     tree, cfg, rng, counts, newick = wl.tree, wl.cfg, wl.rng, wl.counts, wl.newick
     has_mu = cfg["mu"] >= 0
 
-    def run(rows, label, generator_prior=False, lookahead=None):
+    def run(rows, label, generator_prior=False, lookahead=None, cold=False):
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "families.tab")
             with open(path, "w") as f:
@@ -1001,6 +1078,28 @@ def lambda_search_wallclock(wl):
                 command = "lambda -s -t " + synth.clade_classes(tree, cfg["n_classes"])[1]
             else:
                 command = "lambda -s"
+            if cold:
+                # the same command in a FRESH process (what a user's `cafehip script.sh` is: no wave grid remembered, kernels not
+                # loaded yet); the child prints its own clock around the search command
+                setup_lines = ["seed 10", "tree " + newick, "load -i " + path]
+                if cfg.get("error_model"):
+                    setup_lines.append("errormodel -model %s -all" % em)
+                sh.close()
+                code = ("import json,sys,time\nsys.path.insert(0, %r)\nfrom cafe_amd.shell import CafeShell\n"
+                        "a=json.loads(sys.argv[1])\nsh=CafeShell(0, a['log'])\n"
+                        "[sh.dispatch(l) for l in a['setup']]\nt0=time.perf_counter()\nsh.dispatch(a['command'])\n"
+                        "w=time.perf_counter()-t0\n"
+                        "print(json.dumps({'wall_s': w, 'search_s': sh.search_seconds, 'iterations': sh.iterations, 'evaluations': sh.evaluations, "
+                        "'fitted': [float(x) for x in sh.params], 'score': sh.score}))\nsh.close()\n") % ROOT
+                t0 = time.perf_counter()
+                cp = subprocess.run([sys.executable, "-c", code, json.dumps({"log": os.path.join(d, "cold_log.txt"), "setup": setup_lines, "command": command})],
+                                    capture_output=True, text=True, timeout=600)
+                if cp.returncode != 0:
+                    return {"what": label, "error": cp.stderr[-500:]}
+                child = json.loads(cp.stdout.strip().splitlines()[-1])
+                child["what"] = label
+                child["process_wall_s"] = time.perf_counter() - t0
+                return child
             t0 = time.perf_counter()
             sh.dispatch(command)
             wall = time.perf_counter() - t0
@@ -1017,6 +1116,14 @@ def lambda_search_wallclock(wl):
     # identical trajectory, every evaluation pays its own matrix build
     plain = run(counts, "the same, host option lookahead=0", lookahead=0)
     res["search_s_without_lookahead"] = plain["search_s"]
+    # ... and in a fresh process: the FIRST search of a process (round 5 reported only a later one: the first paid the wave-grid
+    # measurement in line, 13.8 against 6.95 ms at configs[1]; round 6 measures by replacing launches, not adding them)
+    cold = run(counts, "the same command as the first search of a FRESH process (python -c ... CafeShell): cold wave grid, kernels not loaded", cold=True)
+    res["cold_process"] = cold
+    res["cold_process_wall_s"] = cold.get("wall_s")
+    res["cold_process_search_s"] = cold.get("search_s")
+    res["same_result_in_cold_process"] = (cold.get("fitted") == res["fitted"] and cold.get("score") == res["score"] and
+                                          cold.get("evaluations") == res["evaluations"])
     res["same_result_without_lookahead"] = (plain["fitted"] == res["fitted"] and plain["score"] == res["score"] and
                                             plain["evaluations"] == res["evaluations"])
     mle = float((counts[counts > 0] - 1).mean())

@@ -333,9 +333,13 @@ int launch_mfma4_g(cafehip_ctx* c, K2MfmaArgs a, int G, int nrt_w, int grid, int
 }
 
 // measured wave-grid choices of this process, by problem shape
-constexpr int kTuneReps = 4;
-constexpr int kTuneRounds = 5;   // round 0 warm-up, round 1 every grid, rounds 2-4 those within 5 % of the best (minimum kept):
-                                 // with one re-timing the choice between two grids 3 % apart flipped in one run out of five
+// Round 6: the measurement REPLACES launches instead of adding them.  Rounds 1-4 used to time 4 back-to-back launches of a
+// candidate per deciding evaluation (a single ~55 us launch is within the noise of the candidates' differences): ~30 tuning
+// evaluations x 3 extra launches made the FIRST search of a process twice as long as the fifth (configs[1]: 13.8 against
+// 6.95 ms, profiles/r05_lookahead_ab.txt).  Now every tuning evaluation launches its candidate once -- it costs what the
+// candidate is slower than the best grid, ~10-20 us -- and the noise is met with more rounds of the survivors (minimum kept).
+constexpr int kTuneReps = 1;
+constexpr int kTuneRounds = 8;   // round 0 warm-up, round 1 every grid, rounds 2-7 those within 6 % of the best (minimum kept)
 std::mutex g_tuned_mu;
 std::map<std::array<long, 8>, K2Cand> g_tuned;
 std::array<long, 8> tune_key(const cafehip_ctx* c, int n_items)
@@ -474,7 +478,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
                         t.cur = 0;
                         ++t.round;
                     }
-                } while (t.round >= 2 && t.round < kTuneRounds && t.best_ms[t.cur] > 1.05f * best);
+                } while (t.round >= 2 && t.round < kTuneRounds && t.best_ms[t.cur] > 1.06f * best);
                 if (t.round >= kTuneRounds) {
                     t.locked = (int)(std::min_element(t.best_ms.begin(), t.best_ms.end()) - t.best_ms.begin());
                     if (c->opt.k2tune_log)
@@ -588,7 +592,8 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     int reps = 1;
     if (tuning_launch && c->tune.round >= 1) {
         const float warm = c->tune.best_ms[c->tune.cur];   // round 0's (or round 1's) time of this grid
-        reps = warm < 0.25f ? kTuneReps : (warm < 1.0f ? 2 : 1);
+        reps = warm < 0.25f ? kTuneReps : 1;
+        (void)warm;
     }
     if (tuning_launch) c->tune.reps_launched = reps;
     int rc = 0;
