@@ -411,7 +411,7 @@ namespace {
 // ---- run-time switches ---------------------------------------------------------------------------------------
 // (name, what it selects) -- cafehip_set_option; the same names upper-cased behind CAFEHIP_ are read from the
 // environment ONCE, when the context is created (tools/ sweeps), never during an evaluation
-const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "compress_max_level", "compress_drop_top", "errfold", "errband", "k1", "k1kpb", "k2", "mfma",
+const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "compress_max_level", "compress_drop_top", "errfold", "errband", "k1", "k1kpb", "k1_balance", "k2_skip_epilogue", "k2", "mfma",
                                     "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch", "k2c_pair", "k2c_pair_min", "k2c_gemm", "k2c_nst", "k2c_xcd",
                                     "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "exp_like_host", "matrix_cache",
                                     "matrix_cache_mb", "prefetch_where", "prefetch_kpb", "prearm", "comm"};
@@ -436,6 +436,8 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
         else if (val.empty() || val == "auto" || val == "rb") o.k1 = 0;
         else return fail("option k1: auto | exact | perterm, got '%s'", val.c_str());
     } else if (key == "k1kpb") o.k1_kpb = std::max(1, iv);
+    else if (key == "k1_balance") o.k1_balance = iv != 0;
+    else if (key == "k2_skip_epilogue") o.k2_skip_epilogue = iv != 0;
     else if (key == "k2") {
         if (val == "v1") o.k2 = 1;
         else if (val == "v1ref") o.k2 = 2;   // ... in the reference's arithmetic (separate multiply and add per term)
@@ -529,6 +531,53 @@ static int launch_k4_nf(cafehip_ctx* c, int nf, const K4Args& a, int block, size
 // ====================================================================================
 // C ABI
 // ====================================================================================
+namespace {
+// The library's kernels live in one code object per translation unit, and the runtime loads a code object at the FIRST launch
+// of one of its kernels: ~2.8 ms each for the two walk units (profiles/r06/cold_evaluations_before.txt: evaluation 1 of a
+// process took 2.9 ms, the first candidate wave grid of the other matrix-instruction shape another 2.9 ms) -- 6 of the 13 ms
+// of the first search of a process.  A context's creation starts ONE background thread per process and device that asks for
+// the attributes of a kernel of every unit (which loads the unit) while the host parses its table; a launch that needs a
+// unit before the thread got there loads it itself, as before.  CAFEHIP_PRELOAD=0 disables.
+struct KernelPreload {
+    std::mutex mu;
+    std::thread th;
+    bool started[64] = {};
+    ~KernelPreload()
+    {
+        if (th.joinable()) th.join();
+    }
+    void start(int device)
+    {
+        const char* e = getenv("CAFEHIP_PRELOAD");
+        if (e && atoi(e) == 0) return;
+        std::lock_guard<std::mutex> g(mu);
+        if (device < 0 || device >= 64 || started[device]) return;
+        started[device] = true;
+        if (th.joinable()) th.join();
+        th = std::thread([device] {
+            if (hipSetDevice(device) != hipSuccess) return;
+            const void* fns[] = {k1_rb_kernel(), k2c_gemm_kernel(1, 1, 1, 512), k2_mfma4_kernel(1, 1), k3_kernel(true), k2_mfma16_kernel(1, 1),
+                                 k2c_kernel(1, 1, true, false)};
+            for (const void* fn : fns) {
+                hipFuncAttributes at;
+                if (fn) (void)hipFuncGetAttributes(&at, fn);
+            }
+            (void)hipGetLastError();
+        });
+    }
+    void join()
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (th.joinable()) th.join();
+    }
+};
+KernelPreload& kernel_preload()
+{
+    static KernelPreload p;
+    return p;
+}
+}  // namespace
+
 extern "C" {
 
 int cafehip_abi_version(void) { return 1; }
@@ -572,6 +621,7 @@ int cafehip_create(cafehip_ctx** out, int device_id)
     HIP_TRY(hipMalloc(&c->d_arrive, sizeof(int32_t)));
     HIP_TRY(hipMemset(c->d_arrive, 0, sizeof(int32_t)));
     HIP_TRY(hipDeviceSynchronize());  // the memset ran on the null stream; later work uses a non-blocking one
+    kernel_preload().start(device_id);
     *out = c;
     return 0;
 }
@@ -579,6 +629,7 @@ int cafehip_create(cafehip_ctx** out, int device_id)
 void cafehip_destroy(cafehip_ctx* c)
 {
     if (!c) return;
+    kernel_preload().join();
     hipSetDevice(c->device);
     disarm(c);
     (void)sync_streams(c);

@@ -73,6 +73,10 @@ struct K1Args {
     double* prior_dev;
     double* logprior_dev;
     int exp_variant;             // exact form: 1 / 2 = the host libm's exp restated (fused / plain build), 0 = the device library's
+    // register-blocked kernel, round 6: a 1-D grid of gx * gy * gz workgroups dealt heavy tiles first, light tiles last (the
+    // work of tile (s0, c0) grows with min(s, c): co-resident workgroups then add up to about the same), or balanced = 0: 3-D grid
+    int gx, gy, gz, balanced;
+    unsigned char tile_of_rank[128];   // tile id (by * gx + bx) of the tile ranked r by work, heaviest first (gx * gy <= 128)
 };
 
 struct FoldArgs {   // k1e_fold_error
@@ -165,6 +169,7 @@ struct K2MfmaArgs {
     size_t table_set_stride;
     // debug builds (-DCAFE_K2_STAMPS): s_memtime stamps [workgroup][wave][K2_STAMP_SLOTS], else NULL and unused
     unsigned long long* stamps;
+    int skip_epilogue;     // ablation (option k2_skip_epilogue): the walk ends behind its root step, the posterior outputs are NOT written
 };
 
 // ---- k2c_nodes: factor tables of compressed subtrees -----------------------------------------------------------

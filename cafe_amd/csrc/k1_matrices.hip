@@ -342,7 +342,35 @@ __device__ __forceinline__ void k1_rb_block(const K1Args& ka, const int bx, cons
     }
 }
 
-__global__ __launch_bounds__(256) void k1_build_matrices_rb(K1Args ka) { k1_rb_block(ka, blockIdx.x, blockIdx.y, blockIdx.z); }
+// Linear workgroup index -> (column block, row block, key block).  The terms of entry (s, c) number min(s, c) + 1, so the tiles
+// of one key differ in work by an order of magnitude, and with two workgroups per CU the launch lasted as long as the CU that
+// drew two heavy tiles (configs[1]: ~7 us of arithmetic there against ~2.5 on average, 14.4 us in all).  The first half of the
+// grid takes the (tile, key) pairs heaviest first, the second half lightest first: workgroup k and workgroup k + half -- which
+// the dispatcher places on the same CU when every CU starts empty -- add up to about the same work everywhere.  A matter of
+// speed only: every tile is built by exactly one workgroup whatever the placement.
+__device__ __forceinline__ void k1_rb_coords(const K1Args& ka, const int lin, int& bx, int& by, int& bz)
+{
+    if (!ka.balanced) {
+        bx = lin % ka.gx;
+        const int t = lin / ka.gx;
+        by = t % ka.gy;
+        bz = t / ka.gy;
+        return;
+    }
+    const int total = ka.gx * ka.gy * ka.gz, half = (total + 1) >> 1;
+    const int r = lin < half ? lin : total - 1 - (lin - half);
+    const int tile = ka.tile_of_rank[r / ka.gz];
+    bz = r % ka.gz;
+    bx = tile % ka.gx;
+    by = tile / ka.gx;
+}
+
+__global__ __launch_bounds__(256) void k1_build_matrices_rb(K1Args ka)
+{
+    int bx, by, bz;
+    k1_rb_coords(ka, blockIdx.x, bx, by, bz);
+    k1_rb_block(ka, bx, by, bz);
+}
 
 // Score kernel and the matrices of the NEXT candidates in one launch (round 5).  Blocks [0, k3_blocks) are k3_score<true>'s
 // (dispatched first: the score reaches the host as early as from its own launch); the blocks behind them build the
@@ -357,9 +385,9 @@ __global__ __launch_bounds__(256) void k3_score_then_k1_rb(K3K1Args a)
         k3_score_block<true>(a.k3, blockIdx.x, a.k3_blocks, 0, 1);
         return;
     }
-    const int lin = (int)blockIdx.x - a.k3_blocks;
-    const int bx = lin % a.gx, t = lin / a.gx;
-    k1_rb_block(a.k1, bx, t % a.gy, t / a.gy);
+    int bx, by, bz;
+    k1_rb_coords(a.k1, (int)blockIdx.x - a.k3_blocks, bx, by, bz);
+    k1_rb_block(a.k1, bx, by, bz);
 }
 #pragma clang fp contract(fast)
 

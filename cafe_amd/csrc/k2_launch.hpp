@@ -549,6 +549,7 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
     a.max_lik = v1.max_lik;
     a.argmax = v1.argmax;
     a.max_post = v1.max_post;
+    a.skip_epilogue = (c->opt.k2_skip_epilogue && v1.col_max == nullptr) ? 1 : 0;
     c->k2_cfg[0] = k.nft_w;
     c->k2_cfg[1] = k.nrt_w;
     c->k2_cfg[2] = k.wf;

@@ -527,6 +527,12 @@ __device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* L
         }
         return;
     }
+    // (round 6: a LANE per family -- every wave scanning a slice of the root sizes for all families, partial maxima meeting in LDS
+    // atomics, the exact exp(log + log) candidates queued and evaluated one per lane -- was built three ways, bit-identical, and
+    // is SLOWER wherever R > 64: configs[1] walk 56.9 -> 58.2 us, configs[2] 1.350 -> 1.418 ms; only the reference's test1 table
+    // (30 root sizes) gained, 36.1 -> 32.3 us, and with both forms compiled in, the code size alone cost the configs[2] walk 8 %.
+    // The ablation (option k2_skip_epilogue) bounds what any epilogue can give back: 5.7 us at configs[1], 7.1 us on test1.
+    // profiles/r06/lane_per_family_epilogue_ab.txt, lane_per_family_epilogue.patch)
     // (round 3: a variant carrying four families per wave pass, one per 16-lane row, was bit-identical and SLOWER --
     // walk 56.4 -> 57.9 us at configs[1]: the epilogue is bound by instruction fetch, and the variant is more code)
     if (a.R <= 128) k2_epilogue_impl<true, 2>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
@@ -787,6 +793,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     // ---- root vector (in Lbuf) -> posterior (cafe/lambda.cpp:657-689) or packed root rows ----
     k2_release_park_slot(a, s_colmax + a.NF, tid);
     if (a.gen_done && tid == 0) atomicAdd(a.gen_done, 1);
+    if (a.skip_epilogue) return;   // (ablation only: what the posterior epilogue costs the launch)
     k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
 }
@@ -1063,6 +1070,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 
     k2_release_park_slot(a, s_colmax + a.NF, tid);
     if (a.gen_done && tid == 0) atomicAdd(a.gen_done, 1);
+    if (a.skip_epilogue) return;   // (ablation only: what the posterior epilogue costs the launch)
     k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
 }

@@ -331,7 +331,28 @@ int plan_k1_block(cafehip_ctx* c, const K1Launch& L, K1Plan& P)
         P.lds = lds_rb;
         a.tabA = c->d_expA;
         a.tabB = c->d_expB;
-        P.grid = dim3((c->S + 16 * K1Q - 1) / (16 * K1Q), (c->S + 15) / 16, (L.nkeys + kpb - 1) / kpb);
+        a.gx = (c->S + 16 * K1Q - 1) / (16 * K1Q);
+        a.gy = (c->S + 15) / 16;
+        a.gz = (L.nkeys + kpb - 1) / kpb;
+        a.balanced = 0;
+        // (measured: -15 % at 1,280 workgroups -- 62 keys of a 251-wide matrix --, +8 % at 500, where every workgroup is resident
+        // from the start and the order only delays the staging of the heavy tiles: profiles/r06/k1_balance_and_epilogue_ablation.txt)
+        if (c->opt.k1_balance && a.gx * a.gy <= (int)sizeof a.tile_of_rank && a.gx * a.gy * a.gz >= 3 * std::max(c->n_cu, 1)) {
+            // tiles ranked by work: a thread (row s, columns cb .. cb + K1Q - 1) runs floor(min(s, cb + K1Q - 1, M) / 8) + 1 chunks
+            std::vector<std::pair<long, int>> w;
+            for (int by = 0; by < a.gy; ++by)
+                for (int bx = 0; bx < a.gx; ++bx) {
+                    long sum = 0;
+                    for (int s = 16 * by; s < 16 * by + 16 && s <= c->M; ++s)
+                        for (int cb = 16 * K1Q * bx; cb < 16 * K1Q * (bx + 1) && cb <= c->M; cb += K1Q)
+                            sum += s == 0 ? 1 : std::min(s, std::min(cb + K1Q - 1, c->M)) / 8 + 1;
+                    w.push_back({-sum, by * a.gx + bx});
+                }
+            std::sort(w.begin(), w.end());
+            for (size_t r = 0; r < w.size(); ++r) a.tile_of_rank[r] = (unsigned char)w[r].second;
+            a.balanced = 1;
+        }
+        P.grid = dim3(a.gx * a.gy * a.gz);
     } else {
         // product form: every key of this block qualifies and the staged tables are exp(ln C); else the exact form
         P.fn = k1_kernel(use_lds, product);

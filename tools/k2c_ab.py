@@ -94,12 +94,12 @@ def main():
                     eng.get_posterior(nl, nm, prior)
                 step = (time.perf_counter() - t0) / 20 * 1e3
                 ks = np.array(ks)
-                res[st].append((np.median(ks[:, 3]), np.median(ks[:, 1] - ks[:, 3]), step, score))
+                res[st].append((np.median(ks[:, 3]), np.median(ks[:, 1] - ks[:, 3]), step, np.median(ks[:, 0]), np.median(ks[:, 2]), score))
         print("== %s (%d rows)" % (spec, len(counts)))
         for st, eng in zip(sets, engines):
-            r = np.array([x[:3] for x in res[st]])
-            print("  %-44s tables %s  (best %.4f)  walk %.4f  step %.4f ms  score %s" % (
-                st, " ".join("%.4f" % x for x in r[:, 0]), r[:, 0].min(), r[:, 1].min(), r[:, 2].min(), float(res[st][-1][3]).hex()), flush=True)
+            r = np.array([x[:5] for x in res[st]])
+            print("  %-44s tables %s  (best %.4f)  walk %.4f  k1 %.4f  k3 %.4f  step %.4f ms  score %s" % (
+                st, " ".join("%.4f" % x for x in r[:, 0]), r[:, 0].min(), r[:, 1].min(), r[:, 3].min(), r[:, 4].min(), r[:, 2].min(), float(res[st][-1][5]).hex()), flush=True)
             eng.close()
 
 

@@ -1,0 +1,4 @@
+mkdir -p gpurun_out/r06
+export TMPDIR=/tmp
+timeout 900 python tools/k2c_ab.py cfg2:10000 test1 cfg3:100000 cfg4:62464 -- k2_epilogue=wave k2_epilogue=lane 2>&1 | tee gpurun_out/r06/epilogue_ab3.txt | tail -20
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q 2>&1 | tail -4
