@@ -436,7 +436,7 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
         else if (val.empty() || val == "auto" || val == "rb") o.k1 = 0;
         else return fail("option k1: auto | exact | perterm, got '%s'", val.c_str());
     } else if (key == "k1kpb") o.k1_kpb = std::max(1, iv);
-    else if (key == "k1_balance") o.k1_balance = iv != 0;
+    else if (key == "k1_balance") o.k1_balance = iv;   // 0 off, 1 by launch size, 2 / 3: forced, alternating / heaviest first; 11: forced halves
     else if (key == "k2_skip_epilogue") o.k2_skip_epilogue = iv != 0;
     else if (key == "k2") {
         if (val == "v1") o.k2 = 1;

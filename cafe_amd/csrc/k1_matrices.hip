@@ -343,11 +343,12 @@ __device__ __forceinline__ void k1_rb_block(const K1Args& ka, const int bx, cons
 }
 
 // Linear workgroup index -> (column block, row block, key block).  The terms of entry (s, c) number min(s, c) + 1, so the tiles
-// of one key differ in work by an order of magnitude, and with two workgroups per CU the launch lasted as long as the CU that
-// drew two heavy tiles (configs[1]: ~7 us of arithmetic there against ~2.5 on average, 14.4 us in all).  The first half of the
-// grid takes the (tile, key) pairs heaviest first, the second half lightest first: workgroup k and workgroup k + half -- which
-// the dispatcher places on the same CU when every CU starts empty -- add up to about the same work everywhere.  A matter of
-// speed only: every tile is built by exactly one workgroup whatever the placement.
+// of one key differ in work by an order of magnitude.  Where a launch is several rounds of workgroups (3+ per CU: 40-62 keys of
+// a 151- or 251-wide matrix) the (tile, key) pairs are dealt HEAVIEST FIRST, so that the launch does not end on a heavy tile
+// that started late: -11 ... -15 % (configs[2] 52.2 -> 44.1 us, the configs[3] shard 34.7 -> 30.9 us).  A launch whose
+// workgroups are all resident from the start (configs[1]: 500 on 256 CUs) is NOT helped by any order -- heavy half / light half,
+// alternating, heaviest first all measured 5-9 % slower than the grid order there: it is a chain of latencies (key, staging,
+// stores), not of arithmetic.  A matter of speed only: every tile is built by exactly one workgroup whatever the placement.
 __device__ __forceinline__ void k1_rb_coords(const K1Args& ka, const int lin, int& bx, int& by, int& bz)
 {
     if (!ka.balanced) {
@@ -358,7 +359,11 @@ __device__ __forceinline__ void k1_rb_coords(const K1Args& ka, const int lin, in
         return;
     }
     const int total = ka.gx * ka.gy * ka.gz, half = (total + 1) >> 1;
-    const int r = lin < half ? lin : total - 1 - (lin - half);
+    // balanced: 1 = heavy half then light half ascending (k and k + half meet), 2 = heavy / light alternating (neighbours meet),
+    // 3 = heaviest first throughout
+    const int r = ka.balanced == 1 ? (lin < half ? lin : total - 1 - (lin - half))
+                : ka.balanced == 2 ? ((lin & 1) ? total - 1 - (lin >> 1) : (lin >> 1))
+                                   : lin;
     const int tile = ka.tile_of_rank[r / ka.gz];
     bz = r % ka.gz;
     bx = tile % ka.gx;

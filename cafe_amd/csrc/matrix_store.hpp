@@ -337,7 +337,7 @@ int plan_k1_block(cafehip_ctx* c, const K1Launch& L, K1Plan& P)
         a.balanced = 0;
         // (measured: -15 % at 1,280 workgroups -- 62 keys of a 251-wide matrix --, +8 % at 500, where every workgroup is resident
         // from the start and the order only delays the staging of the heavy tiles: profiles/r06/k1_balance_and_epilogue_ablation.txt)
-        if (c->opt.k1_balance && a.gx * a.gy <= (int)sizeof a.tile_of_rank && a.gx * a.gy * a.gz >= 3 * std::max(c->n_cu, 1)) {
+        if (c->opt.k1_balance && a.gx * a.gy <= (int)sizeof a.tile_of_rank && (c->opt.k1_balance > 1 || a.gx * a.gy * a.gz >= 3 * std::max(c->n_cu, 1))) {
             // tiles ranked by work: a thread (row s, columns cb .. cb + K1Q - 1) runs floor(min(s, cb + K1Q - 1, M) / 8) + 1 chunks
             std::vector<std::pair<long, int>> w;
             for (int by = 0; by < a.gy; ++by)
@@ -350,7 +350,9 @@ int plan_k1_block(cafehip_ctx* c, const K1Launch& L, K1Plan& P)
                 }
             std::sort(w.begin(), w.end());
             for (size_t r = 0; r < w.size(); ++r) a.tile_of_rank[r] = (unsigned char)w[r].second;
-            a.balanced = 1;
+            // (1 -- a heavy half, then a light half ascending -- and 2 -- alternating -- measured behind 3, heaviest first throughout,
+            // at 62 keys of a 151-wide matrix: 34.7 us in grid order, 34.1 / 33.9 / 30.9 us; profiles/r06/k1_tile_order_ab.txt)
+            a.balanced = c->opt.k1_balance >= 10 ? c->opt.k1_balance - 10 : (c->opt.k1_balance > 1 ? c->opt.k1_balance : 3);
         }
         P.grid = dim3(a.gx * a.gy * a.gz);
     } else {
