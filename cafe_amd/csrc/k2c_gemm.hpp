@@ -24,7 +24,10 @@ using namespace cafehip;
 
 constexpr int K2G_KC = 8;                 // k-steps per chunk
 constexpr int K2G_CS = 4 * K2G_KC + 2;    // row stride of a chunk buffer in doubles: == 2 (mod 32), the A operand's reads are conflict-free
-constexpr int K2G_D = 4;                  // depth of the matrix operand's ring (divides KC: ring slots are compile-time)
+#ifndef CAFE_K2G_DEPTH
+#define CAFE_K2G_DEPTH 4
+#endif
+constexpr int K2G_D = CAFE_K2G_DEPTH;     // depth of the matrix operand's ring (divides KC: ring slots are compile-time)
 
 // The product of one workgroup's wave: NT (<= NRT_W) live row tiles.  Contains the chunk loop, i.e. the gathers and barriers
 // every wave of the workgroup takes part in (the same number of barriers whatever NT).

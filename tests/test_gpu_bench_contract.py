@@ -48,6 +48,23 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert u["options"] == {"compress": 0} and "used=1" not in u["engine"]
     assert u["value"] < d["value"]
     assert c["matrix_build_s"] > 0 and c["family_loop_value"] > c["value"]
+    # round 6: the headline is the median of five timed regions, printed with its spread; every single-GPU configuration of
+    # BASELINE.json is a leg of the same line with its own roofline; the strong leg carries one too; the credit ratios sit beside
+    # the fraction and exceed 1 (they are not fractions); the first search of a fresh process is timed beside the warm one
+    b = d["ms_per_step_blocks"]
+    assert len(b["ms_per_step"]) == 5 and b["min"] <= d["ms_per_step"] <= b["max"]
+    for key, fams in (("2", 100000), ("4", 100000)):
+        leg = d["configs"][key]
+        assert leg["families"] == fams and leg["value"] > 1e6 and 0 < leg["roofline"]["frac"] <= 1
+        assert leg["roofline"]["issued_flops_per_launch"] > 0 and leg["roofline"]["avg_launch_ms"] > 0
+        assert len(leg["ms_per_step_blocks"]["ms_per_step"]) == 3
+    assert d["configs"]["1"]["ms_per_step"] == d["ms_per_step"]
+    assert 0 < d["strong_scaling"]["roofline"]["frac"] <= 1
+    assert "useful_frac" not in r
+    assert d["algorithmic_credit"]["F_alg_over_fp64_peak"] > 1 and d["algorithmic_credit"]["B_alg_over_hbm_peak"] > 1
+    ls = d["lambda_search"]
+    assert ls["cold_process_search_s"] > 0 and ls["same_result_in_cold_process"] is True
+    assert d["bench_wall_s"] < 240
 
 
 def test_forced_one_rank_run_goes_through_the_native_exchange():

@@ -212,3 +212,48 @@ def test_paired_row_tiles_of_the_table_kernel_change_no_bit(max_size, with_error
     assert np.array_equal(ml0, ml1) and np.array_equal(am0, am1) and np.array_equal(mp0, mp1)
     for x, y in zip(m0, m1):
         assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+@pytest.mark.parametrize("options", [
+    {"k2c_gemm": 0},                                   # round 5's k2c_nodes
+    {"k2c_gemm": 1, "k2c_nst": 1, "k2c_pair": 0},      # k2c_gemm (round 6): every state-tile count, one and two row tiles per wave,
+    {"k2c_gemm": 1, "k2c_nst": 1, "k2c_pair": 1},      # dispatch and XCD-aware tile order
+    {"k2c_gemm": 1, "k2c_nst": 2, "k2c_pair": 0},
+    {"k2c_gemm": 1, "k2c_nst": 2, "k2c_pair": 1, "k2c_xcd": 0},
+    {"k2c_gemm": 1, "k2c_nst": 4, "k2c_pair": 0},
+    {"k2c_gemm": 1, "k2c_nst": 4, "k2c_pair": 1},
+])
+@pytest.mark.parametrize("shape", ["narrow", "wide", "error"])
+def test_every_table_kernel_shape_builds_the_same_tables(options, shape):
+    """The factor tables as a chunk-pipelined GEMM (k2c_gemm.hpp) -- 16, 32 or 64 states per workgroup, matrices of 3 / 5 / 7 row
+    tiles with a partial last chunk of every length -- against the uncompressed walk: every per-family output ==."""
+    import cafe_amd
+    from cafe_amd import synth
+    t = O.PyTree(NEWICK)
+    top, rmax = {"narrow": (9, 40), "wide": (30, 104), "error": (12, 70)}[shape]
+    counts = _table(7000, t.n_leaves, 21, top=top)
+    rng_tuple = (0, rmax, 1, 30)
+    prior = O.prior_poisson(1000, 1, 2.0)
+    lam = np.full(t.n_nodes, 0.02)
+    mu = np.full(t.n_nodes, 0.013 if shape == "wide" else -1.0)
+    err = synth.banded_error_matrix(rng_tuple[1]) if shape == "error" else None
+    (s0, fz0, ml0, am0, mp0), d0, _ = _run(False, counts, t, rng_tuple, lam, mu, prior, err)
+    eng = cafe_amd.Engine(0)
+    try:
+        for k, v in options.items():
+            eng.set_option(k, v)
+        eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+        eng.set_families(counts, cafe_amd.FamilySizeRange(*rng_tuple))
+        if err is not None:
+            eng.set_error_model(err)
+        s1, fz1, ml1, am1, mp1 = eng.get_posterior(lam, mu, prior, per_family=True)
+        d1 = eng.describe()
+        # the option can also be changed with the table in place: the plan is rebuilt
+        eng.set_option("k2c_nst", 0)
+        s2, fz2, ml2, am2, mp2 = eng.get_posterior(lam, mu, prior, per_family=True)
+    finally:
+        eng.close()
+    assert "compressed(" in d1 and "used=1" in d1, d1
+    assert s1 == s0 and fz1 == fz0 and s2 == s0
+    assert np.array_equal(ml1, ml0) and np.array_equal(mp1, mp0) and np.array_equal(am1, am0)
+    assert np.array_equal(ml2, ml0) and np.array_equal(mp2, mp0)

@@ -421,3 +421,32 @@ def test_measured_grid_choice_never_changes_a_bit():
         assert len(seen) >= 3, seen   # several grids were really exercised
     finally:
         eng.close()
+
+
+def test_matrices_do_not_depend_on_the_order_the_build_deals_its_tiles():
+    """K1's register-blocked build deals its (tile, key) pairs heaviest first where a launch is several rounds of workgroups
+    (round 6, option k1_balance: 0 grid order, 11 / 2 / 3 forced orders): a matter of speed, every entry the same bits."""
+    import cafe_amd
+    t = O.PyTree("(((a:6,b:6):5,(c:4,(d:2,e:2):2):7):9,((f:3,g:3):8,h:11):9)")
+    rs = np.random.RandomState(5)
+    counts = rs.poisson(3.0, size=(300, t.n_leaves)).clip(0, 60).astype(np.int32)
+    counts[0, 0] = 60
+    rng = cafe_amd.init_family_size(60)
+    prior = O.prior_poisson(1000, rng.root_min, 3.0)
+    lam = np.full(t.n_nodes, 0.011)
+    mu = np.full(t.n_nodes, -1.0)
+    want = None
+    for order in (0, 11, 2, 3):
+        eng = cafe_amd.Engine(0)
+        eng.set_option("k1_balance", order)
+        eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+        eng.set_families(counts, rng)
+        score, fz = eng.get_posterior(lam, mu, prior)
+        mats = [eng.get_matrix(v) for v in range(t.n_nodes) if v != t.root]
+        eng.close()
+        if want is None:
+            want = (score, mats)
+            assert all(m.sum() > 0 for m in mats)
+        else:
+            assert score == want[0]
+            assert all(np.array_equal(a, b) for a, b in zip(mats, want[1]))

@@ -25,7 +25,7 @@ def main():
     for src in B.SOURCES:   # the translation units side by side, as cafe_amd/build.py compiles them
         obj = os.path.join(obj_dir, os.path.basename(src).rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        jobs.append([B.hipcc()] + B.CFLAGS + flags + ["-c", "-o", obj, os.path.join(B.CSRC, src)])
+        jobs.append([B.hipcc()] + B.CFLAGS + B.UNIT_FLAGS.get(src, []) + flags + ["-c", "-o", obj, os.path.join(B.CSRC, src)])
     print(" ".join(jobs[0]), "... (%d units)" % len(jobs), flush=True)
     procs = [subprocess.Popen(j) for j in jobs]
     if any(p.wait() != 0 for p in procs):
