@@ -47,7 +47,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured float4 copy)
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix = vector peak: 256 CUs x 4 SIMDs x 32 flop/cycle x 2.4 GHz
 MIN_KERNEL_SAMPLES = 16
-TRAFFIC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")]
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")]
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
@@ -383,7 +383,7 @@ def roofline_of(leg, F_local):
         "kernel": "k2_prune_mfma4 (v_mfma_f64_4x4x4_4b)" if "mfma4x4" in desc else "k2_prune_mfma (v_mfma_f64_16x16x4)",
         "kernel_does": "the family walk: pruning of all families + posterior in one launch" +
                        (" over the REDUCED tree (compressed subtrees are row gathers from factor tables built by "
-                        "the k2c_nodes launches just before it: see factor_tables / pruning_total)" if compressed else ""),
+                        "the k2c_gemm launches just before it: see factor_tables / pruning_total)" if compressed else ""),
         "achieved": achieved,
         "peak": FP64_PEAK_TFLOPS,
         "unit": "TFLOP/s",
@@ -406,7 +406,7 @@ def roofline_of(leg, F_local):
         "median_launch_ms": float(np.median(km[:, 1] - km[:, 3])),   # (a box hiccup of tens of ms in one sample moves the mean, not this)
         "families_per_launch": F_local,
         "factor_tables": None if not compressed else {
-            "kernel": "k2c_nodes (v_mfma_f64_16x16x4): one launch per compression level, 16 states per workgroup; levels of at least 2 tiles per CU deal a wave two row tiles read with one 16-byte load (option k2c_pair)",
+            "kernel": "k2c_gemm (v_mfma_f64_16x16x4; round 6): one launch per compression level, 16 or 32 states per workgroup, the node vectors formed chunk by chunk of 32 columns beside the matrix instructions of the previous chunk; levels of at least 2 tiles per CU deal a wave two row tiles read with one 16-byte load (options k2c_gemm, k2c_nst, k2c_pair)",
             "launches_per_evaluation": int(re.search(r"levels=(\d+)", desc).group(1)),
             "states": int(re.search(r"states=(\d+)", desc).group(1)),
             "ms_per_evaluation": tables_ms,

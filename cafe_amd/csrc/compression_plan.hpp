@@ -62,7 +62,7 @@ int k2c_wave_rows(const cafehip_ctx* c, int* nrt_w, bool pair = false)
 // compressed and its distinct states number at most `compress_theta` of the unique rows (default by table size
 // and matrix side, see below); option compress=0 disables.  Tables with fewer than 64 unique rows (`compress_min`)
 // are left alone.
-int rebuild_compression(cafehip_ctx* c)
+int rebuild_compression(cafehip_ctx* c, double theta_retry = -1.0)
 {
     free_compression(c);
     if (!c->opt.compress) return 0;
@@ -112,8 +112,16 @@ int rebuild_compression(cafehip_ctx* c)
         // (151-wide, 160 k rows: 0.663 -> 0.644 ms; 62.5 k rows on 64 taxa: 1.444 -> 1.438; 40 k rows: the same plan either
         // way; profiles/r05/theta_sweep2_paired_tables.txt)
         else if (c->C < 200 && Fu >= 160 * std::max(c->n_cu, 1)) theta = 0.7;
+        // round 6, with k2c_gemm: on a WIDE matrix (16 row tiles: 32-state tiles, 0.77 of the matrix peak, no parked vectors) a
+        // table product is cheaper than a walk product even where nothing is shared, so a large table takes EVERY node below
+        // the root as a table and the walk is the root step alone: configs[2] 1.951 -> 1.856 ms (0.9: 1.892), configs[4]
+        // 1.990 -> 1.900; on a 151-wide matrix (16-state tiles) it is 14 % slower and the threshold stays
+        // (profiles/r06/theta_sweep_k2c_gemm.txt).  The tables then grow to (internal nodes) x rows x LD doubles at most:
+        // kept below 8 GiB per parameter set and below the 2^31-element offsets, else the plan is rebuilt with 0.7.
+        else if (c->C >= 200 && Fu >= 160 * std::max(c->n_cu, 1) && c->opt.k2c_gemm != 0) theta = 1.0;
     }
-    if (c->opt.compress_theta >= 0) theta = std::min(c->opt.compress_theta, 1.0);
+    if (theta_retry >= 0) theta = theta_retry;
+    else if (c->opt.compress_theta >= 0) theta = std::min(c->opt.compress_theta, 1.0);
     const size_t limit = (size_t)(theta * Fu);
     const int max_level = c->opt.compress_max_level > 0 ? c->opt.compress_max_level : INT_MAX;
     // a table whose walk is one round of workgroups (at most 64 rows each): an evaluation is a chain of launches and
@@ -249,7 +257,12 @@ int rebuild_compression(cafehip_ctx* c)
             n_idx += 2 * (size_t)D[v];
             p.states += D[v];
         }
-    if (elems >= ((size_t)1 << 31) || n_idx >= ((size_t)1 << 31)) { p = cafehip_ctx::CompressPlan(); return 0; }
+    if (elems >= ((size_t)1 << 31) || n_idx >= ((size_t)1 << 31) || elems * sizeof(double) > ((size_t)8 << 30)) {
+        p = cafehip_ctx::CompressPlan();
+        // (too many states for one allocation / the 32-bit offsets: once more with the threshold that shares, then not at all)
+        if (theta > 0.7 && theta_retry < 0) return rebuild_compression(c, 0.7);
+        return 0;
+    }
     p.table_elems = elems;
     // tiles, level by level (children's tables are complete before a level starts)
     p.level_first.assign(1, 0);

@@ -14,7 +14,7 @@ import sys
 
 
 def short(name):
-    for key in ("k1_build_matrices_rb", "k1_build_matrices", "k1e_fold_error", "k2c_nodes", "k2_prune_mfma4", "k2_prune_mfma",
+    for key in ("k1_build_matrices_rb", "k1_build_matrices", "k1e_fold_error", "k2c_gemm", "k2c_nodes", "k2_prune_mfma4", "k2_prune_mfma",
                 "k2_prune_v1", "k3_score_x", "k3_score", "k3_cluster_score", "k_fetch_small", "k_x_collect", "ncclDevKernel", "rccl"):
         if key in name:
             return key

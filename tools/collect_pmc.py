@@ -4,7 +4,7 @@ two rocprofv3 passes per workload (FETCH_SIZE and WRITE_SIZE cannot share a pass
 --kernel-trace only (the PMC guidance of /opt/skills/guides/MI355X_MICROARCH.md).  On gfx950 FETCH_SIZE tallies
 128-byte requests at 64 bytes: it is doubled; WRITE_SIZE is taken as reported -- both factors measured on known-bytes
 kernels with this walk's access patterns (profiles/r03_fetch_size_calibration.txt: x2.000 / x1.000).  Writes
-<out>/<ROUND_TAG, default r05>_pmc_traffic.json (keys "<config>:<families per launch>:<k2|mcnull>") and a text summary.
+<out>/<ROUND_TAG, default r06>_pmc_traffic.json (keys "<config>:<families per launch>:<k2|mcnull>") and a text summary.
 
     python tools/collect_pmc.py [out_dir]          (on the GPU box; needs rocprofv3)"""
 import glob
@@ -34,7 +34,7 @@ def run_pass(counter, cmd, out_dir, tag, largest=0):
             continue
         if "k2_prune" in name:
             agg.setdefault(name, []).append(v)
-        elif "k2c_nodes" in name:
+        elif "k2c_nodes" in name or "k2c_gemm" in name:
             tables.append(v)
     # the dominant kernel = the instantiation launched most often (the tuner's pick; the timed launches)
     name = max(agg, key=lambda k: len(agg[k]))
@@ -71,15 +71,15 @@ def main():
             "write_kib": write_kib, "traffic_bytes": traffic, "fetch_factor": 2,
             "tables_traffic_bytes": tables, "tables_fetch_kib_raw": t_fetch, "tables_write_kib": t_write,
             "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate runs), FETCH_SIZE x2 / WRITE_SIZE x1 (calibrated: profiles/r03_fetch_size_calibration.txt), "
-                    "mean over the second half of the kernel's launches; tables_* = the k2c_nodes launches of one "
+                    "mean over the second half of the kernel's launches; tables_* = the k2c_gemm / k2c_nodes launches of one "
                     "evaluation (factor tables of compressed subtrees), 0 where the table does not compress",
         }
         lines.append("%-22s %-60s launches %4d  FETCH_SIZE %12.1f KiB (x2 = %12.1f)  WRITE_SIZE %12.1f KiB  -> %.3f MB per launch"
-                     "   + k2c_nodes per evaluation: FETCH %.1f KiB (x2) WRITE %.1f KiB -> %.3f MB"
+                     "   + factor tables per evaluation: FETCH %.1f KiB (x2) WRITE %.1f KiB -> %.3f MB"
                      % ("%s:%d:%s" % (cfg, F, kind), kname[:60], n, fetch_kib, 2 * fetch_kib, write_kib, traffic / 1e6,
                         t_fetch, t_write, tables / 1e6))
         print(lines[-1], flush=True)
-    tag = os.environ.get("ROUND_TAG", "r05")
+    tag = os.environ.get("ROUND_TAG", "r06")
     json.dump(res, open(os.path.join(out_dir, tag + "_pmc_traffic.json"), "w"), indent=1)
     open(os.path.join(out_dir, tag + "_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
 
