@@ -118,7 +118,8 @@ int rebuild_compression(cafehip_ctx* c, double theta_retry = -1.0)
         // 1.990 -> 1.900; on a 151-wide matrix (16-state tiles) it is 14 % slower and the threshold stays
         // (profiles/r06/theta_sweep_k2c_gemm.txt).  The tables then grow to (internal nodes) x rows x LD doubles at most:
         // kept below 8 GiB per parameter set and below the 2^31-element offsets, else the plan is rebuilt with 0.7.
-        else if (c->C >= 200 && Fu >= 160 * std::max(c->n_cu, 1) && c->opt.k2c_gemm != 0) theta = 1.0;
+        // (from 8 k rows on: 10 k rows 0.392 -> 0.365 ms, 20 k 0.624 -> 0.533, 40 k 0.949 -> 0.888, 100 k 1.941 -> 1.845)
+        else if (c->C >= 200 && Fu >= 32 * std::max(c->n_cu, 1) && c->opt.k2c_gemm != 0) theta = 1.0;
     }
     if (theta_retry >= 0) theta = theta_retry;
     else if (c->opt.compress_theta >= 0) theta = std::min(c->opt.compress_theta, 1.0);
