@@ -435,6 +435,27 @@ def roofline_of(leg, F_local):
                              "not a utilisation (it can exceed the peak: see algorithmic_credit)",
         "useful_TFLOP/s": useful * F_local / (k2_ms * 1e-3) / 1e12,
     }
+    if compressed and tables_ms > walk_ms:
+        # Round 6: on a wide matrix every node below the root is a factor table (threshold 1.0) and the walk is the root step alone
+        # -- gathers, no matrix instruction.  The DOMINANT kernel is then k2c_gemm, and the top-level fields describe its launches
+        # of one evaluation (one per level, back to back: avg_launch_ms is their sum, as rocprofv3's per-evaluation total of k2c_gemm)
+        ft = roof["factor_tables"]
+        roof["family_walk"] = {"kernel": roof["kernel"], "avg_launch_ms": walk_ms, "issued_flops_per_launch": walk_fl, "achieved_TFLOP/s": achieved,
+                               "frac": frac, "what": "the walk of the reduced tree (here: the root step over gathered table rows + the posterior)"}
+        roof["kernel"] = "k2c_gemm (v_mfma_f64_16x16x4), the %d level launches of one evaluation" % ft["launches_per_evaluation"]
+        roof["kernel_does"] = ("factor tables of ALL nodes below the root, one launch per level (children before parents): 16 or 32 states per "
+                               "workgroup, node vectors formed chunk by chunk beside the matrix instructions; the family walk behind them is "
+                               "the root step alone (family_walk)")
+        roof["achieved"] = ft["achieved_TFLOP/s"]
+        roof["frac"] = ft["frac"]
+        roof["issued_flops_per_launch"] = table_fl
+        roof["flops_counted"] = ("matrix-instruction flops ISSUED by the level launches of one evaluation, tile padding included: 16-state slots "
+                                 "x roundup16(C) x roundup4(C) x 2")
+        roof["avg_launch_ms"] = tables_ms
+        roof["min_launch_ms"] = float(km[:, 3].min())
+        roof["max_launch_ms"] = float(km[:, 3].max())
+        roof["median_launch_ms"] = float(np.median(km[:, 3]))
+        roof["launches_per_evaluation"] = ft["launches_per_evaluation"]
     credit = {
         "what": "SURVEY.md 8(d) F_alg = 2*N_el flops and B_alg = 8*N_el bytes per family evaluation: what the "
                 "reference's per-family dense mat-vecs execute/stream; a rate comparable with the CPU path, "
@@ -469,14 +490,20 @@ def minimal_traffic_bytes(wl, eng_desc, F_local, batch_rows=None):
                 "total": batch_rows * (tree.n_leaves + 3) * 4 + matrices + batch_rows * 8}
     if m and "used=1" in eng_desc:
         states, cols = int(m.group(1)), int(m.group(2))
-        tables = states * LD * 8
+        mt = re.search(r"top_states=(\d+)", eng_desc)
+        top = int(mt.group(1)) if mt else states
+        tables_all = states * LD * 8
+        tables = top * LD * 8            # rows the WALK gathers from: the tables of the maximal compressed nodes
         idx = F_local * cols * 4
     else:
-        tables, idx = 0, F_local * tree.n_leaves * 4
+        tables, tables_all, idx = 0, 0, F_local * tree.n_leaves * 4
     outputs = F_local * (8 + 8 + 4)
     return {"counts_index": idx, "matrices_once": matrices, "factor_tables_read_once": tables, "outputs": outputs,
             "total": idx + matrices + tables + outputs,
-            "factor_tables_build": {"write_once": tables, "matrices_once": matrices, "total": tables + matrices}}
+            "factor_tables_build": {"write_once": tables_all, "child_rows_read_once": tables_all - tables, "matrices_once": matrices,
+                                    "total": 2 * tables_all - tables + matrices,
+                                    "what": "every table row written once; every row of a table that is not at the top of its subtree "
+                                            "gathered at least once by its parent's tiles; one copy of the matrices"}}
 
 
 def pmc_traffic(config, families, kernel="k2", minimal=None):
@@ -503,6 +530,21 @@ def pmc_traffic(config, families, kernel="k2", minimal=None):
         out["traffic_minimal_bytes"] = minimal["total"]
         out["traffic_minimal_breakdown"] = minimal
     return out
+
+
+def apply_traffic(roof, pm):
+    """pmc_traffic() describes the walk's launch at the top level and the table launches beside it; where the table launches are
+    the dominant kernel (roofline_of put the walk under `family_walk`) the two change places."""
+    if "family_walk" in roof and pm.get("factor_tables_traffic") is not None:
+        pm = dict(pm)
+        roof["family_walk"].update({"traffic": pm.get("traffic"), "traffic_minimal_bytes": pm.get("traffic_minimal_bytes"),
+                                    "traffic_over_minimal": pm.get("traffic_over_minimal")})
+        pm["traffic"] = pm.pop("factor_tables_traffic")
+        if pm.get("traffic_minimal_breakdown", {}).get("factor_tables_build"):
+            pm["traffic_minimal_bytes"] = pm["traffic_minimal_breakdown"]["factor_tables_build"]["total"]
+        if "factor_tables_traffic_over_minimal" in pm:
+            pm["traffic_over_minimal"] = pm.pop("factor_tables_traffic_over_minimal")
+    roof.update(pm)
 
 
 def measured_peaks(device):
@@ -792,7 +834,7 @@ def main():
     if rank == 0 and leg.kernel_ms:
         roof, credit, kms, desc = roofline_of(leg, F_local)
         minimal = minimal_traffic_bytes(wl, desc, F_local)
-        roof.update(pmc_traffic(args.config if args.table == "synthetic" else wl.name, F_local, minimal=minimal))
+        apply_traffic(roof, pmc_traffic(args.config if args.table == "synthetic" else wl.name, F_local, minimal=minimal))
         out["roofline"] = roof
         out["algorithmic_credit"] = credit
         out["kernel_ms"] = kms
@@ -838,7 +880,7 @@ def main():
             leg2["table_generation_s"] = t_gen
             leg2["config"] = "BASELINE.json configs[%s]: %s" % (key, w2.desc)
             minimal = minimal_traffic_bytes(w2, leg2["engine"], len(w2.counts))
-            leg2["roofline"].update(pmc_traffic(cname, len(w2.counts), minimal=minimal))
+            apply_traffic(leg2["roofline"], pmc_traffic(cname, len(w2.counts), minimal=minimal))
             out["configs"][key] = leg2
 
     if rank == 0 and world == 1 and not multi and not args.no_search and args.table == "synthetic":
@@ -934,6 +976,7 @@ def strong_leg(args, eng, comm, rank, world, local_rank):
         r, credit, kms, desc = roofline_of(leg, len(w.counts))
         roof = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "median_launch_ms", "launch_samples",
                                   "issued_flops_per_launch", "factor_tables", "pruning_total", "whole_evaluation")}
+        roof.update({k: r[k] for k in ("family_walk", "launches_per_evaluation", "kernel_does") if k in r})
         roof["kernel_ms"] = kms
         roof["engine"] = desc
         roof["algorithmic_credit"] = {k: credit[k] for k in ("F_alg_over_fp64_peak", "B_alg_over_hbm_peak")}
@@ -979,6 +1022,7 @@ def table_leg(w, local_rank, options=None, steps=100, blocks=3):
                                              "issued_flops_per_launch", "factor_tables", "pruning_total", "whole_evaluation")},
            "algorithmic_credit": {k: credit[k] for k in ("F_alg_over_fp64_peak", "B_alg_over_hbm_peak")},
            "setup_ms": leg.setup["set_families_ms"], "engine": desc, "last_score": last}
+    res["roofline"].update({k: roof[k] for k in ("family_walk", "launches_per_evaluation", "kernel_does") if k in roof})
     if options:
         res["options"] = options
     leg.eng.close()

@@ -1661,8 +1661,8 @@ const char* cafehip_describe(cafehip_ctx* c)
              c->k2_cfg[2], c->k2_cfg[3], c->k2_grid, c->k2_park_slots);
     c->desc = buf;
     if (c->cp.valid) {
-        snprintf(buf, sizeof buf, " compressed(nodes=%d levels=%zu states=%ld walk_steps=%zu walk_cols=%d used=%d level_tiles=", c->cp.n_nodes,
-                 c->cp.level_first.size() - 1, c->cp.states, c->cp.sched.ops.size(), c->cp.n_cols, (int)c->last_compressed);
+        snprintf(buf, sizeof buf, " compressed(nodes=%d levels=%zu states=%ld top_states=%ld walk_steps=%zu walk_cols=%d used=%d level_tiles=", c->cp.n_nodes,
+                 c->cp.level_first.size() - 1, c->cp.states, c->cp.top_states, c->cp.sched.ops.size(), c->cp.n_cols, (int)c->last_compressed);
         c->desc += buf;
         for (size_t l = 0; l + 1 < c->cp.level_first.size(); ++l) c->desc += (l ? "/" : "") + std::to_string(c->cp.level_first[l + 1] - c->cp.level_first[l]);
         c->desc += ")";

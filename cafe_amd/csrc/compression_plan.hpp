@@ -331,6 +331,7 @@ int rebuild_compression(cafehip_ctx* c, double theta_retry = -1.0)
     for (int v = 0; v < n; ++v) {
         if (under[v]) continue;
         if (!internal(v) || comp[v]) {
+            if (internal(v)) p.top_states += D[v];
             leafcol_of[v] = p.n_cols++;
             p.col_leaf.push_back(internal(v) ? -1 : v / 2);
         }

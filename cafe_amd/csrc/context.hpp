@@ -149,6 +149,7 @@ struct cafehip_ctx {
         double* d_tables = nullptr;
         size_t tables_cap = 0;              // elements
         long states = 0;                    // sum of D over the compressed nodes
+        long top_states = 0;                // ... over the MAXIMAL compressed nodes (the tables the walk gathers from)
     } cp;
     // run-time switches (cafehip_set_option; CAFEHIP_<NAME> in the environment is read ONCE, by cafehip_create)
     struct Options {

@@ -54,7 +54,8 @@ void cafehip_destroy(cafehip_ctx *ctx);
 /* Run-time switches of a context (A/B runs, tuning sweeps, tests of the alternative kernels).  Every one has a
  * default that is the product path; none changes a value beyond what DESIGN.md states for it.  key / value:
  *   compress        0|1        subtree-state compression of the objective path (1)
- *   compress_theta  0..1       share of the unique rows a node's distinct states may reach (by table size)
+ *   compress_theta  0..1       share of the unique rows a node's distinct states may reach (by table size and matrix width;
+ *                              1.0 = every node below the root is a factor table: the default on matrices of >= 200 columns)
  *   compress_min    n          unique rows below which a table is left alone (64)
  *   compress_drop_top 0|1      launch-bound tables (one round of walk workgroups): top levels of the compressed forest whose
  *                              nodes are cheaper as walk steps than the level's launch go back to the walk (1)
@@ -63,6 +64,9 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *   errband         0|1        banded error models as short sums of column gathers (1)
  *   k1              auto|exact|perterm   arithmetic form of the matrix build (auto: register-blocked product form)
  *   k1kpb           n          matrices per K1 workgroup (1)
+ *   k1_balance      0|1|2|3|11 order in which the register-blocked build deals its (tile, key) pairs: 1 = heaviest first where a
+ *                              launch is at least three workgroups per CU, grid order otherwise (default); 0 grid order; forced:
+ *                              2 alternating, 3 heaviest first, 11 heavy half / light half.  Same matrices bit for bit
  *   k2              auto|v1|v1ref   pruning kernel: matrix cores | row-per-thread vector FMA | row-per-thread in the
  *                              reference's arithmetic (separate multiply and add per term: with k1=exact the oracle's bits)
  *   mfma            auto|4|16  matrix instruction shape of the walk
@@ -72,7 +76,11 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *   k2slots         0|1        park scratch owned per resident workgroup (1) | one region per family tile
  *   ldspark         n          park buffers kept in LDS (empty: by residency)
  *   vitlds          0|1        Viterbi argmax tables in LDS (0: global scratch)
- *   k2c_batch       0|1        factor-table kernel gathers the child columns of a state in one batch (1)
+ *   k2c_gemm        -1|0|1     factor tables by k2c_gemm, the chunk-pipelined table kernel of round 6 (default), 0 = k2c_nodes
+ *   k2c_nst         0|1|2|4    k2c_gemm: state tiles of 16 per workgroup (0: by level size and matrix width)
+ *   k2c_xcd         0|1        k2c_gemm: on levels of at least four tiles per CU, XCD x takes a contiguous eighth of the tiles (1)
+ *   k2_skip_epilogue 0|1       ABLATION: the walk ends behind its root step, the posterior outputs are NOT written (0)
+ *   k2c_batch       0|1        k2c_nodes gathers the child columns of a state in one batch (1)
  *   k2c_pair        -1|0|1     factor-table kernel deals a wave TWO row tiles and reads both with one 16-byte load per k-step
  *                              (half the vector-memory instructions, four tiles resident per CU instead of two): -1 = on levels
  *                              of at least k2c_pair_min tiles per CU (default), 0 = never, 1 = always.  Bit-identical either way
