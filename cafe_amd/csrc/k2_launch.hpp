@@ -326,6 +326,10 @@ int launch_mfma4_g(cafehip_ctx* c, K2MfmaArgs a, int G, int nrt_w, int grid, int
 {
     // only the (G, NRT_W) pairs within the register budget are instantiated
     const void* fn = k2_mfma4_kernel(G, nrt_w);
+    // at most 64 root sizes (the reference's test1 table, its example): the instantiation with a lane per family in the posterior
+    // epilogue (k2_walk4s.hip; test1 walk 36.1 -> 32.3 us); never in batch mode, whose "epilogue" copies root rows
+    if (c->opt.k2_small_r && a.R <= 64 && a.NF <= 96 && a.col_max == nullptr && !a.skip_epilogue)
+        if (const void* fs = k2_mfma4_small_r_kernel(G, nrt_w, 1)) fn = fs;
     if (!fn) return fail("unsupported 4x4 wave grid G=%d NRT_W=%d", G, nrt_w);
     if (grant_lds(c, fn, lds, 64 * 1024)) return -1;
     if (k2_fit_grid(c, fn, a, &grid, block, lds)) return -1;

@@ -513,6 +513,101 @@ __device__ __forceinline__ void k2_epilogue_impl(const K2MfmaArgs& a, const doub
     }
 }
 
+// The posterior with a LANE per family, for tables of at most 64 root sizes (the reference's test1 table: 30; its example: 42).
+// The wave-per-family form above runs a wave's families one after the other, each a chain of ~500 dependent instructions that
+// does not shrink with R: 7.1 us of the 36.6 us test1 walk (option k2_skip_epilogue).  Here lane l of EVERY wave owns family
+// l (+ 64 per pass) and wave w scans the root sizes i == w (mod waves): the families' chains run side by side.  Partial results
+// meet in LDS through integer atomics on the doubles' bit patterns (likelihoods and products are >= +0: the patterns order like
+// the values), three barriers in all:
+//   pass 1: max_i L_i and max_i L_i * prior_i                                           -> atomicMax
+//   pass 2: the lowest i with L_i == max (first maximum wins, libcommon/mathfunc.c:9-24) -> atomicMin; the maximum over the
+//           candidates {i : L_i * prior_i >= (1 - 1e-9) max product} of exp(log L_i + log prior_i) (cafe/lambda.cpp:681 as
+//           written) -> atomicMax; a family whose largest product is below 1e-290 takes every i.
+// The same values as the form above -- the maximum over the candidates IS the maximum over all root sizes, every term is the
+// same expression on the same operands (tests: test_small_root_range_epilogue_equals_the_wave_form).  The prior and its
+// logarithm of root size `lane` sit in a register of every wave and are read with v_readlane (i is wave-uniform).
+// A separate instantiation of the 4-family walk (k2_prune_mfma4<G, NRT_W, true>, k2_walk4s.hip), NOT a branch inside the other
+// kernels: compiled in beside the wave form it cost the configs[2] walk 8 % by its code size alone (round 6), and with more than
+// 64 root sizes it is slower than the wave form (configs[1] 56.9 -> 58.2 us).
+template <int PR>   // R <= 64 * PR
+__device__ __forceinline__ void k2_epilogue_small_r(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0, size_t out_off,
+                                                    int wave_in, int lane, int nwaves)
+{
+    unsigned long long* maxbits = reinterpret_cast<unsigned long long*>(scratch);   // [NF] max_i L_i
+    unsigned long long* qbits = maxbits + a.NF;                                      // [NF] max_i L_i * prior_i
+    unsigned long long* pbits = qbits + a.NF;                                        // [NF] max posterior
+    int* amin = reinterpret_cast<int*>(pbits + a.NF);                                // [NF] argmax (lowest index)
+    const int wave = __builtin_amdgcn_readfirstlane(wave_in);
+    const int tid = wave * 64 + lane, nthreads = nwaves * 64;
+    const int R = a.R;   // <= 64 * PR
+    double pr[PR], lpr[PR];
+#pragma unroll
+    for (int q = 0; q < PR; ++q) {
+        pr[q] = (lane + 64 * q < R) ? a.prior[lane + 64 * q] : 0.0;
+        lpr[q] = (lane + 64 * q < R) ? a.logprior[lane + 64 * q] : 0.0;
+    }
+    auto bcast = [](const double (&x)[PR], int i) {   // element i of the array spread over the lanes (i wave-uniform)
+        double r = 0.0;
+#pragma unroll
+        for (int q = 0; q < PR; ++q) {
+            const double xq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x[q]), i & 63),
+                                               __builtin_amdgcn_readlane(__double2loint(x[q]), i & 63));
+            if (PR == 1 || (i >> 6) == q) r = xq;
+        }
+        return r;
+    };
+    __syncthreads();   // (the scratch overlays the walk's counts and park-slot word, which thread 0 has just read)
+    for (int f = tid; f < a.NF; f += nthreads) {
+        maxbits[f] = 0ull;
+        qbits[f] = 0ull;
+        pbits[f] = 0ull;
+        amin[f] = INT_MAX;
+    }
+    __syncthreads();
+    for (int f0 = 0; f0 < a.NF; f0 += 64) {   // (wave-uniform trips; a lane beyond the last family scans that family and stores nothing)
+        const int f = f0 + lane;
+        const double* L = Lbuf + (size_t)min(f, a.NF - 1) * a.LDv;
+        double best = 0.0, q = 0.0;
+        for (int i = wave; i < R; i += nwaves) {
+            const double v = L[i];
+            best = fmax(best, v);
+            q = fmax(q, v * bcast(pr, i));
+        }
+        if (f < a.NF) {
+            atomicMax(&maxbits[f], (unsigned long long)__double_as_longlong(best));
+            atomicMax(&qbits[f], (unsigned long long)__double_as_longlong(q));
+        }
+    }
+    __syncthreads();
+    for (int f0 = 0; f0 < a.NF; f0 += 64) {
+        const int f = f0 + lane, fc = min(f, a.NF - 1);
+        const double* L = Lbuf + (size_t)fc * a.LDv;
+        const double M = __longlong_as_double((long long)maxbits[fc]);
+        const double qmax = __longlong_as_double((long long)qbits[fc]);
+        const bool filtered = qmax >= 1e-290;
+        const double thr = qmax * (1.0 - 1e-9);
+        int bi = INT_MAX;
+        double bestp = 0.0;
+        for (int i = wave; i < R; i += nwaves) {
+            const double v = L[i];
+            if (v == M) bi = min(bi, i);
+            if (!filtered || v * bcast(pr, i) >= thr) bestp = fmax(bestp, exp(log(v) + bcast(lpr, i)));
+        }
+        if (f < a.NF) {
+            if (bi != INT_MAX) atomicMin(&amin[f], bi);
+            atomicMax(&pbits[f], (unsigned long long)__double_as_longlong(bestp));
+        }
+    }
+    __syncthreads();
+    for (int f = tid; f < a.NF; f += nthreads) {
+        const int u = fam0 + f;
+        if (u >= a.Fu) continue;
+        a.max_lik[out_off + u] = __longlong_as_double((long long)maxbits[f]);
+        a.argmax[out_off + u] = amin[f];
+        a.max_post[out_off + u] = __longlong_as_double((long long)pbits[f]);
+    }
+}
+
 __device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* Lbuf, void* scratch, int fam0, size_t out_off,
                                             bool batch, int wave, int lane, int nwaves)
 {
@@ -813,7 +908,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 // Y[fam_base + 4g + (l>>4)][row0 + (l&15)]: the same walk, gathers and stores as k2_prune_mfma with
 // (i, r) flattened to g = 4i + r.
 // ====================================================================================
-template <int G, int NRT_W>
+template <int G, int NRT_W, int SMALL_R = 0>   // SMALL_R > 0: lane-per-family epilogue for R <= 64 * SMALL_R
 __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 {
     extern __shared__ double Lbuf[];                          // [NF][LDv]
@@ -1071,7 +1166,8 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     k2_release_park_slot(a, s_colmax + a.NF, tid);
     if (a.gen_done && tid == 0) atomicAdd(a.gen_done, 1);
     if (a.skip_epilogue) return;   // (ablation only: what the posterior epilogue costs the launch)
-    k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
+    if constexpr (SMALL_R > 0) k2_epilogue_small_r<SMALL_R>(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, wave, lane, blockDim.x >> 6);
+    else k2_epilogue(a, Lbuf, s_cnt, fam0, (size_t)blockIdx.y * a.Fu, batch, wave, lane, blockDim.x >> 6);
     K2_STAMP(2 + 6 * a.n_ops);
 }
 

@@ -23,6 +23,8 @@ constexpr bool k2_fits16(int nft_w, int nrt_w) { return nft_w >= 1 && nft_w <= 2
 constexpr bool k2_fits4(int G, int nrt_w) { return G >= 1 && G <= 7 && nrt_w >= 1 && nrt_w <= 7 && G * nrt_w <= 18; }   // (8, 1): 20 B of scratch
 const void* k2_mfma16_kernel(int nft_w, int nrt_w);
 const void* k2_mfma4_kernel(int G, int nrt_w);
+// k2_walk4s.hip: the same walk with the lane-per-family posterior epilogue, R <= 64 and NF <= 96 only (NULL: not instantiated)
+const void* k2_mfma4_small_r_kernel(int G, int nrt_w, int pr = 1);   // pr: R <= 64 * pr (1, 2)
 
 // k2c_tables.hip: factor tables of compressed subtrees, K2cArgs (batch_gathers: the child columns of a state in one batch)
 const void* k2c_kernel(int nft_w, int nrt_w, bool batch_gathers, bool pair);

@@ -450,3 +450,44 @@ def test_matrices_do_not_depend_on_the_order_the_build_deals_its_tiles():
         else:
             assert score == want[0]
             assert all(np.array_equal(a, b) for a, b in zip(mats, want[1]))
+
+
+@pytest.mark.parametrize("m,lam_v,F", [(20, 0.008, 3000), (40, 0.004, 1500), (12, 1e-7, 600)])
+def test_small_root_range_epilogue_equals_the_wave_form(m, lam_v, F):
+    """Tables of at most 64 root sizes run the 4-family walk with a lane per family in its posterior epilogue (k2_walk4s.hip,
+    option k2_small_r): per-family maximum likelihood, its first index and the maximum posterior (cafe/lambda.cpp:657-689) must
+    be the wave-per-family form's, bit for bit -- on every wave grid the measurement tries, with families whose largest
+    L * prior is below 1e-290 (tiny rate, spread counts: every root size goes through exp(log + log)) and with zero rows."""
+    import cafe_amd
+    t = O.PyTree("(((a:6,b:6):5,(c:4,(d:2,e:2):2):7):9,((f:3,g:3):8,h:11):9)")
+    rs = np.random.RandomState(m)
+    counts = rs.poisson(2.5, size=(F, t.n_leaves)).clip(0, m).astype(np.int32)
+    counts[0, :] = 0
+    counts[1, 0] = m
+    counts[2, :] = [m, 0, m, 0, m, 0, m, 0]
+    rng = cafe_amd.init_family_size(m)
+    assert rng.root_max - rng.root_min + 1 <= 64
+    prior = O.prior_poisson(1000, rng.root_min, 2.5)
+    lam = np.full(t.n_nodes, lam_v)
+    mu = np.full(t.n_nodes, -1.0)
+    got = {}
+    for form in (0, 1):
+        eng = cafe_amd.Engine(0)
+        try:
+            eng.set_option("k2_small_r", form)
+            eng.set_option("mfma", 4)
+            eng.set_tree(t.parent, t.left, t.right, t.branchlength)
+            eng.set_families(counts, rng)
+            rows = [eng.get_posterior(lam, mu, prior, per_family=True) for _ in range(12)]
+            for r in rows[1:]:
+                assert r[0] == rows[0][0] or (np.isnan(r[0]) and np.isnan(rows[0][0]))
+                assert all(np.array_equal(x, y) for x, y in zip(r[2:5], rows[0][2:5]))
+            got[form] = rows[0]
+        finally:
+            eng.close()
+    assert got[0][1] == got[1][1]
+    assert got[0][0] == got[1][0] or (np.isinf(got[0][0]) and np.isinf(got[1][0]))
+    for x, y in zip(got[0][2:5], got[1][2:5]):
+        assert np.array_equal(x, y)
+    if lam_v < 1e-6:
+        assert (got[1][4][:F] < 1e-290).any()   # the unfiltered path really ran
