@@ -135,6 +135,8 @@ struct cafehost_session {
     // its GPU (lhtest deals its files to the ranks: whole searches per GPU instead of 59-family tables cut N ways)
     bool solo = false;
     int opt_lhtest_deal = 1;                              // cafehost_set_option "lhtest_deal": 0 = every rank runs every file, sharded
+    int opt_grid_deal = -1;                               // "grid_deal": lambda -r deals its grid points to the ranks: -1 where the table does not fill a GPU, 0 never, 1 always
+    long long grid_points_dealt = 0;
     bool mute_log = false;
 
     void hipapi_check(hipError_t e, const char* what)
@@ -523,6 +525,14 @@ struct cafehost_session {
         int wg = 0, cu = 0;
         if (cafehip_launch_info(ctx, &wg, &cu) != 0) return false;
         return wg > 0 && 2 * wg <= cu;
+    }
+
+    // (sharded job) would the WHOLE table be more than one round of walk workgroups on one GPU?  Then cutting it N ways pays.
+    bool whole_table_fills_a_gpu()
+    {
+        int wg = 0, cu = 0;
+        if (cafehip_launch_info(ctx, &wg, &cu) != 0 || wg <= 0) return true;
+        return (long long)wg * std::max(shard_world, 1) > (long long)cu;
     }
 
     void prefetch_points(const std::vector<std::vector<double>>& pts)
@@ -1316,6 +1326,70 @@ struct cafehost_session {
             }
             std::vector<int> idx(ranges.size());
             std::vector<double> x(ranges.size());
+            auto point = [&](long long e, std::vector<double>& y) {
+                y.resize(ranges.size());
+                for (int j = (int)ranges.size() - 1; j >= 0; --j) {
+                    y[j] = ranges[j].step * (double)(e % size[j]) + ranges[j].start;
+                    e /= size[j];
+                }
+            };
+            // Sharded job, small table: the grid points are independent evaluations (cafe_lambda_distribution loops over them,
+            // cafe/lambda.cpp:192-231) and a table that does not fill one GPU gains nothing from being cut N ways, so rank r
+            // evaluates points r, r + N, ... of the grid on the WHOLE table alone (`solo`, as lhtest deals its files), the values
+            // are gathered and the loop below finds every point's score ready: the log lines and the file are the one-rank
+            // run's byte for byte (the score's bits do not depend on how the table is cut).  A table that fills the chip stays
+            // sharded: every point on all ranks is the same work without a second upload.
+            std::vector<double> dealt_score;
+            std::vector<int32_t> dealt_zero;
+            if (native_comm && shard_world > 1 && opt_grid_deal != 0 && total >= 2LL * shard_world && total < (1LL << 24) &&
+                (opt_grid_deal > 0 || !whole_table_fills_a_gpu())) {
+                const long long per = (total + shard_world - 1) / shard_world;
+                std::vector<double> mine((size_t)per * 2, 0.0), all((size_t)per * 2 * shard_world, 0.0);
+                std::string problem;
+                solo = true;
+                device_families_current = false;
+                try {
+                    upload();
+                    std::vector<double> y, nl, nm;
+                    const int ncheck = has_mu ? num_params : num_lambdas;
+                    for (long long e = shard_rank, k = 0; e < total; e += shard_world, ++k) {
+                        point(e, y);
+                        bool neg = false;
+                        for (int i = 0; i < ncheck && i < (int)y.size(); ++i) neg = neg || y[i] < 0;
+                        int32_t zero = -1;
+                        double sc = 0;
+                        if (!neg) {   // (objective() never evaluates a negative rate)
+                            node_rates(y.data(), nl, nm);
+                            sc = evaluate(nl, nm, prior, zero);
+                        }
+                        mine[(size_t)2 * k] = sc;
+                        mine[(size_t)2 * k + 1] = (double)zero;
+                    }
+                } catch (const std::exception& ex) {
+                    problem = ex.what();   // the others are about to wait for this rank's values
+                }
+                solo = false;
+                device_families_current = false;   // the next evaluation loads this rank's block again
+                std::vector<char> ok(shard_world, 0);
+                const char my_ok = problem.empty() ? 1 : 0;
+                if (allgather(allgather_user, &my_ok, 1, ok.data(), 1) != 0) throw std::runtime_error("lambda -r: allgather failed");
+                for (int r = 0; r < shard_world; ++r)
+                    if (!ok[r]) {
+                        if (fp) fclose(fp);
+                        throw std::runtime_error("lambda -r: rank " + std::to_string(r) + " failed" + (r == shard_rank ? ": " + problem : std::string()));
+                    }
+                if (allgather(allgather_user, mine.data(), (long long)(mine.size() * sizeof(double)), all.data(), (long long)(mine.size() * sizeof(double))) != 0)
+                    throw std::runtime_error("lambda -r: allgather failed");
+                dealt_score.resize((size_t)total);
+                dealt_zero.resize((size_t)total);
+                for (long long e = 0; e < total; ++e) {
+                    const size_t at = (size_t)(e % shard_world) * (size_t)per * 2 + (size_t)(e / shard_world) * 2;
+                    dealt_score[(size_t)e] = all[at];
+                    dealt_zero[(size_t)e] = (int32_t)all[at + 1];
+                }
+                grid_points_dealt += total;
+                if (opt_timing && shard_rank == 0) fprintf(stderr, "lambda -r: %lld grid points dealt to %d ranks\n", total, shard_world);
+            }
             for (long long e = 0; e < total; ++e) {
                 long long rem = e;
                 for (int j = (int)ranges.size() - 1; j >= 0; --j) {
@@ -1323,7 +1397,10 @@ struct cafehost_session {
                     rem /= size[j];
                 }
                 for (size_t j = 0; j < ranges.size(); ++j) x[j] = ranges[j].step * idx[j] + ranges[j].start;
-                if (e % CAFEHIP_MAX_SETS == 0) {
+                if (!dealt_score.empty()) {
+                    spec.clear();
+                    spec.push_back(SpecEntry{x, dealt_score[(size_t)e], dealt_zero[(size_t)e]});
+                } else if (e % CAFEHIP_MAX_SETS == 0) {
                     // the next grid points in one batched pass (small tables): same values, one launch
                     std::vector<std::vector<double>> pts;
                     for (long long e2 = e; e2 < total && e2 < e + CAFEHIP_MAX_SETS; ++e2) {
@@ -2562,6 +2639,7 @@ int cafehost_create(cafehost_session** out, int device_id, const char* log_path)
     if (const char* e = getenv("CAFEHOST_LOOKAHEAD")) s->opt_lookahead = atoi(e) != 0;
     if (getenv("CAFEHOST_TIMING")) s->opt_timing = true;
     if (const char* e = getenv("CAFEHOST_LHTEST_DEAL")) s->opt_lhtest_deal = atoi(e);
+    if (const char* e = getenv("CAFEHOST_GRID_DEAL")) s->opt_grid_deal = atoi(e);
     if (const char* e = getenv("CAFEHOST_PRIOR_LOOKAHEAD")) s->opt_prior_lookahead = atoi(e);
     if (const char* e = getenv("CAFEHOST_REPORT_ARITH")) s->opt_report_reference = std::string(e) == "reference";
     *out = s;
@@ -2601,6 +2679,10 @@ int cafehost_set_option(cafehost_session* s, const char* key, const char* value)
     }
     if (k == "lhtest_deal") {
         s->opt_lhtest_deal = atoi(v.c_str());
+        return 0;
+    }
+    if (k == "grid_deal") {
+        s->opt_grid_deal = atoi(v.c_str());
         return 0;
     }
     if (k == "prior_file") {

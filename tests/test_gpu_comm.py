@@ -234,3 +234,34 @@ def test_lhtest_files_are_dealt_to_the_ranks_and_the_output_is_the_one_rank_file
     got, last, t = run(2, deal=False)
     assert got == one and last == last_one
     print("lhtest wall clock, 7 files, ranks sharing ONE device: %s; undealt 2 ranks %.2f s" % (times, t))
+
+
+def test_lambda_grid_points_are_dealt_to_the_ranks_and_the_surface_is_the_one_rank_file(tmp_path):
+    # cafe/lambda.cpp:192-231 (cafe_lambda_distribution): `lambda -r a:b:c` evaluates a grid of independent points.  In a
+    # sharded job on a table that does not fill a GPU, rank r evaluates points r, r + N, ... on the WHOLE table and the values
+    # are gathered (option grid_deal, CAFEHOST_GRID_DEAL): the log lines and the -o file must be the one-rank run's, byte for
+    # byte -- also with the dealing switched off (every rank evaluates every point on its block), and the session after it
+    # must be the one-rank session (the search that follows draws the same start on the same table).
+    GOLD = os.path.join(ROOT, "tests", "golden")
+    newick = "(((chimp:6,human:6):81,(mouse:17,rat:17):70):6,dog:93)"
+
+    def run(world, deal):
+        out = tmp_path / ("grid_%d_%d.txt" % (world, deal))
+        script = tmp_path / ("grid_%d_%d.sh" % (world, deal))
+        script.write_text("\n".join(["seed 10", "load -i %s -t 1" % os.path.join(GOLD, "example_data.tab"), "tree " + newick,
+                                     "lambda -r 0.001:0.0015:0.0175 -o %s" % out, "lambda -s"]) + "\n")
+        args = [CLI] + (["--gpus", str(world), "--same-device"] if world > 1 else []) + [str(script)]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=900, cwd=str(tmp_path),
+                           env=dict(os.environ, CAFEHIP_COMM_TIMEOUT_S="90", CAFEHOST_GRID_DEAL=str(deal), CAFEHOST_TIMING="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = re.findall(r"Lambda : \S+ & Score: \S+", r.stdout)
+        return open(out).read(), lines, ("grid points dealt" in r.stderr)
+
+    surface, lines, dealt = run(1, 1)
+    assert surface.count("\n") == 12 and len(lines) > 12 and not dealt
+    for world in (2, 3):
+        got, ln, dealt = run(world, 1)
+        assert dealt, world
+        assert got == surface and ln == lines, world
+    got, ln, dealt = run(2, 0)
+    assert not dealt and got == surface and ln == lines
