@@ -12,7 +12,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcafehip.so")
 
 # translation units of libcafehip.so: compiled in parallel into cafe_amd/lib/obj/, relinked when any object changes
-SOURCES = ["cafehip.hip", "cafehip_comm.hip", "k1_matrices.hip", "k2_walk16.hip", "k2_walk4.hip", "k2_walk4s.hip", "k2c_tables.hip", "k2c_gemm.hip", "k_misc.hip",
+SOURCES = ["cafehip.hip", "cafehip_comm.hip", "k1_matrices.hip", "k2_walk16.hip", "k2_walk16o.hip", "k2_walk4.hip", "k2_walk4o.hip", "k2_walk4s.hip", "k2c_tables.hip", "k2c_gemm.hip", "k_misc.hip",
            os.path.join("host", "cafe_host.cpp")]
 # per-unit flags: k2c_gemm keeps its accumulators in VGPRs (with 256 registers per lane the compiler otherwise shuttles them
 # between AGPRs inside the chunk loop and VGPRs across its back edge: 128 moves per chunk)

@@ -411,7 +411,7 @@ namespace {
 // ---- run-time switches ---------------------------------------------------------------------------------------
 // (name, what it selects) -- cafehip_set_option; the same names upper-cased behind CAFEHIP_ are read from the
 // environment ONCE, when the context is created (tools/ sweeps), never during an evaluation
-const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "compress_max_level", "compress_drop_top", "errfold", "errband", "k1", "k1kpb", "k1_balance", "k2_small_r", "k2_skip_epilogue", "k2", "mfma",
+const char* const kOptionNames[] = {"compress", "compress_theta", "compress_min", "compress_max_level", "compress_drop_top", "errfold", "errband", "k1", "k1kpb", "k1_balance", "k2_small_r", "k2_objective_kernels", "k2_skip_epilogue", "k2", "mfma",
                                     "k2cfg", "k2cfg4", "k2tune", "k2tune_log", "k2slots", "ldspark", "vitlds", "k2c_batch", "k2c_pair", "k2c_pair_min", "k2c_gemm", "k2c_nst", "k2c_xcd",
                                     "batch_trim", "batch_lockstep", "walk_lockstep", "batch_lockstep_slack", "exp_like_host", "matrix_cache",
                                     "matrix_cache_mb", "prefetch_where", "prefetch_kpb", "prearm", "comm"};
@@ -437,6 +437,7 @@ int set_option(cafehip_ctx* c, const std::string& key, const std::string& val)
         else return fail("option k1: auto | exact | perterm, got '%s'", val.c_str());
     } else if (key == "k1kpb") o.k1_kpb = std::max(1, iv);
     else if (key == "k2_small_r") o.k2_small_r = iv != 0;
+    else if (key == "k2_objective_kernels") o.k2_objective_kernels = iv != 0;
     else if (key == "k1_balance") o.k1_balance = iv;   // 0 off, 1 by launch size, 2 / 3: forced, alternating / heaviest first; 11: forced halves
     else if (key == "k2_skip_epilogue") o.k2_skip_epilogue = iv != 0;
     else if (key == "k2") {
@@ -557,7 +558,8 @@ struct KernelPreload {
         if (th.joinable()) th.join();
         th = std::thread([device] {
             if (hipSetDevice(device) != hipSuccess) return;
-            const void* fns[] = {k1_rb_kernel(), k2c_gemm_kernel(1, 1, 1, 512), k2_mfma4_kernel(1, 1), k2_mfma4_small_r_kernel(1, 1), k3_kernel(true), k2_mfma16_kernel(1, 1),
+            const void* fns[] = {k1_rb_kernel(), k2c_gemm_kernel(1, 1, 1, 512), k2_mfma4_objective_kernel(1, 1), k2_mfma4_small_r_kernel(1, 1), k3_kernel(true), k2_mfma16_objective_kernel(1, 1),
+                                 k2_mfma4_kernel(1, 1), k2_mfma16_kernel(1, 1),
                                  k2c_kernel(1, 1, true, false)};
             for (const void* fn : fns) {
                 hipFuncAttributes at;

@@ -175,6 +175,7 @@ struct cafehip_ctx {
         int k2c_pair = -1;            // k2c_nodes: two row tiles per wave read with one 16-byte load per k-step: -1 by level size, 0 never, 1 always (round 5)
         int k2_skip_epilogue = 0;     // ABLATION: the walk without its posterior epilogue (outputs invalid; profiles/r06)
         int k1_balance = 1;           // register-blocked K1: heavy tiles first, light tiles last (round 6)
+        int k2_objective_kernels = 1; // objective evaluations run the walk instantiations without the batch mode's code (k2_walk16o / k2_walk4o.hip)
         int k2_small_r = 1;           // 4-family walk: lane-per-family posterior epilogue where R <= 64 (k2_walk4s.hip)
         int k2c_gemm = -1;            // factor tables by k2c_gemm (round 6): -1 by level size, 0 never (k2c_nodes), 1 always
         int k2c_nst = 0;              // ... state tiles of 16 per workgroup: 0 by level size, else 1 | 2 | 4

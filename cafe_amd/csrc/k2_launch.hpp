@@ -167,7 +167,8 @@ int launch_mfma16(cafehip_ctx* c, K2MfmaArgs a, int nft_w, int nrt_w, int grid, 
 {
     // only the (NFT_W, NRT_W) pairs within the register budget (NFT_W * NRT_W <= 8 accumulator tiles, NRT_W <= 7:
     // no scratch spills) are instantiated
-    const void* fn = k2_mfma16_kernel(nft_w, nrt_w);
+    const bool objective = c->opt.k2_objective_kernels && a.col_max == nullptr && (a.err == nullptr || a.PTfold != nullptr);
+    const void* fn = objective ? k2_mfma16_objective_kernel(nft_w, nrt_w) : k2_mfma16_kernel(nft_w, nrt_w);
     if (!fn) return fail("unsupported 16x16 wave grid NFT_W=%d NRT_W=%d", nft_w, nrt_w);
     if (grant_lds(c, fn, lds, 64 * 1024)) return -1;
     if (k2_fit_grid(c, fn, a, &grid, block, lds)) return -1;
@@ -325,10 +326,13 @@ bool choose_mfma4_cfg(const cafehip_ctx* c, int n_items, K2Cfg* out, double* out
 int launch_mfma4_g(cafehip_ctx* c, K2MfmaArgs a, int G, int nrt_w, int grid, int block, size_t lds)
 {
     // only the (G, NRT_W) pairs within the register budget are instantiated
-    const void* fn = k2_mfma4_kernel(G, nrt_w);
+    // an objective evaluation (no per-row column limits, error model folded into the matrices or absent) runs the instantiation
+    // without the batch mode's code (option k2_objective_kernels)
+    const bool objective = c->opt.k2_objective_kernels && a.col_max == nullptr && (a.err == nullptr || a.PTfold != nullptr);
+    const void* fn = objective ? k2_mfma4_objective_kernel(G, nrt_w) : k2_mfma4_kernel(G, nrt_w);
     // at most 64 root sizes (the reference's test1 table, its example): the instantiation with a lane per family in the posterior
     // epilogue (k2_walk4s.hip; test1 walk 36.1 -> 32.3 us); never in batch mode, whose "epilogue" copies root rows
-    if (c->opt.k2_small_r && a.R <= 64 && a.NF <= 96 && a.col_max == nullptr && !a.skip_epilogue)
+    if (c->opt.k2_small_r && objective && a.R <= 64 && a.NF <= 96 && !a.skip_epilogue)
         if (const void* fs = k2_mfma4_small_r_kernel(G, nrt_w, 1)) fn = fs;
     if (!fn) return fail("unsupported 4x4 wave grid G=%d NRT_W=%d", G, nrt_w);
     if (grant_lds(c, fn, lds, 64 * 1024)) return -1;

@@ -635,7 +635,13 @@ __device__ __forceinline__ void k2_epilogue(const K2MfmaArgs& a, const double* L
     else k2_epilogue_impl<false, 1>(a, Lbuf, scratch, fam0, out_off, wave, lane, nwaves);
 }
 
-template <int NFT_W, int NRT_W>
+// OBJ (round 6): the instantiation an OBJECTIVE evaluation runs -- no per-row column limits (batch mode: the Monte-Carlo null, the
+// report's per-family ranges) and every error-model leaf folded into the matrices -- carries none of the batch mode's trimming,
+// banded error sums and root-row copies: 54.7 -> 43.2 KB of code and 226 -> 215 registers for k2_prune_mfma4<5, 3>, and the
+// objective walk is 1-6 % faster for it (configs[1] 56.7 -> 55.5 us, test1 32.1 -> 30.2 us, the configs[3] shard 0.990 ->
+// 0.980 ms; profiles/r06/objective_only_walk_ab.txt): these kernels feel their code size (the CU pair's instruction cache is
+// 64 KB).  Same instructions on the same operands for everything an objective evaluation executes: bit-identical.
+template <int NFT_W, int NRT_W, bool OBJ = false>
 __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 {
     extern __shared__ double Lbuf[];                          // [NF][LDv]
@@ -658,8 +664,8 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
     // half so that the waves carrying the odd extra tile do not pile up on the same SIMDs
     const int wr = (wave / a.Wf + ((blockIdx.x >> 8) & 1) * (a.Wr >> 1)) % a.Wr;
     const int ft0 = wf * NFT_W;
-    const bool batch = (a.col_max != nullptr);
-    const bool fold = (a.PTfold != nullptr) && !batch;
+    const bool batch = OBJ ? false : (a.col_max != nullptr);
+    const bool fold = OBJ ? true : ((a.PTfold != nullptr) && !batch);   // (OBJ: the launcher guarantees PTfold wherever a leaf carries the model)
     const size_t park_stride = (size_t)a.NF * a.LDv;
     const int fam0 = blockIdx.x * a.NF;
     k2_wait_for_generation(a, tid);
@@ -908,7 +914,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 // Y[fam_base + 4g + (l>>4)][row0 + (l&15)]: the same walk, gathers and stores as k2_prune_mfma with
 // (i, r) flattened to g = 4i + r.
 // ====================================================================================
-template <int G, int NRT_W, int SMALL_R = 0>   // SMALL_R > 0: lane-per-family epilogue for R <= 64 * SMALL_R
+template <int G, int NRT_W, int SMALL_R = 0, bool OBJ = (SMALL_R > 0)>   // SMALL_R > 0: lane-per-family epilogue for R <= 64 * SMALL_R; OBJ: see k2_prune_mfma
 __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 {
     extern __shared__ double Lbuf[];                          // [NF][LDv]
@@ -931,8 +937,8 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     // half so that the waves carrying the odd extra tile do not pile up on the same SIMDs
     const int wr = (wave / a.Wf + ((blockIdx.x >> 8) & 1) * (a.Wr >> 1)) % a.Wr;
     const int fbase = wf * 4 * G;               // first family of this wave inside the workgroup
-    const bool batch = (a.col_max != nullptr);
-    const bool fold = (a.PTfold != nullptr) && !batch;
+    const bool batch = OBJ ? false : (a.col_max != nullptr);
+    const bool fold = OBJ ? true : ((a.PTfold != nullptr) && !batch);   // (OBJ: the launcher guarantees PTfold wherever a leaf carries the model)
     const size_t park_stride = (size_t)a.NF * a.LDv;
     const int fam0 = blockIdx.x * a.NF;
     k2_wait_for_generation(a, tid);

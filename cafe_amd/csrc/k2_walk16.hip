@@ -5,14 +5,19 @@
 
 namespace cafehip {
 
+#ifndef CAFE_K2_OBJ
+#define CAFE_K2_OBJ false
+#define CAFE_K2_GETTER16 k2_mfma16_kernel
+#endif
+
 template <int NFT_W, int NRT_W>
 static const void* pick16()
 {
-    if constexpr (k2_fits16(NFT_W, NRT_W)) return reinterpret_cast<const void*>(&k2_prune_mfma<NFT_W, NRT_W>);
+    if constexpr (k2_fits16(NFT_W, NRT_W)) return reinterpret_cast<const void*>(&k2_prune_mfma<NFT_W, NRT_W, CAFE_K2_OBJ>);
     else return nullptr;
 }
 
-const void* k2_mfma16_kernel(int nft_w, int nrt_w)
+const void* CAFE_K2_GETTER16(int nft_w, int nrt_w)
 {
 #define CAFE_M16(F, N) if (nft_w == F && nrt_w == N) return pick16<F, N>();
     CAFE_M16(1, 1) CAFE_M16(1, 2) CAFE_M16(1, 3) CAFE_M16(1, 4) CAFE_M16(1, 5) CAFE_M16(1, 6) CAFE_M16(1, 7)

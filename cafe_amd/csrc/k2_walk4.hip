@@ -5,10 +5,15 @@
 
 namespace cafehip {
 
+#ifndef CAFE_K2_OBJ
+#define CAFE_K2_OBJ false
+#define CAFE_K2_GETTER4 k2_mfma4_kernel
+#endif
+
 template <int G, int NRT_W>
 static const void* pick4()
 {
-    if constexpr (k2_fits4(G, NRT_W)) return reinterpret_cast<const void*>(&k2_prune_mfma4<G, NRT_W>);
+    if constexpr (k2_fits4(G, NRT_W)) return reinterpret_cast<const void*>(&k2_prune_mfma4<G, NRT_W, 0, CAFE_K2_OBJ>);
     else return nullptr;
 }
 
@@ -27,7 +32,7 @@ static const void* pick4_nrt(int nrt_w)
     return nullptr;
 }
 
-const void* k2_mfma4_kernel(int G, int nrt_w)
+const void* CAFE_K2_GETTER4(int G, int nrt_w)
 {
     switch (G) {
         case 1: return pick4_nrt<1>(nrt_w);

@@ -23,6 +23,10 @@ constexpr bool k2_fits16(int nft_w, int nrt_w) { return nft_w >= 1 && nft_w <= 2
 constexpr bool k2_fits4(int G, int nrt_w) { return G >= 1 && G <= 7 && nrt_w >= 1 && nrt_w <= 7 && G * nrt_w <= 18; }   // (8, 1): 20 B of scratch
 const void* k2_mfma16_kernel(int nft_w, int nrt_w);
 const void* k2_mfma4_kernel(int G, int nrt_w);
+// k2_walk16o.hip / k2_walk4o.hip: the same kernels without the batch mode's and the unfolded error model's code, for launches
+// with col_max == NULL and (err == NULL or PTfold != NULL): every objective evaluation
+const void* k2_mfma16_objective_kernel(int nft_w, int nrt_w);
+const void* k2_mfma4_objective_kernel(int G, int nrt_w);
 // k2_walk4s.hip: the same walk with the lane-per-family posterior epilogue, R <= 64 and NF <= 96 only (NULL: not instantiated)
 const void* k2_mfma4_small_r_kernel(int G, int nrt_w, int pr = 1);   // pr: R <= 64 * pr (1, 2)
 
