@@ -718,7 +718,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
 #pragma unroll
     for (int i = 0; i < NFT_W; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cmx[i][r] = s_colmax[(ft0 + i) * 16 + lk + 4 * r];
+        for (int r = 0; r < 4; ++r) cmx[i][r] = OBJ ? a.C - 1 : s_colmax[(ft0 + i) * 16 + lk + 4 * r];   // (OBJ: one limit, a scalar)
 
     for (int oi = 0; oi < a.n_ops; ++oi) {
         const cafehip::MfmaOp op = *reinterpret_cast<const cafehip::MfmaOp*>(s_ops + oi * 12);
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma(K2MfmaArgs a)
                     for (int r = 0; r < 4; ++r) {
                         const int f = (ft0 + i) * 16 + lk + 4 * r;
                         const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
-                        const bool ok = from_table || cnt <= cmx[i][r];
+                        const bool ok = OBJ || from_table || cnt <= cmx[i][r];   // (OBJ: counts never exceed the range)
                         // one address per family; the row tiles are constant byte offsets from it
                         const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
@@ -989,7 +989,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
     // this lane's families do not change during the walk: their column limits are read once, not once per step
     int cmx[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) cmx[g] = s_colmax[fbase + 4 * g + lk];
+    for (int g = 0; g < G; ++g) cmx[g] = OBJ ? a.C - 1 : s_colmax[fbase + 4 * g + lk];   // (OBJ: one limit, a scalar)
 
     for (int oi = 0; oi < a.n_ops; ++oi) {
         const cafehip::MfmaOp op = *reinterpret_cast<const cafehip::MfmaOp*>(s_ops + oi * 12);
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
             for (int g = 0; g < G; ++g) {
                 const int f = fbase + 4 * g + lk;
                 const int cnt = s_cnt[f * a.n_leaves + leafcol];
-                const bool ok = pre_table || cnt <= cmx[g];
+                const bool ok = OBJ || pre_table || cnt <= cmx[g];   // (OBJ: counts never exceed the range)
                 // one address per family group; the row tiles are constant byte offsets from it
                 const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
 #pragma unroll
             for (int j = 0; j < NRT_W; ++j) hold[g][j] = 1.0;
         bool first = true;
-#pragma unroll
+#pragma unroll   // (rolled -- one copy of the product code for both children, 43 -> 36 KB -- the kernel spills and the configs[1] walk goes 55 -> 63 us)
         for (int ch = 0; ch < 2; ++ch) {
             if (ch == pre_ch) continue;
             const bool has_err = s_err[oi * 2 + ch] != 0;
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(512) void k2_prune_mfma4(K2MfmaArgs a)
                 for (int g = 0; g < G; ++g) {
                     const int f = fbase + 4 * g + lk;
                     const int cnt = s_cnt[f * a.n_leaves + op.leafcol[ch]];
-                    const bool ok = from_table || cnt <= cmx[g];
+                    const bool ok = OBJ || from_table || cnt <= cmx[g];
                     const double* col = PTe + (size_t)cnt * a.LD + rt0 * 16 + li;
 #pragma unroll
                     for (int j = 0; j < NRT_W; ++j) fac[g][j] = (ok && j < ntile) ? col[j * 16] : 0.0;
