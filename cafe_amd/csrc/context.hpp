@@ -248,6 +248,7 @@ struct cafehip_ctx {
     std::vector<int> node_key;
     std::vector<double> stage_l, stage_m;   // key dedup scratch of stage_params (kept: no allocation per evaluation)
     std::vector<int> stage_b;
+    std::vector<int> stage_node_key;        // mc_stage: a candidate set's node -> slot map until the set is accepted
     std::vector<double> prior_seen, logprior_seen;   // the last prior staged and its logarithms
     int nkeys = 0;
     bool have_matrices = false;

@@ -567,11 +567,12 @@ int mc_stage(cafehip_ctx* c, int n_sets, const double* node_lambda, const double
         const double* nl = node_lambda + (size_t)todo[t] * n;
         const double* nm = node_mu + (size_t)todo[t] * n;
         auto& e = mc.e[victims[t]];
-        if (e.valid) ++mc.evicted;
-        e.valid = false;
         const int base = (int)(mc.first_slot + (size_t)victims[t] * mc.kpe);
         const int nk0 = nk;
-        e.node_key.assign(n, -1);
+        // (the victim is touched only once the set is accepted -- ADVICE r05: a set skipped for its arithmetic form used to
+        // throw a valid entry away for nothing)
+        std::vector<int>& set_keys = c->stage_node_key;
+        set_keys.assign(n, -1);
         bool all_fast = true;
         auto& kl = c->stage_l;   // this set's distinct (lambda, mu) by key, the branch length in the key itself
         auto& km = c->stage_m;
@@ -591,13 +592,16 @@ int mc_stage(cafehip_ctx* c, int n_sets, const double* node_lambda, const double
                 if (keys[k].mode >= 2 && !keys[k].fast_ok) all_fast = false;
                 ++nk;
             }
-            e.node_key[i] = base + (k - nk0);
+            set_keys[i] = base + (k - nk0);
             node_key[(size_t)sets * n + i] = base + (k - nk0);
         }
         if (k1_product_form(c, all_fast) != k1_product_form(c, true)) {
             nk = nk0;   // this set's own evaluation would run another arithmetic form than the launch: built on demand
             continue;
         }
+        if (e.valid) ++mc.evicted;
+        e.valid = false;
+        e.node_key = set_keys;
         e.nl.assign(nl, nl + n);
         e.nm.assign(nm, nm + n);
         e.nkeys = nk - nk0;

@@ -263,3 +263,25 @@ def test_moving_the_matrix_storage_forgets_the_matrices_built_on_demand():
     eng.get_posterior(nl[0], nm[0], prior)
     assert np.array_equal(eng.get_matrix(2), before)
     eng.close()
+
+
+def test_a_set_left_to_the_demand_build_does_not_evict_an_entry():
+    """a candidate whose keys the launch's arithmetic form cannot take (a rate so small that rho^8 leaves the double
+    range: per-term keys in a product-form launch) is skipped by the store -- and must not cost a valid entry its slot: with the
+    store FULL of valid sets, announcing only such a set evicts nothing and every stored set still hits."""
+    eng, tree, rng, prior = _table(F=800, options=(("matrix_cache", 4),))
+    good = [np.full(tree.n_nodes, x) for x in (0.0019, 0.0021, 0.0023, 0.0025)]
+    mu = np.full(tree.n_nodes, -1.0)
+    eng.get_posterior(good[0], mu, prior)
+    eng.prefetch_matrices(np.array(good), np.array([mu] * 4))
+    for g in good:
+        eng.get_posterior(g, mu, prior)
+    before = eng.matrix_cache_stats()
+    eng.prefetch_matrices(np.array([np.full(tree.n_nodes, 1e-9)]), np.array([mu]))
+    after = eng.matrix_cache_stats()
+    assert after["replaced"] == before["replaced"], (before, after)
+    for g in good:
+        eng.get_posterior(g, mu, prior)
+    last = eng.matrix_cache_stats()
+    assert last["hits"] - after["hits"] >= 3, (after, last)   # (the bound entry's own set may be rebuilt on demand)
+    eng.close()
