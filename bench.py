@@ -381,7 +381,8 @@ def roofline_of(leg, F_local):
     roof = {
         "bound": "mfma",
         "kernel": "k2_prune_mfma4 (v_mfma_f64_4x4x4_4b)" if "mfma4x4" in desc else "k2_prune_mfma (v_mfma_f64_16x16x4)",
-        "kernel_does": "the family walk: pruning of all families + posterior in one launch" +
+        "kernel_does": "the family walk (round 6: the objective-only instantiation, k2_walk16o / k2_walk4o.hip -- k2_walk4s.hip where R <= 64): "
+                       "pruning of all families + posterior in one launch" +
                        (" over the REDUCED tree (compressed subtrees are row gathers from factor tables built by "
                         "the k2c_gemm launches just before it: see factor_tables / pruning_total)" if compressed else ""),
         "achieved": achieved,
