@@ -605,6 +605,12 @@ int launch_k2_mfma(cafehip_ctx* c, const K2Args& v1, int n_items, int n_sets = 1
         (void)warm;
     }
     if (tuning_launch) c->tune.reps_launched = reps;
+    {
+        // (probe: CAFEHIP_K2_REPS=2 launches the idempotent walk twice back to back, so that a kernel trace shows what a launch
+        // costs whose code is already in the instruction caches: profiles/r06/walk_warm_icache_probe.txt)
+        static const int extra_reps = [] { const char* e = getenv("CAFEHIP_K2_REPS"); return e ? atoi(e) : 0; }();
+        if (!tuning_launch && extra_reps > 1) reps = extra_reps;
+    }
     int rc = 0;
     for (int rep = 0; rep < reps && rc == 0; ++rep) {
         if (use4) rc = launch_mfma4_g(c, a, k.nft_w, k.nrt_w, grid, block, lds);
