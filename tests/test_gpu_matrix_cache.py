@@ -277,7 +277,8 @@ def test_a_set_left_to_the_demand_build_does_not_evict_an_entry():
     for g in good:
         eng.get_posterior(g, mu, prior)
     before = eng.matrix_cache_stats()
-    eng.prefetch_matrices(np.array([np.full(tree.n_nodes, 1e-9)]), np.array([mu]))
+    # lambda / mu with a denormal mu: alpha ~ 1e-320, coeff / (alpha * beta) is not finite -> no product form for this set
+    eng.prefetch_matrices(np.array([np.full(tree.n_nodes, 0.002)]), np.array([np.full(tree.n_nodes, 1e-320)]))
     after = eng.matrix_cache_stats()
     assert after["replaced"] == before["replaced"], (before, after)
     for g in good:
