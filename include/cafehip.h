@@ -102,6 +102,10 @@ void cafehip_destroy(cafehip_ctx *ctx);
  *   matrix_cache    n          entries of the store of matrices built ahead of time (cafehip_prefetch_matrices; 12, 0: off)
  *   matrix_cache_mb n          ... and its size limit in MiB (1024)
  *   comm            auto|direct|rccl   exchange mode of sharded evaluations (multi-GPU section below)
+ *   k2_objective_kernels 0|1   objective evaluations run the walk instantiations compiled without the batch mode's and the
+ *                              unfolded error model's code (k2_walk16o / k2_walk4o.hip; 1)
+ *   k2_small_r      0|1        4-family walk of a table with at most 64 root sizes: lane-per-family posterior epilogue
+ *                              (k2_walk4s.hip; 1)
  * The same names, upper-cased behind CAFEHIP_ (CAFEHIP_COMPRESS=0 ...), are read from the environment ONCE, by
  * cafehip_create; nothing reads the environment during an evaluation.  Options that change the compression plan
  * rebuild it.  No reference counterpart. */
